@@ -1,0 +1,74 @@
+"""Shared case builders for the oracle fixtures (TEST INFRASTRUCTURE).
+
+Both oracle/gen_golden.py (build container, reference mounted) and tests/ use
+these so the inputs of every golden case are regenerated identically.
+"""
+import os
+import sys
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(os.path.dirname(_HERE), 'spatial-intention-maps_amd')
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from simq import synth  # noqa: E402  (numpy-only helper, no HIP)
+
+from . import fcn, learner  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(_HERE), 'tests', 'golden')
+
+# (name, cin, cout, batch, weight seed, data seed)
+FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), ('fwd_c5o1', 5, 1, 2, 13, 23)]
+TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
+SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
+
+LR, MOMENTUM, WEIGHT_DECAY, CLIP, GAMMA = 0.01, 0.9, 1e-4, 100, 0.75   # base config yml / train.py:186
+
+
+def make_cfg(batch_size, use_double_dqn=True, grad_norm_clipping=CLIP):
+    return SimpleNamespace(batch_size=batch_size, use_double_dqn=use_double_dqn,
+                           grad_norm_clipping=grad_norm_clipping)
+
+
+def oracle_state(cin, cout, seed, dtype=torch.float32):
+    return fcn.state_from_numpy(synth.make_state_dict(cin, cout, seed), dtype)
+
+
+def make_batch(cin, cout, batch, seed):
+    trs = synth.make_transitions(batch, cin, cout, seed, terminal_frac=0.25)
+    return learner.Transition(*zip(*trs))
+
+
+def bn_buffer_vector(state):
+    return np.concatenate([state[k].detach().double().numpy().ravel() for k in state
+                           if k.endswith('running_mean') or k.endswith('running_var')])
+
+
+def sample_indices(numel, n=16):
+    """Deterministic element indices probed inside each gradient tensor."""
+    return [int((i * 2654435761) % numel) for i in range(n)]
+
+
+def grad_summary(grads):
+    """Per-tensor L2 norm + 16 sampled elements (float64 arrays keyed by tensor name)."""
+    out = OrderedDict()
+    for k, g in grads.items():
+        flat = g.detach().double().reshape(-1)
+        idx = torch.tensor(sample_indices(flat.numel()))
+        out[k] = np.concatenate([[float(flat.norm())], flat[idx].numpy()])
+    return out
+
+
+def param_summary(state, spec):
+    """Per-tensor (sum, L2) of every parameter after the optimiser step."""
+    rows = []
+    for k, _, kind in spec:
+        if fcn.is_parameter(kind):
+            t = state[k].detach().double()
+            rows.append([float(t.sum()), float(t.norm())])
+    return np.asarray(rows)

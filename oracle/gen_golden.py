@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the imported reference and write tests/golden/*.npz.
+
+TEST INFRASTRUCTURE.  Run ONLY in the build container (where /root/reference is
+mounted):   python -m oracle.gen_golden
+
+For every case the reference's own code (networks.FCN wrapped in DataParallel as
+policies.py:39 does, train.train, train.ReplayBuffer) is executed on seeded
+inputs and compared BIT-EXACTLY with the oracle restatement; only then are the
+results stored.  The reference source never leaves /root/reference -- fixtures
+hold inputs' seeds and outputs only.
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+if not os.path.isdir(REF):
+    sys.exit('gen_golden: %s not mounted -- fixtures can only be generated in the build container' % REF)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+sys.modules['utils'] = types.ModuleType('utils')                 # train.py:20, used only inside main()
+_tb = types.ModuleType('torch.utils.tensorboard')
+_tb.SummaryWriter = object
+sys.modules['torch.utils.tensorboard'] = _tb                     # train.py:17
+
+import networks as ref_networks  # noqa: E402
+import train as ref_train  # noqa: E402
+
+from oracle import cases, fcn, learner  # noqa: E402
+from oracle import policy as opolicy  # noqa: E402
+from simq import synth  # noqa: E402
+
+
+def ref_net(cin, cout, seed):
+    net = torch.nn.DataParallel(ref_networks.FCN(num_input_channels=cin, num_output_channels=cout))
+    sd = fcn.state_from_numpy(synth.make_state_dict(cin, cout, seed))
+    assert list(sd.keys()) == list(net.state_dict().keys()), 'state_dict key order differs from reference'
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd)
+    return net
+
+
+def assert_same(a, b, what):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    if not torch.equal(a, b):
+        raise AssertionError('oracle != reference for %s (max abs diff %g)' % (what, (a.double() - b.double()).abs().max()))
+
+
+def gen_forward():
+    for name, cin, cout, B, wseed, dseed in cases.FORWARD_CASES:
+        x_hwc = synth.make_states(B, cin, dseed)
+        x = torch.cat([learner.apply_transform(s) for s in x_hwc])
+        out = {}
+        # eval mode
+        net = ref_net(cin, cout, wseed)
+        net.eval()
+        with torch.no_grad():
+            q_ref = net(x)
+        st = cases.oracle_state(cin, cout, wseed)
+        taps = {}
+        with torch.no_grad():
+            q_or = fcn.fcn_forward(st, x, False, taps)
+        assert_same(q_or, q_ref, name + ' eval')
+        out['q_eval'] = q_ref.numpy()
+        for k, t in taps.items():
+            out['tap_eval.' + k] = np.array([float(t.double().mean()), float(t.double().abs().mean()),
+                                             float(t.double().pow(2).mean().sqrt())])
+        # train mode (batch statistics, running-stat update)
+        net = ref_net(cin, cout, wseed)
+        net.train()
+        with torch.no_grad():
+            q_ref = net(x)
+        st = cases.oracle_state(cin, cout, wseed)
+        with torch.no_grad():
+            q_or = fcn.fcn_forward(st, x, True)
+        assert_same(q_or, q_ref, name + ' train')
+        for k, v in net.state_dict().items():
+            assert_same(st[k], v, name + ' train buffer ' + k)
+        out['q_train'] = q_ref.numpy()
+        out['bn_buffers_after'] = cases.bn_buffer_vector(st).astype(np.float32)
+        np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'), **out)
+        print('forward case', name, 'oracle == reference (bit-exact); saved')
+
+
+def gen_train():
+    for name, cin, cout, B, wseed, dseed in cases.TRAIN_CASES:
+        cfg = cases.make_cfg(B)
+        batch = cases.make_batch(cin, cout, B, dseed)
+        spec = fcn.state_spec(cin, cout)
+        # --- reference: two consecutive train() calls (2nd exercises momentum) ---
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM,
+                              weight_decay=cases.WEIGHT_DECAY)                    # train.py:186
+        tf = learner.apply_transform
+        info_ref = [ref_train.train(cfg, policy, target, opt, batch, tf, cases.GAMMA) for _ in range(2)]
+        # --- oracle fp32 ---
+        st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        mom = [None] * len(learner.grad_keys(spec))
+        extras = [{}, {}]
+        info_or = [learner.train_step(cfg, st, tg, spec, mom, batch, cases.GAMMA, cases.LR, cases.MOMENTUM,
+                                      cases.WEIGHT_DECAY, extras=extras[i]) for i in range(2)]
+        for i in range(2):
+            assert info_or[i] == info_ref[i], (name, i, info_or[i], info_ref[i])
+        for k, v in policy.state_dict().items():
+            assert_same(st[k], v, name + ' post-step ' + k)
+        for (k, p), m in zip([(k, p) for k, p in policy.named_parameters() if p.grad is not None], mom):
+            assert_same(m, opt.state[p]['momentum_buffer'], name + ' momentum ' + k)
+        # --- oracle fp64 (the accuracy yardstick for gradients) ---
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        ex64 = {}
+        info64 = learner.train_step(cfg, st64, tg64, spec, [None] * len(mom), batch, cases.GAMMA, cases.LR,
+                                    cases.MOMENTUM, cases.WEIGHT_DECAY, dtype=torch.float64, extras=ex64)
+        out = {
+            'loss': np.array([i['loss'] for i in info_ref]), 'td_error': np.array([i['td_error'] for i in info_ref]),
+            'total_norm': np.array([e['total_norm'] for e in extras]),
+            'q_sa': extras[0]['q'].numpy(), 'y': extras[0]['y'].numpy(),
+            'output_step1': extras[0]['output'].numpy() if B <= 4 else np.zeros(0, np.float32),
+            'param_summary_after2': cases.param_summary(st, spec),
+            'bn_buffers_after2': cases.bn_buffer_vector(st).astype(np.float32),
+            'num_batches_tracked': np.array([int(st[k]) for k in st if k.endswith('num_batches_tracked')]),
+            'loss64': np.array(info64['loss']), 'td_error64': np.array(info64['td_error']),
+            'total_norm64': np.array(ex64['total_norm']),
+        }
+        g32, g64 = cases.grad_summary(extras[0]['grads']), cases.grad_summary(ex64['grads'])
+        out['grad_keys'] = np.array(list(g32.keys()))
+        out['grad32'] = np.stack(list(g32.values()))
+        out['grad64'] = np.stack(list(g64.values()))
+        # global relative L2 error of the reference's own fp32 gradient vs fp64
+        num = sum(float((extras[0]['grads'][k].double() - ex64['grads'][k]).pow(2).sum()) for k in g32)
+        den = sum(float(ex64['grads'][k].pow(2).sum()) for k in g32)
+        out['ref_fp32_grad_relerr'] = np.array((num / den) ** 0.5)
+        np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'), **out)
+        print('train case', name, 'oracle == reference (bit-exact, 2 steps); ref fp32 grad rel err vs fp64 = %.3g'
+              % out['ref_fp32_grad_relerr'])
+
+
+def gen_sampler():
+    out = {}
+    for n, B, seed in cases.SAMPLER_CASES:
+        ref_buf, or_buf = ref_train.ReplayBuffer(n), learner.ReplayBuffer(n)
+        for i in range(n + 3):      # wrap the ring by 3
+            ref_buf.push(i, i, float(i), None)
+            or_buf.push(i, i, float(i), None)
+        assert [t.state for t in ref_buf.buffer] == [t.state for t in or_buf.buffer]
+        assert ref_buf.position == or_buf.position
+        random.seed(seed)
+        a = ref_buf.sample(B)
+        random.seed(seed)
+        b = or_buf.sample(B)
+        assert a == b
+        random.seed(seed)
+        idx = random.sample(range(n), B)   # index-driven form used by the device ring
+        assert [ref_buf.buffer[i].state for i in idx] == list(a.state)
+        out['n%d_b%d_s%d' % (n, B, seed)] = np.array(a.state, dtype=np.int64)
+        out['idx_n%d_b%d_s%d' % (n, B, seed)] = np.array(idx, dtype=np.int64)
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'sampler.npz'), **out)
+    print('sampler cases: oracle == reference; random.sample(range(n),B) reproduces the picks')
+
+
+def gen_step():
+    """policies.py cannot be imported (torchvision/pybullet absent): the step()
+    fixture is produced by the oracle restatement; its network forward is the
+    reference-pinned fcn_forward and its RNG draw order follows policies.py:61-64."""
+    cin, wseed = 4, 51
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], num_input_channels=cin,
+                                final_exploration=0.01)
+    seeds = iter([wseed, wseed + 1])
+    pol = opolicy.DQNPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=5)
+    s = synth.make_states(3, cin, 61)
+    state = [[s[0], None], [s[1]]]
+    acts = []
+    for eps in (0.0, 0.5, 1.0, 0.5):
+        acts.append(pol.step(state, exploration_eps=eps))
+    a, info = pol.step([[None, s[2]], [None]], exploration_eps=0.0, debug=True)
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'policy_step.npz'),
+             actions=np.array([[x[0][0], x[1][0]] for x in acts], dtype=np.int64),
+             debug_action=np.array([a[0][1]], dtype=np.int64), debug_output=info['output'][0][1])
+    print('policy.step case saved (oracle restatement; policies.py not importable here)')
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
+    gen_sampler()
+    gen_forward()
+    gen_step()
+    gen_train()

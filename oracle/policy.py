@@ -1,0 +1,75 @@
+"""Oracle: CPU restatement of the reference DQNPolicy.  TEST INFRASTRUCTURE.
+
+/root/reference/policies.py cannot be imported here (needs torchvision, pybullet,
+anki_vector, skimage), so this follows policies.py:11-74 literally, with the
+three VectorEnv statics it calls replaced by the constants they return:
+  envs.py:2010        Mapper.LOCAL_MAP_PIXEL_WIDTH = 96
+  envs.py:810,1090    NUM_OUTPUT_CHANNELS: pushing 1; lifting/throwing/rescue 2
+  envs.py:374-376     action space = channels * 96 * 96
+"""
+import random
+
+import torch
+
+from . import fcn
+from .learner import apply_transform
+
+STATE_WIDTH = 96
+NUM_OUTPUT_CHANNELS = {'pushing_robot': 1, 'lifting_robot': 2, 'throwing_robot': 2, 'rescue_robot': 2}
+
+
+def get_num_output_channels(robot_type):
+    if robot_type not in NUM_OUTPUT_CHANNELS:
+        raise Exception(robot_type)          # envs.py:1052
+    return NUM_OUTPUT_CHANNELS[robot_type]
+
+
+def get_action_space(robot_type):
+    return get_num_output_channels(robot_type) * STATE_WIDTH * STATE_WIDTH
+
+
+class DQNPolicy:
+    """policies.py:11-74 over functional oracle states.  ``make_state(cin, cout)``
+    supplies each group's initial state dict (the reference draws a fresh random
+    init per build_policy_nets() call; fixtures pass seeded states instead)."""
+
+    def __init__(self, cfg, make_state, train=False, random_seed=None):
+        self.cfg = cfg
+        self.robot_group_types = [next(iter(g.keys())) for g in self.cfg.robot_config]   # policies.py:14
+        self.train = train
+        if random_seed is not None:
+            random.seed(random_seed)                                                      # policies.py:16-17
+        self.num_robot_groups = len(self.robot_group_types)
+        self._make_state = make_state
+        self.policy_nets = self.build_policy_nets()
+
+    def build_policy_nets(self):                                                          # policies.py:35-42
+        nets = []
+        for robot_type in self.robot_group_types:
+            nets.append(self._make_state(self.cfg.num_input_channels, get_num_output_channels(robot_type)))
+        return nets
+
+    def apply_transform(self, s):                                                         # policies.py:44-45
+        return apply_transform(s)
+
+    def step(self, state, exploration_eps=None, debug=False):                             # policies.py:47-74
+        if exploration_eps is None:
+            exploration_eps = self.cfg.final_exploration
+        action = [[None for _ in g] for g in state]
+        output = [[None for _ in g] for g in state]
+        with torch.no_grad():
+            for i, g in enumerate(state):
+                robot_type = self.robot_group_types[i]
+                for j, s in enumerate(g):
+                    if s is not None:
+                        s = self.apply_transform(s)
+                        o = fcn.fcn_forward(self.policy_nets[i], s, False).squeeze(0)     # eval mode, :56,:60
+                        if random.random() < exploration_eps:                             # :61
+                            a = random.randrange(get_action_space(robot_type))            # :62
+                        else:
+                            a = o.view(1, -1).max(1)[1].item()                            # :64
+                        action[i][j] = a
+                        output[i][j] = o.cpu().numpy()
+        if debug:
+            return action, {'output': output}
+        return action

@@ -1,0 +1,28 @@
+"""simq -- MI355X-native spatial-action-map DQN learner (hot path only).
+
+Host-side mirror of the reference's Python interface for the path
+train.py / networks.py / policies.py; the arithmetic lives in hand-written HIP
+kernels behind the C-ABI of ``include/simq.h`` (libsimq.so).  Submodules that
+need torch / the HIP library are imported lazily so that ``simq.arch`` and
+``simq.synth`` stay importable on a bare CPU box.
+"""
+import importlib
+
+_LAZY = {
+    'FCN': ('.fcn', 'FCN'),
+    'DQNPolicy': ('.policy', 'DQNPolicy'),
+    'ReplayBuffer': ('.learner', 'ReplayBuffer'),
+    'DeviceReplayBuffer': ('.learner', 'DeviceReplayBuffer'),
+    'Transition': ('.learner', 'Transition'),
+    'train': ('.learner', 'train'),
+    'train_step': ('.learner', 'train_step'),
+    'Learner': ('.learner', 'Learner'),
+    'lib': ('._lib', 'lib'),
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module(mod, __name__), attr)
+    raise AttributeError(name)

@@ -1,0 +1,121 @@
+"""CPU: the oracle restatement reproduces the committed golden fixtures.
+
+The fixtures were written by oracle/gen_golden.py AFTER a bit-exact comparison
+with the imported reference (build container).  Here (any host, no reference) the
+oracle is re-run and must agree within fp32 round-off -- a different CPU may pick
+different MKL-DNN kernels, so the check is 1e-5 (max-abs / max-abs), not bitwise.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, fcn, learner
+from oracle import policy as opolicy
+from simq import arch, synth
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_state_spec_matches_product_table():
+    for cin, cout in ((4, 2), (5, 1), (10, 2)):
+        assert fcn.state_spec(cin, cout) == arch.state_spec(cin, cout)
+        assert len(fcn.state_spec(cin, cout)) == 138
+        n_grad = sum(int(np.prod(s)) for _, s, k in arch.state_spec(cin, cout) if k in arch.TRAINABLE_KINDS)
+        assert n_grad == {(4, 2): 11249826, (5, 1): 11252929, (10, 2): 11249826 + 6 * 64 * 49}[(cin, cout)]
+
+
+@pytest.mark.parametrize('case', cases.FORWARD_CASES, ids=[c[0] for c in cases.FORWARD_CASES])
+def test_forward_golden(case, golden_dir):
+    name, cin, cout, B, wseed, dseed = case
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    x = torch.cat([learner.apply_transform(s) for s in synth.make_states(B, cin, dseed)])
+    st = cases.oracle_state(cin, cout, wseed)
+    taps = {}
+    with torch.no_grad():
+        q = fcn.fcn_forward(st, x, False, taps)
+    assert rel(q.numpy(), g['q_eval']) < 1e-5
+    for k, t in taps.items():
+        ref = g['tap_eval.' + k]
+        assert abs(float(t.double().abs().mean()) - ref[1]) <= 1e-5 * ref[1]
+    st = cases.oracle_state(cin, cout, wseed)
+    with torch.no_grad():
+        q = fcn.fcn_forward(st, x, True)
+    assert rel(q.numpy(), g['q_train']) < 1e-5
+    assert rel(cases.bn_buffer_vector(st), g['bn_buffers_after']) < 1e-5
+    assert all(int(st[k]) == 1 for k in st if k.endswith('num_batches_tracked'))
+
+
+@pytest.mark.parametrize('case', cases.TRAIN_CASES[:2], ids=[c[0] for c in cases.TRAIN_CASES[:2]])
+def test_train_step_golden(case, golden_dir):
+    name, cin, cout, B, wseed, dseed = case
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
+    st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+    mom = [None] * len(learner.grad_keys(spec))
+    ex = [{}, {}]
+    info = [learner.train_step(cfg, st, tg, spec, mom, batch, cases.GAMMA, cases.LR, cases.MOMENTUM,
+                               cases.WEIGHT_DECAY, extras=ex[i]) for i in range(2)]
+    assert rel([i['loss'] for i in info], g['loss']) < 2e-5
+    assert rel([i['td_error'] for i in info], g['td_error']) < 2e-5
+    assert rel(ex[0]['q'].numpy(), g['q_sa']) < 2e-5
+    assert rel(ex[0]['y'].numpy(), g['y']) < 2e-5
+    # one train() call bumps num_batches_tracked by 2 (train.py:114 + :121) -> 4 after two calls
+    assert (g['num_batches_tracked'] == 4).all()
+    assert all(int(st[k]) == 4 for k in st if k.endswith('num_batches_tracked'))
+    assert all(int(tg[k]) == 0 for k in tg if k.endswith('num_batches_tracked'))
+    assert rel(cases.bn_buffer_vector(st), g['bn_buffers_after2']) < 1e-4
+    # gradient: judged against the fp64 golden relative to the reference's own fp32 error
+    g32 = cases.grad_summary(ex[0]['grads'])
+    num = sum(((g32[k][1:] - g['grad64'][i][1:]) ** 2).sum() for i, k in enumerate(g32))
+    den = sum((g['grad64'][i][1:] ** 2).sum() for i, k in enumerate(g32))
+    ref_err = float(g['ref_fp32_grad_relerr'])
+    assert (num / den) ** 0.5 < max(3 * ref_err, 1e-3)
+    # fc.* never receive a gradient; head conv1/conv2 biases have a ~0 gradient (BN follows)
+    assert not any(k.endswith('fc.weight') or k.endswith('fc.bias') for k in g32)
+    assert g32['module.conv1.bias'][0] < 1e-5 and g32['module.conv2.bias'][0] < 1e-5
+
+
+def test_sampler_golden(golden_dir):
+    g = np.load('%s/sampler.npz' % golden_dir)
+    for n, B, seed in cases.SAMPLER_CASES:
+        buf = learner.ReplayBuffer(n)
+        for i in range(n + 3):
+            buf.push(i, i, float(i), None)
+        assert len(buf) == n and buf.position == 3 % n
+        random.seed(seed)
+        picked = buf.sample(B)
+        assert list(picked.state) == list(g['n%d_b%d_s%d' % (n, B, seed)])
+        random.seed(seed)
+        idx = random.sample(range(n), B)
+        assert idx == list(g['idx_n%d_b%d_s%d' % (n, B, seed)])
+        assert [buf.buffer[i].state for i in idx] == list(picked.state)
+
+
+def test_policy_step_golden(golden_dir):
+    import types
+    g = np.load('%s/policy_step.npz' % golden_dir)
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], num_input_channels=4,
+                                final_exploration=0.01)
+    seeds = iter([51, 52])
+    pol = opolicy.DQNPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=5)
+    s = synth.make_states(3, 4, 61)
+    state = [[s[0], None], [s[1]]]
+    acts = [pol.step(state, exploration_eps=e) for e in (0.0, 0.5, 1.0, 0.5)]
+    assert [[a[0][0], a[1][0]] for a in acts] == g['actions'].tolist()
+    assert all(a[0][1] is None for a in acts)
+    a, info = pol.step([[None, s[2]], [None]], exploration_eps=0.0, debug=True)
+    assert a[0][1] == int(g['debug_action'][0]) and a[1][0] is None
+    assert rel(info['output'][0][1], g['debug_output']) < 1e-5
+    assert int(np.argmax(g['debug_output'].reshape(-1))) == a[0][1]      # first-index argmax, CHW order
+
+
+def test_argmax_first_index_tiebreak():
+    q = torch.zeros(3, 2 * 96 * 96)
+    q[0, 5] = q[0, 9000] = 1.0
+    q[1, 18431] = 2.0
+    assert q.max(1)[1].tolist() == [5, 18431, 0]
