@@ -1,0 +1,143 @@
+/*
+ * simq.h -- C-ABI of libsimq.so: the MI355X (gfx950) implementation of the
+ * spatial-action-map DQN training step of jimmyyhwu/spatial-intention-maps.
+ *
+ * The reference defines NO FFI for this path (it is pure Python over
+ * torch.nn); the boundary it does define is the Python object contract of
+ *   networks.py:6-26    FCN(num_input_channels, num_output_channels).forward
+ *   resnet.py:93-104    ResNet.features
+ *   train.py:108-141    train(cfg, policy_net, target_net, optimizer, batch, ...)
+ *   train.py:28-45      ReplayBuffer.push / sample
+ *   policies.py:47-74   DQNPolicy.step
+ * Each entry point below names the reference lines it replaces.  The Python
+ * mirror of those objects (package `simq`) binds this header with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (simq_last_error() has the
+ *     message, thread-local); no C++ exception crosses the boundary;
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (in the
+ *     Python host: a torch-ROCm tensor's data_ptr()); the library allocates no
+ *     device memory;
+ *   - every launch goes to the hipStream_t passed as `stream` (void* here so the
+ *     header needs no HIP include); calls are asynchronous;
+ *   - activations are NHWC fp32; convolution weights are OHWI fp32 (= [Cout][R][S][Cin]);
+ *     the Q-map output is NCHW [B][Cout][96][96] because the reference's flat
+ *     action index is CHW-ordered (envs.py:858);
+ *   - a plan is immutable after creation and may be shared by streams; workspaces
+ *     carry all mutable state.
+ */
+#ifndef SIMQ_H
+#define SIMQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIMQ_VERSION 100            /* 0.1.0 */
+#define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
+
+/* forward modes of simq_forward */
+#define SIMQ_MODE_EVAL 0            /* BN uses running stats (policies.py:56, train.py:216)          */
+#define SIMQ_MODE_TRAIN 1           /* BN batch stats + running update, activations saved for backward (train.py:114) */
+#define SIMQ_MODE_TRAIN_NOGRAD 2    /* same arithmetic as TRAIN, nothing kept for backward (train.py:121)       */
+
+/* kinds reported by simq_param_tensor_info */
+#define SIMQ_KIND_CONV_W 0
+#define SIMQ_KIND_CONV_B 1
+#define SIMQ_KIND_BN_W 2
+#define SIMQ_KIND_BN_B 3
+
+typedef struct simq_plan simq_plan;
+
+int simq_version(void);
+const char* simq_last_error(void);
+
+/* ---- plan: the network of networks.py:7-14 for (Cin, Cout); replaces FCN.__init__ ---------- */
+int simq_plan_create(int num_input_channels, int num_output_channels, simq_plan** out);
+void simq_plan_destroy(simq_plan* plan);
+
+/* Flat parameter buffer layout.  All tensors that receive a gradient (70 in the
+ * reference; resnet18.fc.* is excluded because features() never uses it) live
+ * in ONE fp32 buffer of simq_param_count() elements, in reference state_dict
+ * order.  Gradients and SGD momentum use identically laid-out buffers.  */
+int64_t simq_param_count(const simq_plan* plan);
+int simq_param_num_tensors(const simq_plan* plan);
+/* name: reference key without the "module." prefix, e.g. "resnet18.layer1.0.conv1.weight".
+ * shape: conv weights report {Cout, R, S, Cin} (OHWI, device layout), vectors {C,1,1,1}.      */
+int simq_param_tensor_info(const simq_plan* plan, int index, char* name, int name_cap,
+                           int64_t* offset, int64_t shape[4], int* kind);
+/* BN running statistics: one fp32 buffer, per BN layer [mean(C) | var(C)], reference order. */
+int64_t simq_bnbuf_count(const simq_plan* plan);
+int simq_bn_num_layers(const simq_plan* plan);
+int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_cap, int64_t* offset, int* channels);
+
+/* Bytes of workspace simq_forward/simq_backward need for `batch` samples. */
+int64_t simq_workspace_bytes(const simq_plan* plan, int batch);
+
+/* ---- FCN.forward (networks.py:16-26) ---------------------------------------------------------
+ * d_x      [batch][96][96][Cin] fp32 NHWC  (== the reference's HWC replay states, stacked)
+ * d_q      [batch][Cout][96][96] fp32 NCHW
+ * d_bnbuf  running stats; updated in place in TRAIN / TRAIN_NOGRAD modes (momentum 0.1,
+ *          unbiased variance), read-only in EVAL.                                            */
+int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, float* d_bnbuf,
+                 const float* d_x, float* d_q, void* d_workspace, void* stream);
+
+/* ---- autograd backward of FCN.forward (loss.backward(), train.py:132) ----------------------------
+ * d_workspace must be the one used by the matching simq_forward(mode=TRAIN) call.
+ * d_dq     [batch][Cout][96][96] upstream gradient (dense).
+ * d_grads  flat gradient buffer (param layout); OVERWRITTEN.                                  */
+int simq_backward(const simq_plan* plan, int batch, const float* d_params, const float* d_dq,
+                  float* d_grads, void* d_workspace, void* stream);
+
+/* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */
+/* flat max / first-index argmax over each row of d_q [rows][n]  (train.py:121,124; policies.py:64) */
+int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream);
+/* d_out[i] = d_q[i][d_index[i]]  (train.py:115,122) */
+int simq_q_gather(const float* d_q, int rows, int n, const int64_t* d_index, float* d_out, void* stream);
+/* next_state_values[nonfinal_pos[i]] = d_values[i]; others 0 (train.py:116,122) */
+int simq_scatter_next_values(const float* d_values, const int32_t* d_nonfinal_pos, int n_nonfinal,
+                             float* d_next_state_values, int batch, void* stream);
+/* y = r + gamma*v ; td = |q_sa - y| ; loss = mean Huber(delta=1) ; dq = one-hot dLoss/dQ
+ * (train.py:115,126-129 and the gradient autograd would deliver to `output`).
+ * grad_scale = 1/global_batch (train.py:129 'mean'; data-parallel ranks pass the GLOBAL batch).
+ * d_out4: {sum Huber, sum |td|, unused, unused} over this rank's rows (host divides).       */
+int simq_td_huber(const float* d_q, int batch, int n, const int64_t* d_action, const float* d_reward,
+                  const float* d_next_state_values, float gamma, float grad_scale,
+                  float* d_q_sa, float* d_y, float* d_td_error, float* d_out4, float* d_dq, void* stream);
+
+/* ---- clip_grad_norm_ + SGD.step (train.py:133-135,186) ----------------------------------------
+ * total_norm = ||g||_2 ; g *= min(1, max_norm/(total_norm+1e-6)) (skipped when max_norm <= 0);
+ * g += wd*p ; m = first_step ? g : momentum*m + g ; p -= lr*m.
+ * d_scratch: >= 16 bytes; receives {double sumsq}.  d_total_norm (may be NULL): 1 float.     */
+int simq_clip_sgd_step(float* d_params, float* d_grads, float* d_momentum, int64_t count,
+                       float max_norm, float lr, float momentum, float weight_decay, int first_step,
+                       void* d_scratch, float* d_total_norm, void* stream);
+
+/* ---- replay minibatch gather (train.py:40-42,109,112) -------------------------------------------
+ * d_ring [capacity][96][96][C] fp32; d_out[i] = d_ring[d_index[i]].                           */
+int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* d_index, int count,
+                       float* d_out, void* stream);
+
+/* layout helpers for callers that hold NCHW tensors (apply_transform, policies.py:44-45) */
+int simq_nchw_to_nhwc(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);
+int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);
+
+/* ---- single-op entry points (unit-test surface; same kernels the plan launches) ------------- */
+int simq_conv2d_fwd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
+                    int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
+                    double* d_stats /* NULL or [2*cout] zeroed */, void* stream);
+int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scratch, float* d_dx,
+                      int batch, int hin, int win, int cin, int cout, int r, int s, int pad, void* stream);
+int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* zeroed by callee */,
+                      int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
+                      void* stream);
+int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream);
+int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMQ_H */

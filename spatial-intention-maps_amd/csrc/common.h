@@ -1,0 +1,108 @@
+// Internal declarations shared by the libsimq translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace simq {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+void set_error(const char* fmt, ...);
+
+#define SIMQ_CHECK_HIP(expr)                                                        \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            simq::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -2;                                                              \
+        }                                                                           \
+    } while (0)
+
+#define SIMQ_CHECK_LAUNCH() SIMQ_CHECK_HIP(hipGetLastError())
+
+#define SIMQ_REQUIRE(cond, ...)             \
+    do {                                    \
+        if (!(cond)) {                      \
+            simq::set_error(__VA_ARGS__);   \
+            return -1;                      \
+        }                                   \
+    } while (0)
+
+// One convolution as an implicit GEMM:  y[M][Cout] = im2col(x)[M][R*S*Cin] * w[Cout][R*S*Cin]^T
+struct ConvGeom {
+    int B, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
+    int M() const { return B * Hout * Wout; }
+    int K() const { return R * S * Cin; }
+};
+
+// Epilogue of the implicit-GEMM kernel:  v = acc (+bias[n]) ; (stats += v, v*v) ;
+// v = v*scale[n]+shift[n] ; v += addend[m][n] ; relu ; store.
+struct ConvEpilogue {
+    const float* bias = nullptr;     // [Cout]
+    double* stats = nullptr;         // [2*Cout] sum | sumsq (atomically accumulated)
+    const float* scale = nullptr;    // [Cout] (folded BN, eval mode)
+    const float* shift = nullptr;    // [Cout]
+    const float* addend = nullptr;   // [M][Cout] (may alias the output)
+    int relu = 0;
+};
+
+int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
+                      hipStream_t stream);
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
+// wt[ci][R*S-1-t][co] = w[co][t][ci]
+int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, hipStream_t stream);
+
+// ---- channel-last elementwise / reduction kernels (elementwise.hip) -------------------------------
+// BN finalize.  train: mean/var from stats[2C] over `rows`, running update, writes scale/shift/mean/invstd.
+int launch_bn_finalize_train(const double* stats, int C, int64_t rows, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* scale, float* shift,
+                             float* save_mean, float* save_invstd, hipStream_t stream);
+int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float* scale, float* shift, hipStream_t stream);
+// out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
+int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res,
+                    const float* rscale, const float* rshift, int relu, float* out, int64_t rows, int C,
+                    hipStream_t stream);
+// stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
+int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx,
+                         int B, int H, int W, int C, hipStream_t stream);
+// dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
+int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
+                         int C, hipStream_t stream);
+// BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat
+int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean,
+                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream);
+// dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
+int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
+                        const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
+                        float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream);
+// out[c] = sum_rows x[r][c]   (conv bias gradient)
+int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
+int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream);
+int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream);
+int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t stream);
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t stream);
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t stream);
+
+// ---- head conv3 (32 -> Cout<=4, NHWC in, NCHW out) (head.hip) ----------------------------------------
+int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, float* q, int B, int HW, int Cin,
+                          int Cout, hipStream_t stream);
+int launch_head_conv3_bwd(const float* x, const float* w, const float* dq, float* dx, float* dw, float* dbias,
+                          int B, int HW, int Cin, int Cout, hipStream_t stream);
+
+// ---- learner kernels (learner.hip) -------------------------------------------------------------------
+int launch_q_argmax(const float* q, int rows, int n, int64_t* index, float* maxv, hipStream_t stream);
+int launch_q_gather(const float* q, int rows, int n, const int64_t* index, float* out, hipStream_t stream);
+int launch_scatter_next_values(const float* values, const int32_t* pos, int n, float* nsv, int batch,
+                               hipStream_t stream);
+int launch_td_huber(const float* q, int batch, int n, const int64_t* action, const float* reward,
+                    const float* nsv, float gamma, float grad_scale, float* q_sa, float* y, float* td,
+                    float* out4, float* dq, hipStream_t stream);
+int launch_clip_sgd(float* p, float* g, float* m, int64_t count, float max_norm, float lr, float momentum,
+                    float wd, int first_step, void* scratch, float* total_norm, hipStream_t stream);
+int launch_replay_gather(const float* ring, int64_t item_floats, const int64_t* index, int count, float* out,
+                         hipStream_t stream);
+
+}  // namespace simq

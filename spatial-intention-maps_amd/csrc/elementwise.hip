@@ -1,0 +1,465 @@
+// Channel-last (NHWC) elementwise and per-channel reduction kernels for gfx950.
+// All are HBM-bound: 16-B vector accesses along C, grid-stride, fp64 only for the
+// cross-block combination of per-channel sums.
+//
+// Reference operators replaced (PyTorch modules used by networks.py / resnet.py):
+//   nn.BatchNorm2d train/eval forward + backward   resnet.py:24,27,57,82 ; networks.py:11,13
+//   nn.ReLU / residual add                          resnet.py:25,44-45
+//   nn.MaxPool2d(3, 2, 1) forward + backward        resnet.py:59
+//   F.interpolate(x2, bilinear, align_corners=True) networks.py:21,25 (+ backward)
+//   ToTensor HWC->CHW of policies.py:44-45 (layout helpers)
+#include "common.h"
+
+namespace simq {
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+constexpr double BN_MOMENTUM = 0.1;
+
+__global__ void bn_finalize_train_kernel(const double* __restrict__ stats, int C, double rows,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* running_mean, float* running_var, float* scale, float* shift,
+                                         float* save_mean, float* save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = stats[c] / rows;
+    double var = stats[C + c] / rows - mean * mean;     // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)BN_EPS);
+    float sc = (float)((double)gamma[c] * invstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+    running_mean[c] = (float)(BN_MOMENTUM * mean + (1.0 - BN_MOMENTUM) * (double)running_mean[c]);
+    running_var[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)running_var[c]);
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ running_mean,
+                                        const float* __restrict__ running_var, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double invstd = 1.0 / sqrt((double)running_var[c] + (double)BN_EPS);
+    scale[c] = (float)((double)gamma[c] * invstd);
+    shift[c] = (float)((double)beta[c] - (double)running_mean[c] * (double)gamma[c] * invstd);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 s, float4 t) {
+    return make_float4(fmaf(a.x, s.x, t.x), fmaf(a.y, s.y, t.y), fmaf(a.z, s.z, t.z), fmaf(a.w, s.w, t.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 relu4(float4 a) {
+    return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+}
+
+// out = [relu]( y*scale+shift [+ res | + res*rscale+rshift] ), one float4 per thread-iteration
+__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ res,
+                                const float* __restrict__ rscale, const float* __restrict__ rshift, int relu,
+                                float* __restrict__ out, size_t total4, int C4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4) * 4;
+        float4 v = fma4(ld4(y + i * 4), ld4(scale + c), ld4(shift + c));
+        if (res) {
+            float4 r = ld4(res + i * 4);
+            if (rscale) r = fma4(r, ld4(rscale + c), ld4(rshift + c));
+            v = add4(v, r);
+        }
+        if (relu) v = relu4(v);
+        st4(out + i * 4, v);
+    }
+}
+
+// stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
+__global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ pooled,
+                                     uint8_t* __restrict__ idx, int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        int px = (int)(r % Wo); r /= Wo;
+        int py = (int)(r % Ho);
+        int b = (int)(r / Ho);
+        float4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            int iy = 2 * py - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                int ix = 2 * px - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                float4 v = relu4(fma4(ld4(y + (((size_t)b * H + iy) * W + ix) * C4 * 4 + c4 * 4), sc, sh));
+                unsigned char s = (unsigned char)(dy * 3 + dx);
+                if (v.x > best.x) { best.x = v.x; bi.x = s; }
+                if (v.y > best.y) { best.y = v.y; bi.y = s; }
+                if (v.z > best.z) { best.z = v.z; bi.z = s; }
+                if (v.w > best.w) { best.w = v.w; bi.w = s; }
+            }
+        }
+        st4(pooled + i * 4, best);
+        *reinterpret_cast<uchar4*>(idx + i * 4) = bi;
+    }
+}
+
+// gather form of maxpool backward fused with the ReLU mask: dz at HxW from g at (H/2)x(W/2)
+__global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pooled,
+                                     const uint8_t* __restrict__ idx, float* __restrict__ dz, int B, int H, int W,
+                                     int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    size_t total = (size_t)B * H * W * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        int x = (int)(r % W); r /= W;
+        int yy = (int)(r % H);
+        int b = (int)(r / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows (py, dy) with 2*py - 1 + dy == yy
+        int py0 = yy >> 1, ny = (yy & 1) ? 2 : 1;
+        int px0 = x >> 1, nx = (x & 1) ? 2 : 1;
+        for (int a = 0; a < ny; ++a) {
+            int py = py0 + a;
+            if (py >= Ho) continue;
+            int dy = yy - 2 * py + 1;
+            for (int e = 0; e < nx; ++e) {
+                int px = px0 + e;
+                if (px >= Wo) continue;
+                int dx = x - 2 * px + 1;
+                unsigned char s = (unsigned char)(dy * 3 + dx);
+                size_t o = ((((size_t)b * Ho + py) * Wo + px) * C4 + c4) * 4;
+                uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
+                float4 pv = ld4(pooled + o), gv = ld4(g + o);
+                if (bi.x == s && pv.x > 0.f) acc.x += gv.x;
+                if (bi.y == s && pv.y > 0.f) acc.y += gv.y;
+                if (bi.z == s && pv.z > 0.f) acc.z += gv.z;
+                if (bi.w == s && pv.w > 0.f) acc.w += gv.w;
+            }
+        }
+        st4(dz + i * 4, acc);
+    }
+}
+
+// per-channel reductions over rows: threads = [rowlanes][C4]; block partials -> fp64 atomics
+template <int MODE>   // 0: bn backward (sum dz, sum dz*xhat)   1: plain column sum
+__global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, double* red, size_t rows,
+                                                          int C4) {
+    __shared__ double sm[256 * 8];
+    const int tid = threadIdx.x;
+    const int rowlanes = 256 / C4;
+    const int c4 = tid % C4, rl = tid / C4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < rowlanes) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (MODE == 0) { mu = ld4(mean + c4 * 4); is = ld4(invstd + c4 * 4); }
+        for (size_t r = (size_t)blockIdx.x * rowlanes + rl; r < rows; r += (size_t)gridDim.x * rowlanes) {
+            size_t o = (r * C4 + c4) * 4;
+            float4 dz = ld4(g + o);
+            if (MODE == 0) {
+                if (mask) {
+                    float4 m = ld4(mask + o);
+                    dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
+                    dz.z = m.z > 0.f ? dz.z : 0.f; dz.w = m.w > 0.f ? dz.w : 0.f;
+                }
+                float4 yv = ld4(y + o);
+                t.x += dz.x * ((yv.x - mu.x) * is.x); t.y += dz.y * ((yv.y - mu.y) * is.y);
+                t.z += dz.z * ((yv.z - mu.z) * is.z); t.w += dz.w * ((yv.w - mu.w) * is.w);
+            }
+            s = add4(s, dz);
+        }
+    }
+    double* my = sm + tid * 8;
+    my[0] = s.x; my[1] = s.y; my[2] = s.z; my[3] = s.w;
+    my[4] = t.x; my[5] = t.y; my[6] = t.z; my[7] = t.w;
+    __syncthreads();
+    if (tid < C4) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < rowlanes; ++l)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += sm[(l * C4 + tid) * 8 + k];
+        const int C = C4 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(red + tid * 4 + k, a[k]);
+            if (MODE == 0) unsafeAtomicAdd(red + C + tid * 4 + k, a[4 + k]);
+        }
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ red, float* __restrict__ dy,
+                                    float* __restrict__ dz_out, float* dgamma, float* dbeta, size_t rows, int C4) {
+    const int C = C4 * 4;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dbeta[c] = (float)red[c];
+            dgamma[c] = (float)red[C + c];
+        }
+    }
+    const float inv_rows = (float)(1.0 / (double)rows);
+    size_t total4 = rows * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4) * 4;
+        float4 dz = ld4(g + i * 4);
+        if (mask) {
+            float4 m = ld4(mask + i * 4);
+            dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
+            dz.z = m.z > 0.f ? dz.z : 0.f; dz.w = m.w > 0.f ? dz.w : 0.f;
+        }
+        if (dz_out) st4(dz_out + i * 4, dz);
+        float4 yv = ld4(y + i * 4), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
+        float db[4] = {(float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]};
+        float dg[4] = {(float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]};
+        float4 o;
+        o.x = ga.x * is.x * (dz.x - db[0] * inv_rows - (yv.x - mu.x) * is.x * dg[0] * inv_rows);
+        o.y = ga.y * is.y * (dz.y - db[1] * inv_rows - (yv.y - mu.y) * is.y * dg[1] * inv_rows);
+        o.z = ga.z * is.z * (dz.z - db[2] * inv_rows - (yv.z - mu.z) * is.z * dg[2] * inv_rows);
+        o.w = ga.w * is.w * (dz.w - db[3] * inv_rows - (yv.w - mu.w) * is.w * dg[3] * inv_rows);
+        st4(dy + i * 4, o);
+    }
+}
+
+__global__ void colsum_finish_kernel(const double* __restrict__ red, float* out, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (float)red[c];
+}
+
+// bilinear x2, align_corners=True (ATen upsample_bilinear2d semantics: float source index, lambda clamp)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_coord(int o, int in_size, float scale) {
+    float real = scale * (float)o;
+    int i0 = (int)real;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    int off = (i0 < in_size - 1) ? 1 : 0;
+    float l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    Lerp r;
+    r.i0 = i0; r.i1 = i0 + off; r.l1 = l1; r.l0 = 1.f - l1;
+    return r;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                      int C4) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        int ox = (int)(r % Wo); r /= Wo;
+        int oy = (int)(r % Ho);
+        int b = (int)(r / Ho);
+        Lerp ly = lerp_coord(oy, H, sy), lx = lerp_coord(ox, W, sx);
+        const float* base = in + (size_t)b * H * W * C4 * 4 + c4 * 4;
+        float4 v00 = ld4(base + ((size_t)ly.i0 * W + lx.i0) * C4 * 4), v01 = ld4(base + ((size_t)ly.i0 * W + lx.i1) * C4 * 4);
+        float4 v10 = ld4(base + ((size_t)ly.i1 * W + lx.i0) * C4 * 4), v11 = ld4(base + ((size_t)ly.i1 * W + lx.i1) * C4 * 4);
+        float4 o;
+        o.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+        o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+        o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+        o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        st4(out + i * 4, o);
+    }
+}
+
+// transpose of the above as a gather: din[iy][ix] = sum over outputs that interpolate from (iy, ix)
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
+                                      int C4) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+    size_t total = (size_t)B * H * W * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        int ix = (int)(r % W); r /= W;
+        int iy = (int)(r % H);
+        int b = (int)(r / H);
+        // candidate outputs: source index in (iy-1, iy+1)  ->  o in ((iy-1)/s, (iy+1)/s), padded by 1
+        int oy_lo = max(0, (int)floorf((float)(iy - 1) / sy) - 1), oy_hi = min(Ho - 1, (int)ceilf((float)(iy + 1) / sy) + 1);
+        int ox_lo = max(0, (int)floorf((float)(ix - 1) / sx) - 1), ox_hi = min(Wo - 1, (int)ceilf((float)(ix + 1) / sx) + 1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            Lerp ly = lerp_coord(oy, H, sy);
+            float wy = (ly.i0 == iy ? ly.l0 : 0.f) + (ly.i1 == iy ? ly.l1 : 0.f);
+            if (ly.i0 == ly.i1 && ly.i0 == iy) wy = ly.l0 + ly.l1;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                Lerp lx = lerp_coord(ox, W, sx);
+                float wx = (lx.i0 == ix ? lx.l0 : 0.f) + (lx.i1 == ix ? lx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                float4 gv = ld4(dout + ((((size_t)b * Ho + oy) * Wo + ox) * C4 + c4) * 4);
+                float w = wy * wx;
+                acc.x += w * gv.x; acc.y += w * gv.y; acc.z += w * gv.z; acc.w += w * gv.w;
+            }
+        }
+        st4(din + i * 4, acc);
+    }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        st4(dst + i * 4, add4(ld4(dst + i * 4), ld4(src + i * 4)));
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / HW, p = i - b * HW;
+        for (int c = 0; c < C; ++c) out[i * C + c] = in[(b * C + c) * HW + p];
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int HW) {
+    size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / HW, p = i - b * HW;
+        for (int c = 0; c < C; ++c) out[(b * C + c) * HW + p] = in[i * C + c];
+    }
+}
+
+inline int grid_for(size_t work_items, int block = 256, int cap = 256 * 8) {
+    size_t b = (work_items + block - 1) / block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+int launch_bn_finalize_train(const double* stats, int C, int64_t rows, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* scale, float* shift,
+                             float* save_mean, float* save_invstd, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, stats, C, (double)rows,
+                       gamma, beta, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float* scale, float* shift, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, C, gamma, beta,
+                       running_mean, running_var, scale, shift);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rscale,
+                    const float* rshift, int relu, float* out, int64_t rows, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
+    size_t total4 = (size_t)rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, scale, shift, res, rscale,
+                       rshift, relu, out, total4, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, int B,
+                         int H, int W, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "stem_pool: bad shape");
+    size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, scale, shift, pooled, idx,
+                       B, H, W, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
+                         int C, hipStream_t stream) {
+    size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, pooled, idx, dz, B, H, W,
+                       C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+static int reduce_grid(int64_t rows, int C4) {
+    int rowlanes = 256 / C4;
+    int64_t blocks = (rows + (int64_t)rowlanes * 8 - 1) / ((int64_t)rowlanes * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
+                         double* red, int64_t rows, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "bn_bwd_reduce: C=%d unsupported", C);
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, g, mask, y, mean,
+                       invstd, red, (size_t)rows, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
+                        const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
+                        int64_t rows, int C, hipStream_t stream) {
+    size_t total4 = (size_t)rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, y, mean, invstd,
+                       gamma, red, dy, dz_out, dgamma, dbeta, (size_t)rows, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
+    SIMQ_CHECK_HIP(hipMemsetAsync(red_scratch, 0, sizeof(double) * C, stream));
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, x, nullptr, nullptr,
+                       nullptr, nullptr, red_scratch, (size_t)rows, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return launch_colsum_finish(red_scratch, out, C, stream);
+}
+
+int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, out, C);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
+    size_t total = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out, B, H, W, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
+    size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dout, din, B, H, W, C / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t stream) {
+    SIMQ_REQUIRE(n % 4 == 0, "add_inplace: n must be a multiple of 4");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for((size_t)n / 4)), dim3(256), 0, stream, dst, src, (size_t)n / 4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, stream, in, out, B, C, HW);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, stream, in, out, B, C, HW);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace simq

@@ -1,0 +1,490 @@
+// libsimq: plan (network description + buffer layout) and the forward / backward executors.
+//
+// The plan restates the module tree of the reference Q-network
+//   networks.py:7-14   FCN.__init__        (head: 1x1 convs + BN + bilinear x2)
+//   resnet.py:52-91    ResNet.__init__     (7x7 s2 stem, maxpool, 4 x 2 BasicBlocks, strides removed)
+// as a flat list of convolution / BatchNorm descriptors over ONE fp32 parameter buffer, and
+// walks it with the HIP kernels of this directory:
+//   simq_forward   == FCN.forward (networks.py:16-26) in eval / train / train-no-grad mode
+//   simq_backward  == the autograd graph torch builds for it (loss.backward(), train.py:132)
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/simq.h"
+#include "common.h"
+
+namespace simq {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+struct ConvL {
+    std::string name;
+    int64_t w_off = -1, b_off = -1;   // into the flat parameter buffer
+    int64_t wt_off = -1;              // into the transposed-weight scratch (dgrad), -1: no dgrad
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
+    int64_t wcount() const { return (int64_t)cout * k * k * cin; }
+};
+
+struct BnL {
+    std::string name;
+    int64_t g_off = -1, b_off = -1;   // gamma / beta in the flat parameter buffer
+    int64_t buf_off = -1;             // running mean | var in the bn buffer
+    int64_t aux_off = -1;             // per-forward scale|shift|mean|invstd (4*C floats) in the workspace aux area
+    int64_t red_off = -1;             // fp64 [2*C] reduction slot (stats fwd / dbeta,dgamma bwd)
+    int C = 0;
+};
+
+struct BlockL {
+    ConvL c1, c2, ds;
+    BnL b1, b2, bds;
+    bool has_ds = false;
+    int cin = 0, planes = 0;
+};
+
+struct TensorInfo { std::string name; int64_t off; int64_t shape[4]; int kind; };
+
+}  // namespace simq
+
+using namespace simq;
+
+struct simq_plan {
+    int cin, cout;
+    ConvL stem, h1, h2, h3;
+    BnL stem_bn, hb1, hb2;
+    BlockL blocks[8];
+    std::vector<TensorInfo> tensors;
+    std::vector<BnL*> bns;
+    int64_t nparams = 0, nbnbuf = 0, wt_total = 0, aux_total = 0, red_total = 0;
+};
+
+namespace {
+
+struct Builder {
+    simq_plan* p;
+    void conv(ConvL& c, const std::string& name, int cin, int cout, int k, int stride, int pad, bool bias, bool dgrad) {
+        c.name = name; c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad;
+        c.w_off = p->nparams;
+        p->tensors.push_back({name + ".weight", c.w_off, {cout, k, k, cin}, SIMQ_KIND_CONV_W});
+        p->nparams += c.wcount();
+        if (bias) {
+            c.b_off = p->nparams;
+            p->tensors.push_back({name + ".bias", c.b_off, {cout, 1, 1, 1}, SIMQ_KIND_CONV_B});
+            p->nparams += cout;
+        }
+        if (dgrad) { c.wt_off = p->wt_total; p->wt_total += c.wcount(); }
+    }
+    void bn(BnL& b, const std::string& name, int C) {
+        b.name = name; b.C = C;
+        b.g_off = p->nparams; p->tensors.push_back({name + ".weight", b.g_off, {C, 1, 1, 1}, SIMQ_KIND_BN_W}); p->nparams += C;
+        b.b_off = p->nparams; p->tensors.push_back({name + ".bias", b.b_off, {C, 1, 1, 1}, SIMQ_KIND_BN_B}); p->nparams += C;
+        b.buf_off = p->nbnbuf; p->nbnbuf += 2 * C;
+        b.aux_off = p->aux_total; p->aux_total += 4 * C;
+        b.red_off = p->red_total; p->red_total += 2 * C;
+        p->bns.push_back(&b);
+    }
+};
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// Workspace layout for a given batch (byte offsets, 256-B aligned).
+struct Layout {
+    int64_t x, y0, pooled, idx;
+    struct Blk { int64_t y1, a1, y2, yd, out; } blk[8];
+    int64_t yh1, ah1, up1, yh2, ah2, up2;
+    int64_t aux, red, wt, colsum;
+    int64_t S[4];
+    int64_t total;
+};
+
+Layout make_layout(const simq_plan* p, int B) {
+    Layout L;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+    const int64_t f = sizeof(float);
+    L.x = take((int64_t)B * 96 * 96 * p->cin * f);
+    L.y0 = take((int64_t)B * 48 * 48 * 64 * f);
+    L.pooled = take((int64_t)B * 576 * 64 * f);
+    L.idx = take((int64_t)B * 576 * 64);
+    for (int i = 0; i < 8; ++i) {
+        const int64_t n = (int64_t)B * 576 * p->blocks[i].planes * f;
+        L.blk[i].y1 = take(n); L.blk[i].a1 = take(n); L.blk[i].y2 = take(n);
+        L.blk[i].yd = p->blocks[i].has_ds ? take(n) : -1;
+        L.blk[i].out = take(n);
+    }
+    L.yh1 = take((int64_t)B * 576 * 128 * f); L.ah1 = take((int64_t)B * 576 * 128 * f);
+    L.up1 = take((int64_t)B * 2304 * 128 * f);
+    L.yh2 = take((int64_t)B * 2304 * 32 * f); L.ah2 = take((int64_t)B * 2304 * 32 * f);
+    L.up2 = take((int64_t)B * 9216 * 32 * f);
+    L.aux = take(p->aux_total * f);
+    L.red = take(p->red_total * (int64_t)sizeof(double));
+    L.wt = take(p->wt_total * f);
+    L.colsum = take(512 * sizeof(double));
+    const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
+    for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
+    L.total = off;
+    return L;
+}
+
+struct Ctx {
+    const simq_plan* p;
+    int B;
+    const float* params;
+    float* grads;
+    float* bnbuf;
+    char* ws;
+    Layout L;
+    hipStream_t stream;
+    float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
+    float* aux(const BnL& b, int which) const { return f(L.aux) + b.aux_off + (int64_t)which * b.C; }   // 0 scale 1 shift 2 mean 3 invstd
+    double* red(const BnL& b) const { return reinterpret_cast<double*>(ws + L.red) + b.red_off; }
+};
+
+ConvGeom geom(const ConvL& c, int B, int hin) {
+    ConvGeom g;
+    g.B = B; g.Hin = hin; g.Win = hin; g.Cin = c.cin; g.Cout = c.cout; g.R = c.k; g.S = c.k; g.stride = c.stride; g.pad = c.pad;
+    g.Hout = (hin + 2 * c.pad - c.k) / c.stride + 1; g.Wout = g.Hout;
+    return g;
+}
+
+// conv (+bias) with train-mode statistics or plain; then BN finalize for the mode
+int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const float* x, float* y, int hin) {
+    ConvGeom g = geom(cv, c.B, hin);
+    ConvEpilogue e;
+    if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
+    if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
+    int rc = launch_conv_igemm(x, c.params + cv.w_off, y, g, e, c.stream);
+    if (rc) return rc;
+    if (mode != SIMQ_MODE_EVAL)
+        return launch_bn_finalize_train(c.red(bn), bn.C, (int64_t)g.M(), c.params + bn.g_off, c.params + bn.b_off,
+                                        c.bnbuf + bn.buf_off, c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1),
+                                        c.aux(bn, 2), c.aux(bn, 3), c.stream);
+    return launch_bn_finalize_eval(bn.C, c.params + bn.g_off, c.params + bn.b_off, c.bnbuf + bn.buf_off,
+                                   c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1), c.stream);
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
+    const simq_plan* p = c.p;
+    const Layout& L = c.L;
+    const int B = c.B;
+    SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+    if (mode != SIMQ_MODE_EVAL)
+        SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
+    // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97)
+    RC(conv_bn(c, p->stem, p->stem_bn, mode, c.f(L.x), c.f(L.y0), 96));
+    RC(launch_stem_pool_fwd(c.f(L.y0), c.aux(p->stem_bn, 0), c.aux(p->stem_bn, 1), c.f(L.pooled),
+                            reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream));
+    const float* cur = c.f(L.pooled);
+    const int64_t rows = (int64_t)B * 576;
+    for (int i = 0; i < 8; ++i) {   // BasicBlock.forward, resnet.py:31-47
+        const BlockL& b = p->blocks[i];
+        const Layout::Blk& o = L.blk[i];
+        RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
+        RC(launch_bn_apply(c.f(o.y1), c.aux(b.b1, 0), c.aux(b.b1, 1), nullptr, nullptr, nullptr, 1, c.f(o.a1), rows, b.planes, c.stream));
+        RC(conv_bn(c, b.c2, b.b2, mode, c.f(o.a1), c.f(o.y2), 24));
+        if (b.has_ds) {
+            RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
+            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), c.f(o.yd), c.aux(b.bds, 0), c.aux(b.bds, 1), 1,
+                               c.f(o.out), rows, b.planes, c.stream));
+        } else {
+            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), cur, nullptr, nullptr, 1, c.f(o.out), rows, b.planes, c.stream));
+        }
+        cur = c.f(o.out);
+    }
+    // head, networks.py:18-26
+    RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
+    RC(launch_bn_apply(c.f(L.yh1), c.aux(p->hb1, 0), c.aux(p->hb1, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
+    RC(launch_upsample2x_fwd(c.f(L.ah1), c.f(L.up1), B, 24, 24, 128, c.stream));
+    RC(conv_bn(c, p->h2, p->hb2, mode, c.f(L.up1), c.f(L.yh2), 48));
+    RC(launch_bn_apply(c.f(L.yh2), c.aux(p->hb2, 0), c.aux(p->hb2, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
+    RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
+    RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
+    return 0;
+}
+
+// BatchNorm backward (train mode) fused with the ReLU mask of the activation that followed it.
+int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, float* dy, float* dz_out, int64_t rows) {
+    RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
+    return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy, dz_out,
+                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream);
+}
+
+int conv_wgrad(const Ctx& c, const ConvL& cv, const float* x, const float* dy, int hin) {
+    return launch_conv_wgrad(x, dy, c.grads + cv.w_off, geom(cv, c.B, hin), c.stream);
+}
+
+// dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
+int conv_dgrad(const Ctx& c, const ConvL& cv, const float* dy, float* dx, const float* addend, int hin) {
+    ConvGeom g;
+    g.B = c.B; g.Hin = hin; g.Win = hin; g.Cin = cv.cout; g.Cout = cv.cin; g.Hout = hin; g.Wout = hin;
+    g.R = cv.k; g.S = cv.k; g.stride = 1; g.pad = cv.k - 1 - cv.pad;
+    ConvEpilogue e;
+    e.addend = addend;
+    return launch_conv_igemm(dy, c.f(c.L.wt) + cv.wt_off, dx, g, e, c.stream);
+}
+
+int backward_impl(const Ctx& c, const float* d_dq) {
+    const simq_plan* p = c.p;
+    const Layout& L = c.L;
+    const int B = c.B;
+    SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
+    SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
+    // flipped / transposed weights for every convolution that needs a data gradient
+    auto wt = [&](const ConvL& cv) {
+        return launch_weight_transpose(c.params + cv.w_off, c.f(L.wt) + cv.wt_off, cv.cout, cv.k * cv.k, cv.cin, c.stream);
+    };
+    for (int i = 0; i < 8; ++i) {
+        RC(wt(p->blocks[i].c1)); RC(wt(p->blocks[i].c2));
+        if (p->blocks[i].has_ds) RC(wt(p->blocks[i].ds));
+    }
+    RC(wt(p->h1)); RC(wt(p->h2));
+    float* S[4] = {c.f(L.S[0]), c.f(L.S[1]), c.f(L.S[2]), c.f(L.S[3])};
+    double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
+    // ---- head (networks.py:18-26 reversed) ----
+    RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
+    RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
+    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), S[0], nullptr, (int64_t)B * 2304));
+    RC(launch_colsum(S[0], cs, c.grads + p->h2.b_off, (int64_t)B * 2304, 32, c.stream));
+    RC(conv_wgrad(c, p->h2, c.f(L.up1), S[0], 48));
+    RC(conv_dgrad(c, p->h2, S[0], S[1], nullptr, 48));
+    RC(launch_upsample2x_bwd(S[1], S[2], B, 24, 24, 128, c.stream));
+    const int64_t rows = (int64_t)B * 576;
+    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), S[0], nullptr, rows));
+    RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
+    RC(conv_wgrad(c, p->h1, c.f(L.blk[7].out), S[0], 24));
+    RC(conv_dgrad(c, p->h1, S[0], S[1], nullptr, 24));
+    int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
+    for (int i = 7; i >= 0; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
+        const BlockL& b = p->blocks[i];
+        const Layout::Blk& o = L.blk[i];
+        const float* xin = i == 0 ? c.f(L.pooled) : c.f(L.blk[i - 1].out);
+        float* G = S[gi];
+        float* T0 = S[(gi + 1) & 3];
+        float* T1 = S[(gi + 2) & 3];
+        float* T2 = S[(gi + 3) & 3];
+        // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
+        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1, rows));
+        if (b.has_ds) RC(bn_bwd(c, b.bds, G, c.f(o.out), c.f(o.yd), T1, nullptr, rows));
+        RC(conv_wgrad(c, b.c2, c.f(o.a1), T0, 24));
+        RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24));
+        RC(bn_bwd(c, b.b1, T2, c.f(o.a1), c.f(o.y1), T0, nullptr, rows));
+        RC(conv_wgrad(c, b.c1, xin, T0, 24));
+        if (b.has_ds) {
+            RC(conv_wgrad(c, b.ds, xin, T1, 24));
+            RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24));
+            RC(conv_dgrad(c, b.c1, T0, G, G, 24));
+        } else {
+            RC(conv_dgrad(c, b.c1, T0, G, T1, 24));
+        }
+        // G (same buffer) now holds the gradient w.r.t. the block input
+    }
+    // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient ----
+    float* G = S[gi];
+    float* T0 = S[(gi + 1) & 3];
+    float* T1 = S[(gi + 2) & 3];
+    RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream));
+    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304));
+    RC(conv_wgrad(c, p->stem, c.f(L.x), T1, 96));
+    return 0;
+}
+
+int copy_name(const std::string& s, char* dst, int cap) {
+    if (!dst || cap <= 0) return 0;
+    snprintf(dst, (size_t)cap, "%s", s.c_str());
+    return 0;
+}
+
+}  // namespace
+
+// ================================= C-ABI =====================================================
+extern "C" {
+
+int simq_version(void) { return SIMQ_VERSION; }
+const char* simq_last_error(void) { return simq::g_error; }
+
+int simq_plan_create(int cin, int cout, simq_plan** out) {
+    SIMQ_REQUIRE(out != nullptr, "plan_create: out is NULL");
+    SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
+    SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);
+    simq_plan* p = new simq_plan();
+    p->cin = cin; p->cout = cout;
+    Builder bd{p};
+    bd.conv(p->stem, "resnet18.conv1", cin, 64, 7, 2, 3, false, false);
+    bd.bn(p->stem_bn, "resnet18.bn1", 64);
+    int inplanes = 64, bi = 0;
+    const int planes_of[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li) {
+        for (int k = 0; k < 2; ++k, ++bi) {
+            BlockL& b = p->blocks[bi];
+            const int planes = planes_of[li];
+            const int bcin = k == 0 ? inplanes : planes;
+            char nm[64];
+            snprintf(nm, sizeof(nm), "resnet18.layer%d.%d.", li + 1, k);
+            b.cin = bcin; b.planes = planes; b.has_ds = (k == 0 && bcin != planes);
+            bd.conv(b.c1, std::string(nm) + "conv1", bcin, planes, 3, 1, 1, false, true);
+            bd.bn(b.b1, std::string(nm) + "bn1", planes);
+            bd.conv(b.c2, std::string(nm) + "conv2", planes, planes, 3, 1, 1, false, true);
+            bd.bn(b.b2, std::string(nm) + "bn2", planes);
+            if (b.has_ds) {
+                bd.conv(b.ds, std::string(nm) + "downsample.0", bcin, planes, 1, 1, 0, false, true);
+                bd.bn(b.bds, std::string(nm) + "downsample.1", planes);
+            }
+        }
+        inplanes = planes_of[li];
+    }
+    bd.conv(p->h1, "conv1", 512, 128, 1, 1, 0, true, true);
+    bd.bn(p->hb1, "bn1", 128);
+    bd.conv(p->h2, "conv2", 128, 32, 1, 1, 0, true, true);
+    bd.bn(p->hb2, "bn2", 32);
+    bd.conv(p->h3, "conv3", 32, cout, 1, 1, 0, true, false);
+    for (const TensorInfo& t : p->tensors)
+        if (t.kind == SIMQ_KIND_CONV_W && (t.off % 4) != 0) {
+            set_error("plan_create: tensor %s not 16-byte aligned in the flat buffer", t.name.c_str());
+            delete p;
+            return -1;
+        }
+    *out = p;
+    return 0;
+}
+
+void simq_plan_destroy(simq_plan* plan) { delete plan; }
+
+int64_t simq_param_count(const simq_plan* plan) { return plan ? plan->nparams : -1; }
+int simq_param_num_tensors(const simq_plan* plan) { return plan ? (int)plan->tensors.size() : -1; }
+
+int simq_param_tensor_info(const simq_plan* plan, int index, char* name, int name_cap, int64_t* offset, int64_t shape[4], int* kind) {
+    SIMQ_REQUIRE(plan && index >= 0 && index < (int)plan->tensors.size(), "param_tensor_info: bad index %d", index);
+    const TensorInfo& t = plan->tensors[index];
+    copy_name(t.name, name, name_cap);
+    if (offset) *offset = t.off;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+    if (kind) *kind = t.kind;
+    return 0;
+}
+
+int64_t simq_bnbuf_count(const simq_plan* plan) { return plan ? plan->nbnbuf : -1; }
+int simq_bn_num_layers(const simq_plan* plan) { return plan ? (int)plan->bns.size() : -1; }
+
+int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_cap, int64_t* offset, int* channels) {
+    SIMQ_REQUIRE(plan && index >= 0 && index < (int)plan->bns.size(), "bn_layer_info: bad index %d", index);
+    const BnL* b = plan->bns[index];
+    copy_name(b->name, name, name_cap);
+    if (offset) *offset = b->buf_off;
+    if (channels) *channels = b->C;
+    return 0;
+}
+
+int64_t simq_workspace_bytes(const simq_plan* plan, int batch) {
+    if (!plan || batch < 1) return -1;
+    return make_layout(plan, batch).total;
+}
+
+int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, float* d_bnbuf, const float* d_x,
+                 float* d_q, void* d_workspace, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_bnbuf && d_x && d_q && d_workspace, "forward: NULL argument");
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "forward: batch=%d out of range", batch);
+    SIMQ_REQUIRE(mode >= 0 && mode <= 2, "forward: bad mode %d", mode);
+    Ctx c{plan, batch, d_params, nullptr, d_bnbuf, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    return forward_impl(c, mode, d_x, d_q);
+}
+
+int simq_backward(const simq_plan* plan, int batch, const float* d_params, const float* d_dq, float* d_grads,
+                  void* d_workspace, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_dq && d_grads && d_workspace, "backward: NULL argument");
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
+    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    return backward_impl(c, d_dq);
+}
+
+int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream) {
+    SIMQ_REQUIRE(rows >= 0 && n >= 1, "q_argmax: bad shape");
+    return launch_q_argmax(d_q, rows, n, d_index, d_max, static_cast<hipStream_t>(stream));
+}
+
+int simq_q_gather(const float* d_q, int rows, int n, const int64_t* d_index, float* d_out, void* stream) {
+    SIMQ_REQUIRE(rows >= 0 && n >= 1, "q_gather: bad shape");
+    return launch_q_gather(d_q, rows, n, d_index, d_out, static_cast<hipStream_t>(stream));
+}
+
+int simq_scatter_next_values(const float* d_values, const int32_t* d_nonfinal_pos, int n_nonfinal, float* d_nsv, int batch, void* stream) {
+    return launch_scatter_next_values(d_values, d_nonfinal_pos, n_nonfinal, d_nsv, batch, static_cast<hipStream_t>(stream));
+}
+
+int simq_td_huber(const float* d_q, int batch, int n, const int64_t* d_action, const float* d_reward, const float* d_nsv,
+                  float gamma, float grad_scale, float* d_q_sa, float* d_y, float* d_td_error, float* d_out4, float* d_dq, void* stream) {
+    SIMQ_REQUIRE(batch >= 1 && n >= 1, "td_huber: bad shape");
+    return launch_td_huber(d_q, batch, n, d_action, d_reward, d_nsv, gamma, grad_scale, d_q_sa, d_y, d_td_error, d_out4, d_dq,
+                           static_cast<hipStream_t>(stream));
+}
+
+int simq_clip_sgd_step(float* d_params, float* d_grads, float* d_momentum, int64_t count, float max_norm, float lr,
+                       float momentum, float weight_decay, int first_step, void* d_scratch, float* d_total_norm, void* stream) {
+    SIMQ_REQUIRE(d_params && d_grads && d_momentum && d_scratch && count > 0, "clip_sgd_step: bad argument");
+    return launch_clip_sgd(d_params, d_grads, d_momentum, count, max_norm, lr, momentum, weight_decay, first_step, d_scratch,
+                           d_total_norm, static_cast<hipStream_t>(stream));
+}
+
+int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* d_index, int count, float* d_out, void* stream) {
+    return launch_replay_gather(d_ring, item_floats, d_index, count, d_out, static_cast<hipStream_t>(stream));
+}
+
+int simq_nchw_to_nhwc(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream) {
+    return launch_nchw_to_nhwc(d_in, d_out, batch, channels, hw, static_cast<hipStream_t>(stream));
+}
+
+int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream) {
+    return launch_nhwc_to_nchw(d_in, d_out, batch, channels, hw, static_cast<hipStream_t>(stream));
+}
+
+int simq_conv2d_fwd(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
+                    int cin, int cout, int r, int s, int stride, int pad, double* d_stats, void* stream) {
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    ConvEpilogue e;
+    e.bias = d_bias; e.stats = d_stats;
+    return launch_conv_igemm(d_x, d_w, d_y, g, e, static_cast<hipStream_t>(stream));
+}
+
+int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, float* d_dx, int batch, int hin, int win,
+                      int cin, int cout, int r, int s, int pad, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SIMQ_REQUIRE(r == s, "conv2d_dgrad: square filters only");
+    RC(launch_weight_transpose(d_w, d_wt_scratch, cout, r * s, cin, st));
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cout; g.Cout = cin; g.Hout = hin; g.Wout = win;
+    g.R = r; g.S = s; g.stride = 1; g.pad = r - 1 - pad;
+    ConvEpilogue e;
+    return launch_conv_igemm(d_dy, d_wt_scratch, d_dx, g, e, st);
+}
+
+int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
+                      int r, int s, int stride, int pad, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
+    return launch_conv_wgrad(d_x, d_dy, d_dw, g, st);
+}
+
+int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream) {
+    return launch_upsample2x_fwd(d_in, d_out, batch, h, w, c, static_cast<hipStream_t>(stream));
+}
+
+int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream) {
+    return launch_upsample2x_bwd(d_dout, d_din, batch, h, w, c, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""ctypes binding of include/simq.h (libsimq.so).
+
+No fallback: if the shared library is missing or does not load, importing this
+module raises -- the product path never routes around the HIP kernels.
+torch is imported first so that libsimq.so binds to the HIP runtime
+(libamdhip64.so.7) already loaded by PyTorch-ROCm and both share one device
+context / stream table.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL: shares the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsimq.so')
+
+MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD = 0, 1, 2
+KIND_CONV_W, KIND_CONV_B, KIND_BN_W, KIND_BN_B = 0, 1, 2, 3
+
+
+class SimqError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise SimqError('libsimq.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                    '(or `make -C spatial-intention-maps_amd/csrc`); there is no CPU fallback' % LIB_PATH)
+
+_c = ctypes.CDLL(LIB_PATH)
+
+_SIGS = {
+    'simq_version': (c_int, []),
+    'simq_last_error': (c_char_p, []),
+    'simq_plan_create': (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    'simq_plan_destroy': (None, [c_void_p]),
+    'simq_param_count': (c_int64, [c_void_p]),
+    'simq_param_num_tensors': (c_int, [c_void_p]),
+    'simq_param_tensor_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int64 * 4), POINTER(c_int)]),
+    'simq_bnbuf_count': (c_int64, [c_void_p]),
+    'simq_bn_num_layers': (c_int, [c_void_p]),
+    'simq_bn_layer_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int)]),
+    'simq_workspace_bytes': (c_int64, [c_void_p, c_int]),
+    'simq_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'simq_scatter_next_values': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'simq_td_huber': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_clip_sgd_step': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+    'simq_replay_gather': (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    'simq_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'simq_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'simq_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    'simq_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'simq_upsample2x_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_c, _name)      # AttributeError here == header / library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return (_c.simq_last_error() or b'').decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SimqError('%s failed (%d): %s' % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device`."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Lib:
+    """Thin checked wrappers; all pointers come from torch tensors."""
+    c = _c
+    version = _c.simq_version()
+
+    @staticmethod
+    def call(name, *args):
+        check(getattr(_c, name)(*args), name)
+
+
+lib = Lib()
+
+
+class Plan:
+    """Owns a simq_plan* and exposes its buffer layout."""
+
+    def __init__(self, num_input_channels, num_output_channels):
+        self.cin, self.cout = int(num_input_channels), int(num_output_channels)
+        h = c_void_p()
+        check(_c.simq_plan_create(self.cin, self.cout, ctypes.byref(h)), 'simq_plan_create')
+        self.handle = h
+        self.param_count = _c.simq_param_count(h)
+        self.bnbuf_count = _c.simq_bnbuf_count(h)
+        self.tensors = []     # (name, offset, shape(list), kind)
+        buf = ctypes.create_string_buffer(128)
+        for i in range(_c.simq_param_num_tensors(h)):
+            off, shape, kind = c_int64(), (c_int64 * 4)(), c_int()
+            check(_c.simq_param_tensor_info(h, i, buf, 128, ctypes.byref(off), ctypes.byref(shape), ctypes.byref(kind)),
+                  'simq_param_tensor_info')
+            shp = list(shape) if kind.value == KIND_CONV_W else [shape[0]]
+            self.tensors.append((buf.value.decode(), off.value, shp, kind.value))
+        self.bn_layers = []   # (name, offset, channels)
+        for i in range(_c.simq_bn_num_layers(h)):
+            off, ch = c_int64(), c_int()
+            check(_c.simq_bn_layer_info(h, i, buf, 128, ctypes.byref(off), ctypes.byref(ch)), 'simq_bn_layer_info')
+            self.bn_layers.append((buf.value.decode(), off.value, ch.value))
+
+    def workspace_bytes(self, batch):
+        n = _c.simq_workspace_bytes(self.handle, int(batch))
+        if n < 0:
+            raise SimqError('simq_workspace_bytes(%d) failed' % batch)
+        return n
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _c.simq_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,264 @@
+"""simq.FCN -- drop-in for the reference ``networks.FCN`` (networks.py:6-26) whose
+arithmetic runs in libsimq's HIP kernels.
+
+Interface kept from the reference (what train.py / policies.py touch):
+  FCN(num_input_channels, num_output_channels)
+  net(x[B,Cin,96,96]) -> Tensor[B,Cout,96,96]   with autograd (loss.backward() works)
+  .parameters()        72 tensors in reference order (70 receive .grad; fc.* never do)
+  .state_dict() / .load_state_dict()   reference keys + OIHW shapes ("module." prefix as
+                       produced by the DataParallel wrapper of policies.py:39)
+  .train() / .eval()   BatchNorm batch statistics vs running statistics
+
+Device layout: ONE flat fp32 parameter buffer (OHWI conv weights) + identically laid-out
+gradient buffer; every nn.Parameter is a view into the flat buffer, so torch.optim.SGD /
+clip_grad_norm_ operate on it unchanged, and the fused learner (simq.learner) can update
+all parameters with one kernel and all-reduce one message.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import arch
+from ._lib import (KIND_CONV_W, MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD, Plan, SimqError, lib, ptr, stream_ptr)
+
+W = arch.STATE_WIDTH
+
+
+class _FCNFunction(torch.autograd.Function):
+    """FCN.forward / its backward as one autograd node over the flat buffers."""
+
+    @staticmethod
+    def forward(ctx, net, x_nhwc, *params):
+        q = net._forward_raw(x_nhwc, MODE_TRAIN)
+        ctx.net = net
+        ctx.generation = net._train_generation
+        ctx.batch = x_nhwc.shape[0]
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        net = ctx.net
+        if ctx.generation != net._train_generation:
+            raise SimqError('simq.FCN: backward() after a newer grad-mode forward of the same net -- the saved '
+                            'activations were overwritten (one grad-mode forward per backward)')
+        g = net._backward_raw(dq.contiguous(), ctx.batch)
+        grads = tuple(g[off:off + n].view(shape) for (off, n, shape) in net._grad_views)
+        return (None, None) + grads
+
+
+class FCN(torch.nn.Module):
+    def __init__(self, num_input_channels=3, num_output_channels=1, device=None, dataparallel_keys=True):
+        super().__init__()
+        if device is None:
+            device = torch.device('cuda')
+        self.device_ = torch.device(device)
+        if self.device_.type != 'cuda':
+            raise SimqError('simq.FCN needs a GPU device (got %s); there is no CPU path' % device)
+        self.num_input_channels, self.num_output_channels = int(num_input_channels), int(num_output_channels)
+        self.key_prefix = arch.PREFIX if dataparallel_keys else ''
+        self.plan = Plan(num_input_channels, num_output_channels)
+        P = self.plan.param_count
+        self.flat_params = torch.zeros(P, dtype=torch.float32, device=self.device_)
+        self.flat_grads = torch.zeros(P, dtype=torch.float32, device=self.device_)
+        self.bn_buffers = torch.zeros(self.plan.bnbuf_count, dtype=torch.float32, device=self.device_)
+        self.num_batches_tracked = OrderedDict((name, 0) for name, _, _ in self.plan.bn_layers)
+        self._grad_views = []
+        self._param_names = []
+        by_name = {name: (off, shape, kind) for name, off, shape, kind in self.plan.tensors}
+        # register in the reference's parameter order (72 tensors; resnet18.fc.* exist in the reference,
+        # resnet.py:68, but features() never calls them, so they never receive a gradient)
+        for key, _, skind in arch.state_spec(self.num_input_channels, self.num_output_channels):
+            k = key[len(arch.PREFIX):]
+            if skind in arch.TRAINABLE_KINDS:
+                off, shape, kind = by_name[k]
+                n = int(math.prod(shape))
+                pname = k.replace('.', '__')
+                self.register_parameter(pname, torch.nn.Parameter(self.flat_params[off:off + n].view(shape)))
+                self._param_names.append((k, pname, kind))
+                self._grad_views.append((off, n, tuple(shape)))
+            elif skind == 'fc_w':
+                self.fc_weight = torch.nn.Parameter(torch.zeros(1000, 512, device=self.device_))
+            elif skind == 'fc_b':
+                self.fc_bias = torch.nn.Parameter(torch.zeros(1000, device=self.device_))
+        self._ws = {}
+        self._train_generation = 0
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ init / (de)serialisation
+    def reset_parameters(self):
+        """Same distributions as the reference: kaiming_normal(fan_out) for ResNet convs, BN 1/0
+        (resnet.py:70-75); PyTorch defaults for the three head convs and fc (networks.py:10-14)."""
+        sd = OrderedDict()
+        for key, shape, kind in arch.state_spec(self.num_input_channels, self.num_output_channels):
+            k = key[len(arch.PREFIX):]
+            in_resnet = k.startswith('resnet18.')
+            if kind == 'conv_w':
+                if in_resnet:
+                    std = math.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))
+                    t = torch.randn(shape) * std
+                else:
+                    bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+                    t = (torch.rand(shape) * 2 - 1) * bound
+            elif kind == 'conv_b':
+                cw = [s for kk, s, _ in arch.state_spec(self.num_input_channels, self.num_output_channels)
+                      if kk == key.replace('.bias', '.weight')][0]
+                bound = 1.0 / math.sqrt(cw[1] * cw[2] * cw[3])
+                t = (torch.rand(shape) * 2 - 1) * bound
+            elif kind in ('bn_weight', 'bn_var'):
+                t = torch.ones(shape)
+            elif kind in ('bn_bias', 'bn_mean'):
+                t = torch.zeros(shape)
+            elif kind == 'bn_count':
+                t = torch.tensor(0, dtype=torch.int64)
+            elif kind == 'fc_w':
+                t = (torch.rand(shape) * 2 - 1) / math.sqrt(512.0)
+            elif kind == 'fc_b':
+                t = (torch.rand(shape) * 2 - 1) / math.sqrt(512.0)
+            sd[key] = t
+        self.load_state_dict(sd)
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        """Reference-format state dict (138 keys, OIHW conv weights)."""
+        out = OrderedDict() if destination is None else destination
+        pre = prefix + self.key_prefix
+        by_name = {name: (off, shape, kind) for name, off, shape, kind in self.plan.tensors}
+        bn_by_name = {name: (off, ch) for name, off, ch in self.plan.bn_layers}
+        for key, shape, kind in arch.state_spec(self.num_input_channels, self.num_output_channels):
+            k = key[len(arch.PREFIX):]
+            if kind in arch.TRAINABLE_KINDS:
+                off, dshape, dkind = by_name[k]
+                n = int(math.prod(dshape))
+                t = self.flat_params[off:off + n].view(dshape)
+                if dkind == KIND_CONV_W:
+                    t = t.permute(0, 3, 1, 2).contiguous()       # OHWI -> OIHW
+                else:
+                    t = t.clone()
+            elif kind in ('bn_mean', 'bn_var'):
+                bn = k.rsplit('.', 1)[0]
+                off, ch = bn_by_name[bn]
+                o = off + (ch if kind == 'bn_var' else 0)
+                t = self.bn_buffers[o:o + ch].clone()
+            elif kind == 'bn_count':
+                t = torch.tensor(self.num_batches_tracked[k.rsplit('.', 1)[0]], dtype=torch.int64, device=self.device_)
+            elif kind == 'fc_w':
+                t = self.fc_weight.detach().clone()
+            else:
+                t = self.fc_bias.detach().clone()
+            out[pre + k] = t.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts reference-format dicts with or without the DataParallel 'module.' prefix."""
+        sd = {}
+        for k, v in state_dict.items():
+            sd[k[len(arch.PREFIX):] if k.startswith(arch.PREFIX) else k] = v
+        by_name = {name: (off, shape, kind) for name, off, shape, kind in self.plan.tensors}
+        bn_by_name = {name: (off, ch) for name, off, ch in self.plan.bn_layers}
+        missing = []
+        with torch.no_grad():
+            for key, shape, kind in arch.state_spec(self.num_input_channels, self.num_output_channels):
+                k = key[len(arch.PREFIX):]
+                if k not in sd:
+                    missing.append(k)
+                    continue
+                v = torch.as_tensor(sd[k])
+                if kind != 'bn_count' and tuple(v.shape) != tuple(shape):
+                    raise SimqError('load_state_dict: %s has shape %s, expected %s' % (k, tuple(v.shape), tuple(shape)))
+                if kind in arch.TRAINABLE_KINDS:
+                    off, dshape, dkind = by_name[k]
+                    n = int(math.prod(dshape))
+                    v = v.to(torch.float32)
+                    if dkind == KIND_CONV_W:
+                        v = v.permute(0, 2, 3, 1)                  # OIHW -> OHWI
+                    self.flat_params[off:off + n].copy_(v.reshape(-1).to(self.device_))
+                elif kind in ('bn_mean', 'bn_var'):
+                    off, ch = bn_by_name[k.rsplit('.', 1)[0]]
+                    o = off + (ch if kind == 'bn_var' else 0)
+                    self.bn_buffers[o:o + ch].copy_(v.to(torch.float32).to(self.device_))
+                elif kind == 'bn_count':
+                    self.num_batches_tracked[k.rsplit('.', 1)[0]] = int(v)
+                elif kind == 'fc_w':
+                    self.fc_weight.copy_(v.to(self.device_))
+                else:
+                    self.fc_bias.copy_(v.to(self.device_))
+        if strict and missing:
+            raise SimqError('load_state_dict: missing keys %s' % missing[:5])
+        return torch.nn.modules.module._IncompatibleKeys(missing, [])
+
+    def copy_state_from(self, other):
+        """target.load_state_dict(policy.state_dict()) (train.py:214,269) without the OIHW round trip."""
+        with torch.no_grad():
+            self.flat_params.copy_(other.flat_params)
+            self.bn_buffers.copy_(other.bn_buffers)
+            self.fc_weight.copy_(other.fc_weight)
+            self.fc_bias.copy_(other.fc_bias)
+        self.num_batches_tracked = OrderedDict(other.num_batches_tracked)
+
+    # ------------------------------------------------------------------ raw kernels over flat buffers
+    def _workspace(self, slot, batch):
+        need = self.plan.workspace_bytes(batch)
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
+            self._ws[slot] = ws
+        return ws
+
+    def _forward_raw(self, x_nhwc, mode):
+        """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96]."""
+        if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous() or x_nhwc.device != self.flat_params.device:
+            raise SimqError('simq.FCN: input must be a contiguous fp32 tensor on %s' % self.device_)
+        B = x_nhwc.shape[0]
+        if tuple(x_nhwc.shape[1:]) != (W, W, self.num_input_channels):
+            raise SimqError('simq.FCN: expected input [B,%d,%d,%d] (NHWC), got %s'
+                            % (W, W, self.num_input_channels, tuple(x_nhwc.shape)))
+        if B < 1:
+            raise SimqError('simq.FCN: empty batch')
+        if mode == MODE_TRAIN:
+            self._train_generation += 1
+        ws = self._workspace('train' if mode == MODE_TRAIN else 'tmp', B)
+        q = torch.empty((B, self.num_output_channels, W, W), dtype=torch.float32, device=self.device_)
+        lib.call('simq_forward', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.bn_buffers), ptr(x_nhwc),
+                 ptr(q), ptr(ws), stream_ptr(self.device_))
+        if mode != MODE_EVAL:
+            for k in self.num_batches_tracked:
+                self.num_batches_tracked[k] += 1
+        return q
+
+    def _backward_raw(self, dq, batch):
+        """dq [B,Cout,96,96] -> flat gradient buffer (overwritten)."""
+        ws = self._ws.get('train')
+        if ws is None:
+            raise SimqError('simq.FCN: backward without a grad-mode forward')
+        lib.call('simq_backward', self.plan.handle, batch, ptr(self.flat_params), ptr(dq), ptr(self.flat_grads), ptr(ws),
+                 stream_ptr(self.device_))
+        return self.flat_grads
+
+    def to_nhwc(self, x_nchw):
+        x = x_nchw.to(self.device_, torch.float32).contiguous()
+        out = torch.empty((x.shape[0], W, W, x.shape[1]), dtype=torch.float32, device=self.device_)
+        lib.call('simq_nchw_to_nhwc', ptr(x), ptr(out), x.shape[0], x.shape[1], W * W, stream_ptr(self.device_))
+        return out
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def forward(self, x):
+        """x: [B,Cin,96,96] (reference layout, networks.py:16)."""
+        if x.dim() != 4 or x.shape[1] != self.num_input_channels or x.shape[2] != W or x.shape[3] != W:
+            raise SimqError('simq.FCN: expected input [B,%d,%d,%d], got %s' % (self.num_input_channels, W, W, tuple(x.shape)))
+        return self.forward_nhwc(self.to_nhwc(x))
+
+    def forward_nhwc(self, x_nhwc):
+        """Same as forward() for inputs already in the replay/HWC layout [B,96,96,Cin]."""
+        if not self.training:
+            return self._forward_raw(x_nhwc, MODE_EVAL)
+        if not torch.is_grad_enabled():
+            return self._forward_raw(x_nhwc, MODE_TRAIN_NOGRAD)
+        params = [getattr(self, pname) for _, pname, _ in self._param_names]
+        return _FCNFunction.apply(self, x_nhwc, *params)
+
+    def argmax(self, q):
+        """Flat first-index argmax of one Q-map [Cout,96,96] (policies.py:64: o.view(1,-1).max(1)[1].item())."""
+        q = q.contiguous()
+        idx = torch.empty(1, dtype=torch.int64, device=self.device_)
+        lib.call('simq_q_argmax', ptr(q), 1, q.numel(), ptr(idx), None, stream_ptr(self.device_))
+        return int(idx.item())

@@ -1,0 +1,275 @@
+"""DQN learner: drop-in for the learner half of the reference train.py.
+
+Reference symbols mirrored (same names, argument meaning, return values):
+  Transition               train.py:26
+  ReplayBuffer             train.py:28-45   (host python-list ring, global `random` stream)
+  train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_factor)
+                           train.py:108-141 -> {'td_error': float, 'loss': float}
+Additions for the MI355X path:
+  DeviceReplayBuffer       same push/sample/len contract, states live in an HBM ring
+                           ([capacity][96][96][C] fp32, the reference's own HWC layout) and
+                           sample() is an index gather driven by the same random.sample picks
+  train_step(...)          the fused step over flat buffers (no torch autograd), used by train()
+All arithmetic goes through libsimq (HIP); there is no torch/CPU fallback.
+"""
+import random
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import arch
+from ._lib import MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD, SimqError, lib, ptr, stream_ptr
+from .fcn import FCN
+
+Transition = namedtuple('Transition', ('state', 'action', 'reward', 'next_state'))   # train.py:26
+W = arch.STATE_WIDTH
+
+
+class ReplayBuffer:
+    """train.py:28-45 (host ring; kept for drop-in use and checkpoint compatibility)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.buffer = []
+        self.position = 0
+
+    def push(self, *args):
+        if len(self.buffer) < self.capacity:
+            self.buffer.append(None)
+        self.buffer[self.position] = Transition(*args)
+        self.position = (self.position + 1) % self.capacity
+
+    def sample(self, batch_size):
+        transitions = random.sample(self.buffer, batch_size)
+        return Transition(*zip(*transitions))
+
+    def __len__(self):
+        return len(self.buffer)
+
+
+class DeviceBatch:
+    """A sampled minibatch already resident in HBM (what DeviceReplayBuffer.sample returns).
+
+    state [B,96,96,C] f32 NHWC, action [B] i64, reward [B] f32 (device);
+    next_state [N',96,96,C] (non-final only), nonfinal_pos [N'] i32 device, non_final_mask host bool list.
+    """
+    __slots__ = ('state', 'action', 'reward', 'next_state', 'nonfinal_pos', 'non_final_mask')
+
+    def __init__(self, state, action, reward, next_state, nonfinal_pos, non_final_mask):
+        self.state, self.action, self.reward = state, action, reward
+        self.next_state, self.nonfinal_pos, self.non_final_mask = next_state, nonfinal_pos, non_final_mask
+
+
+def assemble_batch(batch, device):
+    """train.py:109-112,116-117: host Transition-of-tuples -> DeviceBatch.  The reference
+    transposes every HWC state to CHW and concatenates; the HIP path consumes HWC directly, so
+    this is one stack + one H2D copy per tensor."""
+    if isinstance(batch, DeviceBatch):
+        return batch
+    state = torch.from_numpy(np.stack(batch.state)).to(device, non_blocking=True)
+    action = torch.tensor(batch.action, dtype=torch.long).to(device, non_blocking=True)
+    reward = torch.tensor(batch.reward, dtype=torch.float32).to(device, non_blocking=True)
+    mask = [s is not None for s in batch.next_state]
+    nf = [s for s in batch.next_state if s is not None]
+    if not nf:
+        raise SimqError('train: batch has no non-final next state (the reference raises at train.py:112 too)')
+    next_state = torch.from_numpy(np.stack(nf)).to(device, non_blocking=True)
+    pos = torch.tensor([i for i, m in enumerate(mask) if m], dtype=torch.int32).to(device, non_blocking=True)
+    return DeviceBatch(state, action, reward, next_state, pos, mask)
+
+
+class DeviceReplayBuffer:
+    """ReplayBuffer (train.py:28-45) with the states in an HBM ring.
+
+    push(state, action, reward, next_state) / sample(B) / len() / .position as in the reference;
+    `.buffer` is a list of lightweight Transition records whose state fields are ring slot
+    numbers.  Sampling draws `random.sample(range(len), B)` -- the same picks the reference's
+    `random.sample(self.buffer, B)` makes under the same seed (golden: tests/golden/sampler.npz).
+    """
+
+    def __init__(self, capacity, num_input_channels, device=None):
+        self.capacity = int(capacity)
+        self.C = int(num_input_channels)
+        self.device = torch.device('cuda' if device is None else device)
+        self.item = W * W * self.C
+        self.states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
+        self.next_states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
+        self.buffer = []
+        self.position = 0
+
+    def push(self, state, action, reward, next_state):
+        if len(self.buffer) < self.capacity:
+            self.buffer.append(None)
+        slot = self.position
+        self.states[slot].copy_(torch.as_tensor(state), non_blocking=True)
+        if next_state is not None:
+            self.next_states[slot].copy_(torch.as_tensor(next_state), non_blocking=True)
+        self.buffer[slot] = Transition(slot, int(action), float(reward), slot if next_state is not None else None)
+        self.position = (self.position + 1) % self.capacity
+
+    def push_many(self, states, actions, rewards, next_states, terminal):
+        """Bulk fill (bench / tests): arrays [n,96,96,C], [n], [n], [n,96,96,C], bool [n]."""
+        n = len(actions)
+        if len(self.buffer) + n > self.capacity or self.position != len(self.buffer):
+            for i in range(n):
+                self.push(states[i], actions[i], rewards[i], None if terminal[i] else next_states[i])
+            return
+        s0 = self.position
+        self.states[s0:s0 + n].copy_(torch.as_tensor(states))
+        self.next_states[s0:s0 + n].copy_(torch.as_tensor(next_states))
+        for i in range(n):
+            self.buffer.append(Transition(s0 + i, int(actions[i]), float(rewards[i]), None if terminal[i] else s0 + i))
+        self.position = (s0 + n) % self.capacity
+
+    def __len__(self):
+        return len(self.buffer)
+
+    def sample_indices(self, batch_size):
+        return random.sample(range(len(self.buffer)), batch_size)
+
+    def gather(self, idx):
+        recs = [self.buffer[i] for i in idx]
+        B = len(recs)
+        dev = self.device
+        st = stream_ptr(dev)
+        index = torch.tensor([r.state for r in recs], dtype=torch.int64).to(dev, non_blocking=True)
+        state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
+        lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
+        mask = [r.next_state is not None for r in recs]
+        nf = [r.next_state for r in recs if r.next_state is not None]
+        if not nf:
+            raise SimqError('sample: no non-final next state in the batch (train.py:112 would raise)')
+        nindex = torch.tensor(nf, dtype=torch.int64).to(dev, non_blocking=True)
+        next_state = torch.empty((len(nf), W, W, self.C), dtype=torch.float32, device=dev)
+        lib.call('simq_replay_gather', ptr(self.next_states), self.item, ptr(nindex), len(nf), ptr(next_state), st)
+        action = torch.tensor([r.action for r in recs], dtype=torch.long).to(dev, non_blocking=True)
+        reward = torch.tensor([r.reward for r in recs], dtype=torch.float32).to(dev, non_blocking=True)
+        pos = torch.tensor([i for i, m in enumerate(mask) if m], dtype=torch.int32).to(dev, non_blocking=True)
+        return DeviceBatch(state, action, reward, next_state, pos, mask)
+
+    def sample(self, batch_size):
+        return self.gather(self.sample_indices(batch_size))
+
+
+class _OptState:
+    """Flat momentum buffer aliased into a torch.optim.SGD's per-parameter state so that
+    optimizer.state_dict() / load_state_dict() (train.py:204,331) keep working."""
+
+    def __init__(self, net):
+        self.momentum = torch.zeros_like(net.flat_params)
+        self.scratch = torch.zeros(4, dtype=torch.float64, device=net.flat_params.device)
+        self.total_norm = torch.zeros(1, dtype=torch.float32, device=net.flat_params.device)
+        self.initialised = False
+        self.views = None
+
+
+def _opt_state(net, optimizer):
+    st = getattr(net, '_simq_opt_state', None)
+    if st is None:
+        st = _OptState(net)
+        net._simq_opt_state = st
+    if optimizer is None:
+        return st
+    if st.views is None:
+        st.views = [st.momentum[off:off + n].view(shape) for (off, n, shape) in net._grad_views]
+    params = [getattr(net, pname) for _, pname, _ in net._param_names]
+    # adopt momentum buffers that were loaded from a checkpoint (optimizer.load_state_dict)
+    for p, v in zip(params, st.views):
+        buf = optimizer.state.get(p, {}).get('momentum_buffer')
+        if buf is not None and buf.data_ptr() != v.data_ptr():
+            v.copy_(buf.to(v.device).view_as(v))
+            optimizer.state[p]['momentum_buffer'] = v
+            st.initialised = True
+    return st
+
+
+def _hyper(optimizer):
+    if optimizer is None or not hasattr(optimizer, 'param_groups'):
+        raise SimqError('train: optimizer must expose param_groups (torch.optim.SGD as built at train.py:186)')
+    if len(optimizer.param_groups) != 1:
+        raise SimqError('train: exactly one parameter group expected (train.py:186)')
+    g = optimizer.param_groups[0]
+    if g.get('nesterov') or g.get('dampening', 0) != 0 or g.get('maximize'):
+        raise SimqError('train: only plain momentum SGD (train.py:186) is implemented')
+    return float(g['lr']), float(g.get('momentum', 0.0)), float(g.get('weight_decay', 0.0))
+
+
+def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, momentum, weight_decay,
+               grad_norm_clipping, use_double_dqn=True, opt_state=None, process_group=None, global_batch=None,
+               sync=True):
+    """One TD step (train.py:108-141) entirely on the device, over the nets' flat buffers.
+
+    Data-parallel: pass `process_group` / `global_batch`; this rank's `batch` is its slice of the
+    minibatch, BatchNorm uses per-rank statistics (the reference's DataParallel semantics,
+    policies.py:39) and the flat gradient is summed with ONE all-reduce (RCCL) before clip+SGD.
+    Returns {'td_error','loss'} floats (sync=True, as the reference's .item() calls do) or the
+    device tensor [sum_huber, sum_td] (sync=False).
+    """
+    if not isinstance(policy_net, FCN) or not isinstance(target_net, FCN):
+        raise SimqError('simq.train needs simq.FCN networks (got %s / %s); there is no torch fallback'
+                        % (type(policy_net).__name__, type(target_net).__name__))
+    dev = policy_net.device_
+    b = assemble_batch(batch, dev)
+    B = b.state.shape[0]
+    if B != batch_size:
+        raise SimqError('train: batch has %d transitions but cfg.batch_size is %d' % (B, batch_size))
+    gB = B if global_batch is None else int(global_batch)
+    st = stream_ptr(dev)
+    n = policy_net.num_output_channels * W * W
+    st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
+
+    # train.py:114 -- policy forward, train-mode BN, activations kept for backward
+    q = policy_net._forward_raw(b.state, MODE_TRAIN)
+    # train.py:116-124 -- bootstrap values of the non-final next states
+    Nn = b.next_state.shape[0]
+    nsv = torch.empty(B, dtype=torch.float32, device=dev)
+    vals = torch.empty(Nn, dtype=torch.float32, device=dev)
+    if use_double_dqn:
+        # train.py:121: the POLICY net, still in train mode (batch statistics, 2nd running-stat update)
+        q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD)
+        best = torch.empty(Nn, dtype=torch.int64, device=dev)
+        lib.call('simq_q_argmax', ptr(q_next), Nn, n, ptr(best), None, st)
+        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122 (target in eval mode)
+        lib.call('simq_q_gather', ptr(q_tgt), Nn, n, ptr(best), ptr(vals), st)
+    else:
+        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:124
+        lib.call('simq_q_argmax', ptr(q_tgt), Nn, n, None, ptr(vals), st)
+    lib.call('simq_scatter_next_values', ptr(vals), ptr(b.nonfinal_pos), Nn, ptr(nsv), B, st)
+    # train.py:115,126-129 + the gradient autograd would hand to `output`
+    q_sa = torch.empty(B, dtype=torch.float32, device=dev)
+    y = torch.empty(B, dtype=torch.float32, device=dev)
+    td = torch.empty(B, dtype=torch.float32, device=dev)
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    dq = torch.empty_like(q)
+    lib.call('simq_td_huber', ptr(q), B, n, ptr(b.action), ptr(b.reward), ptr(nsv), float(discount_factor),
+             1.0 / gB, ptr(q_sa), ptr(y), ptr(td), ptr(out4), ptr(dq), st)
+    # train.py:131-132
+    grads = policy_net._backward_raw(dq, B)
+    if process_group is not None:
+        torch.distributed.all_reduce(grads, group=process_group)           # RCCL, one flat message
+        torch.distributed.all_reduce(out4, group=process_group)
+    # train.py:133-135
+    lib.call('simq_clip_sgd_step', ptr(policy_net.flat_params), ptr(grads), ptr(st_opt.momentum),
+             policy_net.plan.param_count, float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0,
+             lr, momentum, weight_decay, 0 if st_opt.initialised else 1, ptr(st_opt.scratch), ptr(st_opt.total_norm), st)
+    st_opt.initialised = True
+    policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q}
+    if not sync:
+        return out4
+    o = out4.tolist()                                                       # train.py:138-139 (.item() host sync)
+    return {'td_error': o[1] / gB, 'loss': o[0] / gB}
+
+
+def train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_factor):
+    """Drop-in for train.train (train.py:108-141).  `transform_fn` (policies.py:44-45) is
+    accepted for signature compatibility; the HIP path reads the HWC states as they are."""
+    lr, momentum, weight_decay = _hyper(optimizer)
+    st = _opt_state(policy_net, optimizer)
+    info = train_step(policy_net, target_net, batch, discount_factor, cfg.batch_size, lr, momentum, weight_decay,
+                      cfg.grad_norm_clipping, use_double_dqn=cfg.use_double_dqn, opt_state=st)
+    if momentum != 0:   # expose the (aliased) momentum buffers exactly where torch.optim.SGD keeps them
+        params = [getattr(policy_net, pname) for _, pname, _ in policy_net._param_names]
+        for p, v in zip(params, st.views):
+            optimizer.state[p]['momentum_buffer'] = v
+    return info

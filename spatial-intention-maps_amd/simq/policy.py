@@ -1,0 +1,84 @@
+"""simq.DQNPolicy -- drop-in for the reference ``policies.DQNPolicy`` (policies.py:11-74).
+
+Same constructor, attributes and methods; each policy net is a simq.FCN (HIP) instead of
+DataParallel(networks.FCN).  The three VectorEnv statics the reference calls are replaced by the
+constants they return (simq.arch, citing envs.py:366-376,810,1090,2010) because the simulator is
+out of scope.  `build_network` / `apply_transition` -- the names BASELINE.json uses -- are aliases
+of the reference's real `build_policy_nets` / `apply_transform`.
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import arch
+from ._lib import SimqError
+from .fcn import FCN
+
+
+class DQNPolicy:
+    def __init__(self, cfg, train=False, random_seed=None):
+        self.cfg = cfg
+        self.robot_group_types = [next(iter(g.keys())) for g in self.cfg.robot_config]     # policies.py:14
+        self.train = train
+        if random_seed is not None:
+            random.seed(random_seed)                                                        # policies.py:16-17
+        self.num_robot_groups = len(self.robot_group_types)
+        if not torch.cuda.is_available():
+            raise SimqError('simq.DQNPolicy needs an MI355X (torch.cuda.is_available() is False); no CPU path')
+        self.device = torch.device('cuda')                                                  # policies.py:21
+        self.policy_nets = self.build_policy_nets()
+        # Resume if applicable (policies.py:25-33)
+        if getattr(self.cfg, 'checkpoint_path', None) is not None:
+            self.policy_checkpoint = torch.load(self.cfg.policy_path, map_location=self.device)
+            for i in range(self.num_robot_groups):
+                self.policy_nets[i].load_state_dict(self.policy_checkpoint['state_dicts'][i])
+                if self.train:
+                    self.policy_nets[i].train()
+                else:
+                    self.policy_nets[i].eval()
+            print("=> loaded policy '{}'".format(self.cfg.policy_path))
+
+    def build_policy_nets(self):                                                            # policies.py:35-42
+        policy_nets = []
+        for robot_type in self.robot_group_types:
+            num_output_channels = arch.get_num_output_channels(robot_type)
+            policy_nets.append(FCN(num_input_channels=self.cfg.num_input_channels,
+                                   num_output_channels=num_output_channels, device=self.device))
+        return policy_nets
+
+    build_network = build_policy_nets      # BASELINE.json's name for the same call
+
+    def apply_transform(self, s):                                                           # policies.py:44-45
+        """ToTensor on a float32 HWC ndarray (no scaling) + unsqueeze(0): [1,C,96,96]."""
+        return torch.from_numpy(np.ascontiguousarray(s).transpose(2, 0, 1)).unsqueeze(0)
+
+    apply_transition = apply_transform     # BASELINE.json's name for the same call
+
+    def step(self, state, exploration_eps=None, debug=False):                               # policies.py:47-74
+        if exploration_eps is None:
+            exploration_eps = self.cfg.final_exploration
+        action = [[None for _ in g] for g in state]
+        output = [[None for _ in g] for g in state]
+        with torch.no_grad():
+            for i, g in enumerate(state):
+                robot_type = self.robot_group_types[i]
+                net = self.policy_nets[i]
+                net.eval()
+                for j, s in enumerate(g):
+                    if s is not None:
+                        # the reference goes HWC -> CHW -> device; the HIP net consumes HWC directly
+                        x = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).unsqueeze(0).to(self.device)
+                        o = net.forward_nhwc(x).squeeze(0)
+                        if random.random() < exploration_eps:
+                            a = random.randrange(arch.get_action_space(robot_type))
+                        else:
+                            a = net.argmax(o)
+                        action[i][j] = a
+                        output[i][j] = o.cpu().numpy()
+                if self.train:
+                    net.train()
+        if debug:
+            info = {'output': output}
+            return action, info
+        return action

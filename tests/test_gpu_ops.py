@@ -1,0 +1,226 @@
+"""GPU: every HIP kernel of libsimq against the same op in plain PyTorch fp32 on the CPU
+(conv / dgrad / wgrad / bilinear / argmax / Huber / clip+SGD), through the C-ABI.
+Tolerance: 1e-4 relative (max-abs error over max-abs value) -- BASELINE.json's fp32 bar;
+observed errors are ~1e-6.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def L():
+    from simq import _lib
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def nhwc(t):     # NCHW cpu -> NHWC cuda
+    return dev(t.permute(0, 2, 3, 1))
+
+
+def ohwi(w):     # OIHW cpu -> OHWI cuda
+    return dev(w.permute(0, 2, 3, 1))
+
+
+CONV_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, bias
+    (2, 24, 64, 64, 3, 1, 1, False),
+    (3, 24, 128, 256, 3, 1, 1, False),      # M = 1728: ragged last 128-row tile
+    (1, 24, 512, 512, 3, 1, 1, False),      # B=1 inference shape (config 0)
+    (2, 24, 256, 512, 1, 1, 0, False),      # downsample 1x1
+    (2, 24, 512, 128, 1, 1, 0, True),       # head conv1 (+bias)
+    (2, 48, 128, 32, 1, 1, 0, True),        # head conv2 (+bias), N = 32 tile
+    (2, 96, 4, 64, 7, 2, 3, False),         # stem, generic gather
+    (3, 96, 5, 64, 7, 2, 3, False),         # stem, Cin = 5 (K = 245, unaligned rows)
+    (16, 24, 64, 128, 3, 1, 1, False),      # enough rows for the 128x128 tile path
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'B%d_H%d_%dto%d_k%d' % (c[0], c[1], c[2], c[3], c[4]))
+def test_conv_fwd_dgrad_wgrad(L, case):
+    B, H, Cin, Cout, k, stride, pad, bias = case
+    g = torch.Generator().manual_seed(1234 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    Ho = y_ref.shape[2]
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    st = L.stream_ptr()
+    xd, wd = nhwc(x.detach()), ohwi(w.detach())
+    bd = dev(b) if bias else None
+    # forward (+ per-channel statistics epilogue)
+    yd = torch.empty(B, Ho, Ho, Cout, device='cuda')
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+    L.lib.call('simq_conv2d_fwd', L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(yd), B, H, H, Cin, Cout, k, k, stride, pad,
+               L.ptr(stats), st)
+    y_nhwc = y_ref.detach().permute(0, 2, 3, 1)
+    assert rel(yd, y_nhwc) < TOL
+    s_ref = y_nhwc.double().reshape(-1, Cout)
+    assert rel(stats[:Cout], s_ref.sum(0)) < 1e-5
+    assert rel(stats[Cout:], (s_ref * s_ref).sum(0)) < 1e-5
+    # weight gradient
+    dyd = nhwc(dy)
+    dwd = torch.full((Cout, k, k, Cin), 7.0, device='cuda')       # callee zero-fills
+    L.lib.call('simq_conv2d_wgrad', L.ptr(xd), L.ptr(dyd), L.ptr(dwd), B, H, H, Cin, Cout, k, k, stride, pad, st)
+    assert rel(dwd, w.grad.permute(0, 2, 3, 1)) < TOL
+    # data gradient (stride-1 convolutions only; the stem never needs one)
+    if stride == 1:
+        dxd = torch.empty(B, H, H, Cin, device='cuda')
+        wt = torch.empty(Cout * k * k * Cin, device='cuda')
+        L.lib.call('simq_conv2d_dgrad', L.ptr(dyd), L.ptr(wd), L.ptr(wt), L.ptr(dxd), B, H, H, Cin, Cout, k, k, pad, st)
+        assert rel(dxd, x.grad.permute(0, 2, 3, 1)) < TOL
+
+
+def test_conv_transpose_detect(L):
+    """A = I with an ASYMMETRIC B: catches a swapped row/col in the MFMA C/D mapping."""
+    C = 64
+    x = torch.zeros(1, C, 24, 24)
+    for c in range(C):
+        x[0, c, c % 24, (c * 7) % 24] = 1.0
+    w = torch.arange(C * C, dtype=torch.float32).reshape(C, C, 1, 1) / 100.0
+    y_ref = F.conv2d(x, w)
+    yd = torch.empty(1, 24, 24, C, device='cuda')
+    L.lib.call('simq_conv2d_fwd', L.ptr(nhwc(x)), L.ptr(ohwi(w)), None, L.ptr(yd), 1, 24, 24, C, C, 1, 1, 1, 0, None,
+               L.stream_ptr())
+    assert torch.equal(yd.cpu(), y_ref.permute(0, 2, 3, 1).contiguous())
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 128), (3, 48, 32), (1, 5, 4)])
+def test_upsample2x(L, shape):
+    B, H, C = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    st = L.stream_ptr()
+    yd = torch.empty(B, 2 * H, 2 * H, C, device='cuda')
+    L.lib.call('simq_upsample2x_fwd', L.ptr(nhwc(x.detach())), L.ptr(yd), B, H, H, C, st)
+    assert rel(yd, y.detach().permute(0, 2, 3, 1)) < 1e-6
+    dxd = torch.empty(B, H, H, C, device='cuda')
+    L.lib.call('simq_upsample2x_bwd', L.ptr(nhwc(dy)), L.ptr(dxd), B, H, H, C, st)
+    assert rel(dxd, x.grad.permute(0, 2, 3, 1)) < 1e-5
+
+
+def test_layout_helpers(L):
+    x = torch.randn(3, 5, 96, 96)
+    st = L.stream_ptr()
+    out = torch.empty(3, 96, 96, 5, device='cuda')
+    L.lib.call('simq_nchw_to_nhwc', L.ptr(dev(x)), L.ptr(out), 3, 5, 96 * 96, st)
+    assert torch.equal(out.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    back = torch.empty(3, 5, 96, 96, device='cuda')
+    L.lib.call('simq_nhwc_to_nchw', L.ptr(out), L.ptr(back), 3, 5, 96 * 96, st)
+    assert torch.equal(back.cpu(), x)
+
+
+def test_argmax_gather_first_index(L):
+    n = 2 * 96 * 96
+    q = torch.randn(5, n)
+    q[0, 17] = q[0, 9000] = 50.0         # tie -> first index (train.py:121 / policies.py:64 semantics)
+    q[1, n - 1] = 60.0
+    q[2] = 0.0                           # all equal -> index 0
+    st = L.stream_ptr()
+    qd = dev(q)
+    idx = torch.empty(5, dtype=torch.int64, device='cuda')
+    mx = torch.empty(5, device='cuda')
+    L.lib.call('simq_q_argmax', L.ptr(qd), 5, n, L.ptr(idx), L.ptr(mx), st)
+    ref_max, ref_idx = q.max(1)
+    assert idx.cpu().tolist() == ref_idx.tolist()
+    assert idx.cpu().tolist()[:3] == [17, n - 1, 0]
+    assert torch.equal(mx.cpu(), ref_max)
+    out = torch.empty(5, device='cuda')
+    L.lib.call('simq_q_gather', L.ptr(qd), 5, n, L.ptr(idx), L.ptr(out), st)
+    assert torch.equal(out.cpu(), ref_max)
+
+
+def test_td_huber_and_scatter(L):
+    B, n = 9, 2 * 96 * 96
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, n, generator=g, requires_grad=True)
+    a = torch.randint(0, n, (B,), generator=g)
+    r = torch.randn(B, generator=g) * 2
+    mask = torch.tensor([1, 0, 1, 1, 0, 1, 1, 1, 0], dtype=torch.bool)
+    vals = torch.randn(int(mask.sum()), generator=g)
+    nsv_ref = torch.zeros(B)
+    nsv_ref[mask] = vals
+    gamma = 0.85
+    q_sa = q.gather(1, a.unsqueeze(1)).squeeze(1)
+    y = r + gamma * nsv_ref
+    loss = F.smooth_l1_loss(q_sa, y)
+    loss.backward()
+    st = L.stream_ptr()
+    pos = dev(torch.nonzero(mask).squeeze(1).to(torch.int32))
+    nsv = torch.full((B,), 9.0, device='cuda')
+    L.lib.call('simq_scatter_next_values', L.ptr(dev(vals)), L.ptr(pos), int(mask.sum()), L.ptr(nsv), B, st)
+    assert torch.equal(nsv.cpu(), nsv_ref)
+    outs = [torch.empty(B, device='cuda') for _ in range(3)]
+    out4 = torch.empty(4, device='cuda')
+    dq = torch.empty(B, n, device='cuda')
+    L.lib.call('simq_td_huber', L.ptr(dev(q.detach())), B, n, L.ptr(dev(a)), L.ptr(dev(r)), L.ptr(nsv), gamma, 1.0 / B,
+               L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(out4), L.ptr(dq), st)
+    assert rel(outs[0], q_sa) < 1e-6 and rel(outs[1], y) < 1e-6
+    assert rel(outs[2], (q_sa - y).abs()) < 1e-6
+    assert abs(out4[0].item() / B - loss.item()) < 1e-6 * max(1, abs(loss.item()))
+    assert rel(dq, q.grad) < 1e-6
+    assert int((dq != 0).sum()) <= B
+
+
+@pytest.mark.parametrize('count,max_norm', [(1003, 100.0), (4096, 0.5), (11249826, 100.0)])
+def test_clip_sgd(L, count, max_norm):
+    g = torch.Generator().manual_seed(count)
+    p = torch.randn(count, generator=g)
+    gr = torch.randn(count, generator=g) * 0.05
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pt], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, md = dev(p), torch.zeros(count, device='cuda')
+    scratch = torch.zeros(4, dtype=torch.float64, device='cuda')
+    tn = torch.zeros(1, device='cuda')
+    st = L.stream_ptr()
+    for step in range(3):
+        grad = gr * (step + 1)
+        pt.grad = grad.clone()
+        total = torch.nn.utils.clip_grad_norm_([pt], max_norm)
+        opt.step()
+        gd = dev(grad)
+        L.lib.call('simq_clip_sgd_step', L.ptr(pd), L.ptr(gd), L.ptr(md), count, max_norm, 0.01, 0.9, 1e-4,
+                   1 if step == 0 else 0, L.ptr(scratch), L.ptr(tn), st)
+        assert abs(tn.item() - float(total)) < 1e-5 * float(total)
+        assert rel(gd, pt.grad) < 1e-5          # clipped gradient left in place
+        assert rel(pd, pt.detach()) < 1e-6
+        assert rel(md, opt.state[pt]['momentum_buffer']) < 1e-5
+
+
+def test_replay_gather(L):
+    ring = torch.randn(20, 96, 96, 5)
+    idx = torch.tensor([3, 19, 0, 3], dtype=torch.int64)
+    out = torch.empty(4, 96, 96, 5, device='cuda')
+    L.lib.call('simq_replay_gather', L.ptr(dev(ring)), 96 * 96 * 5, L.ptr(dev(idx)), 4, L.ptr(out), L.stream_ptr())
+    assert torch.equal(out.cpu(), ring[idx])
+
+
+def test_error_reporting(L):
+    rc = L.lib.c.simq_plan_create(4, 9, ctypes.byref(ctypes.c_void_p()))
+    assert rc != 0 and 'num_output_channels' in L.last_error()
+    with pytest.raises(L.SimqError):
+        L.Plan(0, 1)
