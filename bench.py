@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- Q-map transitions/sec of the spatial-action-map DQN training step on MI355X.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on):
+  lifting_1-small_empty: Cin=4 -> Cout=2, minibatch 32 per GPU, fp32, double DQN,
+  lr 0.01 / momentum 0.9 / wd 1e-4 / clip 100, synthetic replay (seeded).
+A "step" is ONE full reference train() call (train.py:108-141) on one sampled minibatch:
+  replay index sampling + HBM gather, policy forward (train-mode BN), double-DQN next-state
+  forwards (policy train-mode no-grad + target eval), TD target + Huber, backward, global-norm
+  clip, momentum SGD, and the two scalar read-backs the reference does (.item()).
+  That is metric definition M2 of SURVEY 8d (65.0 GFLOP/transition); nothing is skipped.
+N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL), weak scaling (32
+transitions per GPU), per-rank BatchNorm statistics (the reference's DataParallel semantics),
+ONE all-reduce of the flat 45 MB gradient buffer per step.
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CIN, COUT, BATCH_PER_GPU = 4, 2, 32
+GAMMA, LR, MOMENTUM, WD, CLIP = 0.75, 0.01, 0.9, 1e-4, 100.0
+REPLAY_ITEMS = 1024                      # synthetic transitions resident in the HBM ring per rank
+FLOP_M1, FLOP_M2 = 38.963e9, 64.976e9    # per transition, SURVEY 8d [probe-derived] (fwd+bwd / full train())
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, steps=3):
+    """The oracle (CPU restatement, pinned bit-exact to the reference in the build container)
+    running the SAME step on this box's host cores.  Bounded sample: 1 warm-up + `steps` timed
+    train() calls at the GPU workload's batch size."""
+    from oracle import cases, fcn as ofcn, learner as olearner
+    from simq import synth
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = cases.make_cfg(batch)
+    spec = ofcn.state_spec(CIN, COUT)
+    st = ofcn.state_from_numpy(synth.make_state_dict(CIN, COUT, 1))
+    tg = ofcn.state_from_numpy(synth.make_state_dict(CIN, COUT, 2))
+    mom = [None] * len(olearner.grad_keys(spec))
+    trs = synth.make_transitions(batch, CIN, COUT, 3, terminal_frac=0.1)
+    b = olearner.Transition(*zip(*trs))
+    olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
+    dt = time.perf_counter() - t0
+    return {'value': round(batch * steps / dt, 3), 'unit': 'transitions/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), batch %d, '
+                      '1 warm-up + %d timed calls, %.1f s' % (batch, steps, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (no GPU visible); there is no CPU product path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    import simq
+    from simq import synth
+    from simq._lib import lib
+    from simq.learner import _opt_state, train_step
+
+    policy, target = simq.FCN(CIN, COUT, device=dev), simq.FCN(CIN, COUT, device=dev)
+    sd = {k: torch.from_numpy(v) if v.shape != () else torch.tensor(int(v)) for k, v in synth.make_state_dict(CIN, COUT, 1).items()}
+    policy.load_state_dict(sd)          # identical weights on every rank (DataParallel replicas)
+    target.copy_state_from(policy)
+    policy.train()
+    target.eval()
+    st_opt = _opt_state(policy, None)
+
+    # synthetic replay, resident in HBM before the timed region (same content on every rank)
+    trs = synth.make_transitions(REPLAY_ITEMS, CIN, COUT, 5, terminal_frac=0.1)
+    ring = simq.DeviceReplayBuffer(REPLAY_ITEMS, CIN, device=dev)
+    ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
+                   np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
+                   [t[3] is None for t in trs])
+    B, gB = BATCH_PER_GPU, BATCH_PER_GPU * world
+    random.seed(1234)                   # every rank draws the same global minibatch, then takes its slice
+
+    def step():
+        idx = ring.sample_indices(gB)
+        batch = ring.gather(idx[rank * B:(rank + 1) * B])
+        return train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
+                          opt_state=st_opt, process_group=pg, global_batch=gB, sync=True)
+
+    def barrier():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        info = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if pg is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if not np.isfinite(info['loss']):
+        sys.exit('bench: non-finite loss %r' % (info,))
+    value = gB * args.steps / dt
+
+    roof = None
+    if not args.no_roofline:
+        # live per-launch timing of the GEMM-class kernels (HIP events on the launch stream) over the same K steps
+        lib.call('simq_profile_start')
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_inst = time.perf_counter() - t1
+        out = (ctypes.c_double * 8)()
+        lib.call('simq_profile_stop', out, 2)
+        ig = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}
+        wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}
+        ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
+        roof = {
+            'bound': 'mfma', 'kernel': 'igemm_conv_kernel (implicit-GEMM conv forward + dgrad, v_mfma_f32_32x32x2_f32)',
+            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            'traffic': None,
+            'launches_per_step': ig['launches'] / args.steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
+            'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
+            'kernel_ms_per_step': round(ig['ms'] / args.steps, 4),
+            'wgrad': {'launches_per_step': wg['launches'] / args.steps, 'kernel_ms_per_step': round(wg['ms'] / args.steps, 4),
+                      'achieved': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2) if wg['ms'] > 0 else 0.0,
+                      'frac': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if wg['ms'] > 0 else 0.0},
+            'whole_step': {'mfma_frac_M2': round(value / world * FLOP_M2 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                           'hbm_frac_activation_lower_bound': round(value / world * 61.9e6 / (PEAK_HBM_GBS * 1e9), 5)},
+            'ms_per_step_instrumented': round(dt_inst / args.steps * 1e3, 3),
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(BATCH_PER_GPU)
+
+    if rank == 0:
+        line = {
+            'metric': 'Q-map transitions/sec (full train() step: 3 fwd + bwd + clip + SGD, 96x96)',
+            'value': round(value, 2), 'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'lifting_1-small_empty (Cin=4, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
+                                   'device-resident replay of %d transitions' % (BATCH_PER_GPU, REPLAY_ITEMS),
+                       'global_batch': gB, 'parallelism': 'dp%d' % world,
+                       'flop_per_transition': FLOP_M2, 'last_loss': info['loss'], 'last_td_error': info['td_error']},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if pg is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

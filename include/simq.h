@@ -137,6 +137,13 @@ int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* z
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream);
 int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
 
+/* ---- measurement aid (bench.py): HIP-event timing of the GEMM-class launches ----------------
+ * Between start and stop every implicit-GEMM (kind 0: forward + dgrad) and wgrad (kind 1) launch is
+ * bracketed by hipEventRecord on its own stream.  stop() fills, per kind,
+ * {launches, total ms, total algorithmic flops (2*M*N*K), total algorithmic bytes}.  Not thread-safe. */
+int simq_profile_start(void);
+int simq_profile_stop(double* out, int max_kinds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,10 @@ struct ConvEpilogue {
     int relu = 0;
 };
 
+// profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
+void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
+void prof_launch_end(hipStream_t stream);
+
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);

@@ -281,7 +281,12 @@ int run(const IgemmArgs& a, hipStream_t stream) {
     p.tilesN = p.Cout / BN;
     int tilesM = (p.M + BM - 1) / BM;
     dim3 grid((unsigned)(tilesM * p.tilesN));
+    // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
+    prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
+                      4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
+                      stream);
     hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, stream, p);
+    prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

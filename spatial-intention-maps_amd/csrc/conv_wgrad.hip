@@ -217,7 +217,11 @@ int run(const WgradArgs& a, hipStream_t stream) {
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
+    prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K,
+                      4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
+                      stream);
     hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream, p);
+    prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -58,6 +58,8 @@ _SIGS = {
     'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'simq_upsample2x_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'simq_profile_start': (c_int, []),
+    'simq_profile_stop': (c_int, [c_void_p, c_int]),
 }
 
 EXPORTS = tuple(_SIGS)

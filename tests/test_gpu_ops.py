@@ -101,7 +101,8 @@ def test_conv_transpose_detect(L):
     w = torch.arange(C * C, dtype=torch.float32).reshape(C, C, 1, 1) / 100.0
     y_ref = F.conv2d(x, w)
     yd = torch.empty(1, 24, 24, C, device='cuda')
-    L.lib.call('simq_conv2d_fwd', L.ptr(nhwc(x)), L.ptr(ohwi(w)), None, L.ptr(yd), 1, 24, 24, C, C, 1, 1, 1, 0, None,
+    xd, wd = nhwc(x), ohwi(w)
+    L.lib.call('simq_conv2d_fwd', L.ptr(xd), L.ptr(wd), None, L.ptr(yd), 1, 24, 24, C, C, 1, 1, 1, 0, None,
                L.stream_ptr())
     assert torch.equal(yd.cpu(), y_ref.permute(0, 2, 3, 1).contiguous())
 
@@ -116,10 +117,11 @@ def test_upsample2x(L, shape):
     y.backward(dy)
     st = L.stream_ptr()
     yd = torch.empty(B, 2 * H, 2 * H, C, device='cuda')
-    L.lib.call('simq_upsample2x_fwd', L.ptr(nhwc(x.detach())), L.ptr(yd), B, H, H, C, st)
+    xd, dyd = nhwc(x.detach()), nhwc(dy)
+    L.lib.call('simq_upsample2x_fwd', L.ptr(xd), L.ptr(yd), B, H, H, C, st)
     assert rel(yd, y.detach().permute(0, 2, 3, 1)) < 1e-6
     dxd = torch.empty(B, H, H, C, device='cuda')
-    L.lib.call('simq_upsample2x_bwd', L.ptr(nhwc(dy)), L.ptr(dxd), B, H, H, C, st)
+    L.lib.call('simq_upsample2x_bwd', L.ptr(dyd), L.ptr(dxd), B, H, H, C, st)
     assert rel(dxd, x.grad.permute(0, 2, 3, 1)) < 1e-5
 
 
@@ -127,7 +129,8 @@ def test_layout_helpers(L):
     x = torch.randn(3, 5, 96, 96)
     st = L.stream_ptr()
     out = torch.empty(3, 96, 96, 5, device='cuda')
-    L.lib.call('simq_nchw_to_nhwc', L.ptr(dev(x)), L.ptr(out), 3, 5, 96 * 96, st)
+    xd = dev(x)
+    L.lib.call('simq_nchw_to_nhwc', L.ptr(xd), L.ptr(out), 3, 5, 96 * 96, st)
     assert torch.equal(out.cpu(), x.permute(0, 2, 3, 1).contiguous())
     back = torch.empty(3, 5, 96, 96, device='cuda')
     L.lib.call('simq_nhwc_to_nchw', L.ptr(out), L.ptr(back), 3, 5, 96 * 96, st)
@@ -172,12 +175,13 @@ def test_td_huber_and_scatter(L):
     st = L.stream_ptr()
     pos = dev(torch.nonzero(mask).squeeze(1).to(torch.int32))
     nsv = torch.full((B,), 9.0, device='cuda')
-    L.lib.call('simq_scatter_next_values', L.ptr(dev(vals)), L.ptr(pos), int(mask.sum()), L.ptr(nsv), B, st)
+    vals_d, q_d, a_d, r_d = dev(vals), dev(q.detach()), dev(a), dev(r)   # keep alive: raw pointers cross the ABI
+    L.lib.call('simq_scatter_next_values', L.ptr(vals_d), L.ptr(pos), int(mask.sum()), L.ptr(nsv), B, st)
     assert torch.equal(nsv.cpu(), nsv_ref)
     outs = [torch.empty(B, device='cuda') for _ in range(3)]
     out4 = torch.empty(4, device='cuda')
     dq = torch.empty(B, n, device='cuda')
-    L.lib.call('simq_td_huber', L.ptr(dev(q.detach())), B, n, L.ptr(dev(a)), L.ptr(dev(r)), L.ptr(nsv), gamma, 1.0 / B,
+    L.lib.call('simq_td_huber', L.ptr(q_d), B, n, L.ptr(a_d), L.ptr(r_d), L.ptr(nsv), gamma, 1.0 / B,
                L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(out4), L.ptr(dq), st)
     assert rel(outs[0], q_sa) < 1e-6 and rel(outs[1], y) < 1e-6
     assert rel(outs[2], (q_sa - y).abs()) < 1e-6
@@ -188,9 +192,13 @@ def test_td_huber_and_scatter(L):
 
 @pytest.mark.parametrize('count,max_norm', [(1003, 100.0), (4096, 0.5), (11249826, 100.0)])
 def test_clip_sgd(L, count, max_norm):
+    """clip_grad_norm_ + SGD(momentum 0.9, wd 1e-4) (train.py:133-135,186) restated in fp64.
+    (torch's own fp32 CPU norm of an 11M-element vector is only ~5e-4 accurate, so the yardstick
+    is the same formula in double precision; the small cases are also checked against torch.optim.)"""
     g = torch.Generator().manual_seed(count)
     p = torch.randn(count, generator=g)
     gr = torch.randn(count, generator=g) * 0.05
+    p64, m64 = p.double(), None
     pt = p.clone().requires_grad_(True)
     opt = torch.optim.SGD([pt], lr=0.01, momentum=0.9, weight_decay=1e-4)
     pd, md = dev(p), torch.zeros(count, device='cuda')
@@ -199,23 +207,33 @@ def test_clip_sgd(L, count, max_norm):
     st = L.stream_ptr()
     for step in range(3):
         grad = gr * (step + 1)
-        pt.grad = grad.clone()
-        total = torch.nn.utils.clip_grad_norm_([pt], max_norm)
-        opt.step()
+        g64 = grad.double()
+        total = float(g64.norm())
+        g64 = g64 * min(1.0, max_norm / (total + 1e-6))
+        d = g64 + 1e-4 * p64
+        m64 = d.clone() if m64 is None else 0.9 * m64 + d
+        p64 = p64 - 0.01 * m64
         gd = dev(grad)
         L.lib.call('simq_clip_sgd_step', L.ptr(pd), L.ptr(gd), L.ptr(md), count, max_norm, 0.01, 0.9, 1e-4,
                    1 if step == 0 else 0, L.ptr(scratch), L.ptr(tn), st)
-        assert abs(tn.item() - float(total)) < 1e-5 * float(total)
-        assert rel(gd, pt.grad) < 1e-5          # clipped gradient left in place
-        assert rel(pd, pt.detach()) < 1e-6
-        assert rel(md, opt.state[pt]['momentum_buffer']) < 1e-5
+        assert abs(tn.item() - total) < 1e-6 * total
+        assert rel(gd, g64) < 1e-6              # clipped gradient left in place (clip_grad_norm_ semantics)
+        assert rel(pd, p64) < 1e-6
+        assert rel(md, m64) < 1e-6
+        if count < 100000:                      # and against torch's own implementation
+            pt.grad = grad.clone()
+            torch.nn.utils.clip_grad_norm_([pt], max_norm)
+            opt.step()
+            assert rel(pd, pt.detach()) < 1e-6
+            assert rel(md, opt.state[pt]['momentum_buffer']) < 1e-5
 
 
 def test_replay_gather(L):
     ring = torch.randn(20, 96, 96, 5)
     idx = torch.tensor([3, 19, 0, 3], dtype=torch.int64)
     out = torch.empty(4, 96, 96, 5, device='cuda')
-    L.lib.call('simq_replay_gather', L.ptr(dev(ring)), 96 * 96 * 5, L.ptr(dev(idx)), 4, L.ptr(out), L.stream_ptr())
+    ring_d, idx_d = dev(ring), dev(idx)
+    L.lib.call('simq_replay_gather', L.ptr(ring_d), 96 * 96 * 5, L.ptr(idx_d), 4, L.ptr(out), L.stream_ptr())
     assert torch.equal(out.cpu(), ring[idx])
 
 
