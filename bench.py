@@ -49,14 +49,19 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch, steps=3):
+def cpu_baseline(batch):
     """The oracle (CPU restatement, pinned bit-exact to the reference in the build container)
-    running the SAME step on this box's host cores.  Bounded sample: 1 warm-up + `steps` timed
-    train() calls at the GPU workload's batch size."""
+    running the SAME step on this box's host cores.  Bounded sample (~10-30 s): 1 warm-up + up to 3
+    timed train() calls at the GPU workload's batch size.  Threads: the CPUs this process may run
+    on, capped at 32 (oversubscribing a 256-thread host made MKL-DNN 30x slower: 0.26 tr/s)."""
     from oracle import cases, fcn as ofcn, learner as olearner
     from simq import synth
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 32))
+    torch.set_num_threads(nthreads)
     cfg = cases.make_cfg(batch)
     spec = ofcn.state_spec(CIN, COUT)
     st = ofcn.state_from_numpy(synth.make_state_dict(CIN, COUT, 1))
@@ -64,15 +69,19 @@ def cpu_baseline(batch, steps=3):
     mom = [None] * len(olearner.grad_keys(spec))
     trs = synth.make_transitions(batch, CIN, COUT, 3, terminal_frac=0.1)
     b = olearner.Transition(*zip(*trs))
+    t0 = time.perf_counter()
     olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
+    warm = time.perf_counter() - t0
+    steps = 3 if warm < 8 else 1
     t0 = time.perf_counter()
     for _ in range(steps):
         olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
     dt = time.perf_counter() - t0
-    return {'value': round(batch * steps / dt, 3), 'unit': 'transitions/s', 'cores': torch.get_num_threads(),
+    return {'value': round(batch * steps / dt, 3), 'unit': 'transitions/s', 'cores': nthreads,
             'kind': 'port',
             'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), batch %d, '
-                      '1 warm-up + %d timed calls, %.1f s' % (batch, steps, dt)}
+                      '1 warm-up (%.1f s) + %d timed calls (%.1f s); host reports %d CPUs (%d usable)'
+                      % (batch, warm, steps, dt, os.cpu_count() or 0, avail)}
 
 
 def main():
