@@ -105,7 +105,7 @@ def main():
         pg = dist.group.WORLD
 
     import simq
-    from simq import synth
+    from simq import dist as sdist, synth
     from simq._lib import lib
     from simq.learner import _opt_state, train_step
 
@@ -128,7 +128,7 @@ def main():
 
     def step():
         idx = ring.sample_indices(gB)
-        batch = ring.gather(idx[rank * B:(rank + 1) * B])
+        batch = ring.gather(sdist.shard_indices(idx, world, rank))
         return train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
                           opt_state=st_opt, process_group=pg, global_batch=gB, sync=True)
 
@@ -146,9 +146,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if pg is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = sdist.max_over_ranks(dt, dev, pg)
     if not np.isfinite(info['loss']):
         sys.exit('bench: non-finite loss %r' % (info,))
     value = gB * args.steps / dt

@@ -96,14 +96,15 @@ class _BN:
                             s[name + '.weight'], s[name + '.bias'], False, BN_MOMENTUM, BN_EPS)
 
 
-def fcn_forward(state, x, training, taps=None):
+def fcn_forward(state, x, training, taps=None, update_buffers=True):
     """FCN.forward (networks.py:16-26) on NCHW ``x``.
 
     ``state``: dict of tensors keyed as state_spec(); BN buffers are updated IN
-    PLACE when ``training`` (as the reference modules do).  ``taps``: optional
+    PLACE when ``training`` (as the reference modules do) unless ``update_buffers`` is False
+    (a DataParallel replica on device != 0, whose buffer updates are discarded).  ``taps``: optional
     OrderedDict that receives named intermediate activations (for bisecting).
     """
-    bn = _BN(state, training)
+    bn = _BN(state, training, update_buffers)
     r = PREFIX + 'resnet18.'
 
     def tap(name, t):

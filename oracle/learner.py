@@ -168,3 +168,56 @@ def forward_backward(state, spec, state_batch, action_batch, y, dtype=torch.floa
         for p in params:
             p.requires_grad_(False)
     return loss.item(), q.detach(), OrderedDict(zip(gkeys, grads)), output.detach()
+
+
+# ---- data-parallel emulation (fixture G7) ------------------------------------------------
+def shard_gradients(cfg, state, target_state, spec, shard_batch, global_batch, discount_factor, update_buffers,
+                    dtype=torch.float32):
+    """What ONE DataParallel replica contributes (policies.py:39): forward of its shard with its own
+    train-mode BN statistics, Huber SUM over the shard divided by the GLOBAL batch, backward.
+    Returns (flat gradient in grad_keys order, [sum huber, sum |td|])."""
+    B = len(shard_batch.action)
+    state_batch = torch.cat([apply_transform(s) for s in shard_batch.state]).to(dtype)
+    action_batch = torch.tensor(shard_batch.action, dtype=torch.long)
+    reward_batch = torch.tensor(shard_batch.reward, dtype=torch.float32).to(dtype)
+    nf = [apply_transform(s) for s in shard_batch.next_state if s is not None]
+    mask = torch.tensor(tuple(s is not None for s in shard_batch.next_state), dtype=torch.bool)
+    gkeys = grad_keys(spec)
+    params = [state[k] for k in gkeys]
+    for p in params:
+        p.requires_grad_(True)
+    try:
+        output = fcn.fcn_forward(state, state_batch, True, update_buffers=update_buffers)
+        q = output.view(B, -1).gather(1, action_batch.unsqueeze(1)).squeeze(1)
+        nsv = torch.zeros(B, dtype=dtype)
+        if nf:
+            nfns = torch.cat(nf).to(dtype)
+            n = nfns.size(0)
+            with torch.no_grad():
+                best = fcn.fcn_forward(state, nfns, True, update_buffers=update_buffers).view(n, -1).max(1)[1].view(n, 1)
+                nsv[mask] = fcn.fcn_forward(target_state, nfns, False).view(n, -1).gather(1, best).view(-1)
+        y = reward_batch + discount_factor * nsv
+        huber = smooth_l1_loss(q, y, reduction='sum')
+        grads = torch.autograd.grad(huber / global_batch, params)
+    finally:
+        for p in params:
+            p.requires_grad_(False)
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    return flat, torch.stack([huber.detach(), torch.abs(q - y).detach().sum()])
+
+
+def dp_emulation(cfg, state, target_state, spec, batch, world_size, discount_factor, dtype=torch.float32):
+    """Single-process emulation of an N-replica step: contiguous shards (torch.chunk sizes), per-shard BN
+    statistics, gradient sum, rank 0's running statistics kept.  Returns (flat grad sum, loss, td_error)."""
+    gB = len(batch.action)
+    chunk = -(-gB // world_size)
+    total, sums = None, torch.zeros(2, dtype=dtype)
+    for r in range(world_size):
+        lo, hi = min(r * chunk, gB), min((r + 1) * chunk, gB)
+        if lo == hi:
+            continue
+        shard = Transition(*[f[lo:hi] for f in batch])
+        flat, s = shard_gradients(cfg, state, target_state, spec, shard, gB, discount_factor, update_buffers=(r == 0), dtype=dtype)
+        total = flat if total is None else total + flat
+        sums = sums + s
+    return total, float(sums[0]) / gB, float(sums[1]) / gB

@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the data-parallel path of the TD step (simq.dist) -- sharding, global-batch
+loss normalisation, ONE all-reduce of the flat gradient, rank-0 BatchNorm buffers -- against the
+single-process sharded emulation (oracle.learner.dp_emulation).  The per-rank compute is
+the oracle here (no GPU in this container); on the MI355X box the same simq.dist calls carry the HIP
+gradients over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cases
+from oracle import fcn as ofcn
+from oracle import learner as olearner
+
+CIN, COUT, GB, WSEED, DSEED = 4, 2, 4, 71, 72
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, 'spatial-intention-maps_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from simq import dist as sdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = cases.make_cfg(GB)
+        spec = ofcn.state_spec(CIN, COUT)
+        batch = cases.make_batch(CIN, COUT, GB, DSEED)          # every rank draws the same global minibatch
+        st, tg = cases.oracle_state(CIN, COUT, WSEED), cases.oracle_state(CIN, COUT, WSEED + 1)
+        lo, hi = sdist.shard_bounds(GB, world, rank)
+        shard = olearner.Transition(*[f[lo:hi] for f in batch])
+        flat, sums = olearner.shard_gradients(cfg, st, tg, spec, shard, GB, cases.GAMMA, update_buffers=True)
+        sdist.allreduce_gradients(flat, sums)
+        bn = torch.from_numpy(cases.bn_buffer_vector(st)).clone()
+        sdist.broadcast_bn_buffers(bn)                            # rank 0's running statistics win
+        t = sdist.max_over_ranks(float(rank + 1), torch.device('cpu'))
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), flat=flat.numpy(), sums=sums.numpy(), bn=bn.numpy(), tmax=t)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from simq import dist as sdist
+    assert [sdist.shard_bounds(32, 4, r) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    assert [sdist.shard_bounds(5, 2, r) for r in range(2)] == [(0, 3), (3, 5)]          # torch.chunk sizes
+    assert [sdist.shard_bounds(3, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert sdist.shard_indices(list(range(10, 20)), 2, 1) == [15, 16, 17, 18, 19]
+    with pytest.raises(ValueError):
+        sdist.shard_bounds(4, 2, 2)
+
+
+def test_two_rank_gloo_matches_sharded_emulation(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    assert np.array_equal(r0['flat'], r1['flat']) and np.array_equal(r0['sums'], r1['sums'])   # all ranks agree
+    assert np.array_equal(r0['bn'], r1['bn']) and float(r0['tmax']) == 2.0
+    cfg, spec = cases.make_cfg(GB), ofcn.state_spec(CIN, COUT)
+    batch = cases.make_batch(CIN, COUT, GB, DSEED)
+    st, tg = cases.oracle_state(CIN, COUT, WSEED), cases.oracle_state(CIN, COUT, WSEED + 1)
+    total, loss, td = olearner.dp_emulation(cfg, st, tg, spec, batch, world, cases.GAMMA)
+    err = np.abs(r0['flat'] - total.numpy()).max() / np.abs(total.numpy()).max()
+    assert err < 1e-5, err
+    assert abs(r0['sums'][0] / GB - loss) < 1e-5 * abs(loss) and abs(r0['sums'][1] / GB - td) < 1e-5 * abs(td)
+    # rank 0's running statistics == the emulation's (shard 0 only)
+    assert np.abs(r0['bn'] - cases.bn_buffer_vector(st)).max() < 1e-6
+    # and per-shard BN differs from full-batch BN (this is NOT SyncBN -- the reference's DataParallel semantics)
+    st2, tg2 = cases.oracle_state(CIN, COUT, WSEED), cases.oracle_state(CIN, COUT, WSEED + 1)
+    full, _ = olearner.shard_gradients(cfg, st2, tg2, spec, batch, GB, cases.GAMMA, update_buffers=True)
+    assert np.abs(full.numpy() - total.numpy()).max() / np.abs(total.numpy()).max() > 1e-3
