@@ -143,6 +143,8 @@ int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int
  * {launches, total ms, total algorithmic flops (2*M*N*K), total algorithmic bytes}.  Not thread-safe. */
 int simq_profile_start(void);
 int simq_profile_stop(double* out, int max_kinds);
+/* tuning aid (tools/tune_conv.py): force the implicit-GEMM block tile BM x BN; bm = 0 restores the cost model */
+int simq_tune_force_tile(int bm, int bn);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ struct ConvEpilogue {
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
 void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
 void prof_launch_end(hipStream_t stream);
+void tune_force_tile(int bm, int bn);   // conv_igemm.hip: force one tile of the menu (0 = automatic)
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream);

@@ -10,15 +10,22 @@
 //     stride-1 convolution is the same contraction over the flipped/transposed weight
 //     produced by weight_transpose_kernel.
 //
-// Tiling: 256 threads = 4 waves (WM x WN); block tile BM x BN, K-step 16; each wave owns
-// (BM/WM) x (BN/WN) as TM x TN tiles of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain,
-// 64 cycles/instruction/SIMD).  Operands are staged global -> VGPR -> LDS ([row][16+4 pad]
-// floats, conflict-free ds_read_b128: lane (i, h) reads k = 8*kb + 4*h .. +3 of row i and
-// feeds four consecutive MFMAs), double-buffered with one barrier per K-step so the next
-// tile's global loads fly under the current tile's MFMAs.
+// Tiling: 256 threads = 4 wave64 as 2 x 2; block tile BM x BN (multiples of 32), K-step 16;
+// each wave owns (BM/2) x (BN/2) as TM x TN tiles of v_mfma_f32_16x16x4_f32 (exact fp32
+// FMA chain, 32 cycles/instruction/SIMD = the full fp32 matrix rate).  The 16-granular
+// MFMA shape is what lets the host pick BM x BN per layer so that the block count is a
+// whole multiple of the 256 CUs (24x24 feature maps give M = B*576 rows: at B = 32 a
+// 128x128 tiling of layer4 is 576 blocks = 2.25 per CU, a 96x128 tiling is 768 = 3.0).
+// Operands are staged global -> VGPR -> LDS ([row][16+8 pad] floats: every 16-lane group
+// of a ds_read_b128 hits 16 distinct 16-B slots); lane (i, q) reads k = 4q..4q+3 of row i
+// and feeds four consecutive MFMAs.  Two LDS stages, one barrier per K-step: the next
+// tile's global loads are issued before the current tile's MFMAs and stored after them.
 //
 // Epilogue (all optional, fused): +bias, per-channel sum / sum-of-squares for train-mode
 // BatchNorm (fp64 atomics of per-block partials), folded-BN affine, residual add, ReLU.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace simq {
@@ -26,7 +33,7 @@ namespace simq {
 namespace {
 
 constexpr int BK = 16;
-constexpr int LDK = 20;  // padded row stride (floats): 80 B -> 16 distinct 16-B slots per 16 rows
+constexpr int LDK = 24;  // padded row stride (floats): 96 B -> conflict-free ds_read_b128 for the 16x16x4 fragment
 
 struct IgemmArgs {
     const float* x;
@@ -43,12 +50,10 @@ struct IgemmArgs {
     int tilesN;
 };
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, bool VEC>
 __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
-    static_assert(WM * WN == 4, "4 waves per block");
-    constexpr int TM = BM / WM / 32;
-    constexpr int TN = BN / WN / 32;
-    static_assert(TM >= 1 && TN >= 1, "wave tile must be a multiple of 32x32");
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
+    constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave (2x2 waves)
     constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK;
     constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
     // one LDS object: [2 stages of A|B] [row info int4 x BM]
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> 1, wn = wave & 1;
     const int tile_m = blockIdx.x / p.tilesN, tile_n = blockIdx.x % p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -79,18 +84,16 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     }
     __syncthreads();
 
-    floatx16 acc[TM][TN];
+    floatx4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
 
     // ---- staging registers ----
-    constexpr int A_PASSES_V = BM / 64, B_PASSES_V = (BN + 63) / 64;
+    constexpr int A_PASSES_V = (BM + 63) / 64, B_PASSES_V = (BN + 63) / 64;
     constexpr int A_PASSES_S = BM / 16, B_PASSES_S = BN / 16;
     float4 va[VEC ? A_PASSES_V : 1], vb[VEC ? B_PASSES_V : 1];
     float sa[VEC ? 1 : A_PASSES_S], sb[VEC ? 1 : B_PASSES_S];
@@ -103,21 +106,23 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
         if constexpr (VEC) {
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
-                int4 ri = rowinfo[lrow + 64 * ps];
-                int iy = ri.y + ky, ix = ri.z + kx;
-                bool ok = ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                const int r = lrow + 64 * ps;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    size_t off = (size_t)(ri.x + iy * p.Win + ix) * p.Cin + c0 + kq * 4;
-                    v = *reinterpret_cast<const float4*>(p.x + off);
+                if (BM % 64 == 0 || r < BM) {
+                    int4 ri = rowinfo[r];
+                    int iy = ri.y + ky, ix = ri.z + kx;
+                    if (ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
+                        size_t off = (size_t)(ri.x + iy * p.Win + ix) * p.Cin + c0 + kq * 4;
+                        v = *reinterpret_cast<const float4*>(p.x + off);
+                    }
                 }
                 va[ps] = v;
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
-                int n = lrow + 64 * ps;
+                const int n = lrow + 64 * ps;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (BN >= 64 || n < BN) {
+                if (BN % 64 == 0 || n < BN) {
                     size_t off = (size_t)(n0 + n) * p.K + (size_t)tap * p.Cin + c0 + kq * 4;
                     v = *reinterpret_cast<const float4*>(p.w + off);
                 }
@@ -147,12 +152,14 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
         float* Bs = As + A_FLOATS;
         if constexpr (VEC) {
 #pragma unroll
-            for (int ps = 0; ps < A_PASSES_V; ++ps)
-                *reinterpret_cast<float4*>(As + (lrow + 64 * ps) * LDK + kq * 4) = va[ps];
+            for (int ps = 0; ps < A_PASSES_V; ++ps) {
+                const int r = lrow + 64 * ps;
+                if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(As + r * LDK + kq * 4) = va[ps];
+            }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
-                int n = lrow + 64 * ps;
-                if (BN >= 64 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + kq * 4) = vb[ps];
+                const int n = lrow + 64 * ps;
+                if (BN % 64 == 0 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + kq * 4) = vb[ps];
             }
         } else {
 #pragma unroll
@@ -175,7 +182,8 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     store_tile(0);
     __syncthreads();
 
-    const int fi = lane & 31, fh = lane >> 5;
+    // v_mfma_f32_16x16x4_f32 operands: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]
+    const int fi = lane & 15, fq = lane >> 4;
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
@@ -185,44 +193,41 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
         }
         const float* As = smem + buf * STAGE_FLOATS;
         const float* Bs = As + A_FLOATS;
+        floatx4 af[TM], bf[TN];
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            floatx4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / 2) + i * 16 + fi) * LDK + fq * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bf[j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / 2) + j * 16 + fi) * LDK + fq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // MFMA e contracts k = {e, 4+e, 8+e, 12+e} (same permutation for A and B)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / WM) + i * 32 + fi) * LDK + kb * 8 + fh * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / WN) + j * 32 + fi) * LDK + kb * 8 + fh * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         if (more) store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
     // ---- epilogue ----
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
     float ssum[TN], ssq[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + fi;
+        const int n = n0 + wn * (BN / 2) + j * 16 + fi;
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float sc = p.scale ? p.scale[n] : 1.f;
         const float sh = p.scale ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * fq + r;
                 if (m < p.M) {
                     float v = acc[i][j][r] + bias;
                     ssum[j] += v;
@@ -237,25 +242,22 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
         }
     }
     if (p.stats) {   // block-uniform
-        double* red = reinterpret_cast<double*>(smem);   // [WM][BN][2], reuses the (now idle) stage buffers
+        double* red = reinterpret_cast<double*>(smem);   // [2 wave rows][BN][2], reuses the (now idle) stage buffers
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float s = ssum[j] + __shfl_xor(ssum[j], 32);
-            float q = ssq[j] + __shfl_xor(ssq[j], 32);
-            if (fh == 0) {
-                int c = wn * (BN / WN) + j * 32 + fi;
+            float s = ssum[j], q = ssq[j];
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (fq == 0) {
+                int c = wn * (BN / 2) + j * 16 + fi;
                 red[(wm * BN + c) * 2 + 0] = (double)s;
                 red[(wm * BN + c) * 2 + 1] = (double)q;
             }
         }
         __syncthreads();
         if (tid < BN) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                s += red[(i * BN + tid) * 2 + 0];
-                q += red[(i * BN + tid) * 2 + 1];
-            }
+            double s = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+            double q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
             unsafeAtomicAdd(p.stats + n0 + tid, s);
             unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, q);
         }
@@ -275,7 +277,7 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, bool VEC>
 int run(const IgemmArgs& a, hipStream_t stream) {
     IgemmArgs p = a;
     p.tilesN = p.Cout / BN;
@@ -285,10 +287,47 @@ int run(const IgemmArgs& a, hipStream_t stream) {
     prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, WM, WN, VEC>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC>), grid, dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- tile selection -------------------------------------------------------------------------------------
+// The 256 CUs share nothing, so the launch time is (max blocks on one CU) x (time of one block).  Pick the
+// (BM, BN) of the menu that minimises  ceil(blocks / 256) * BM * BN / efficiency(BM, BN):  bigger tiles reuse
+// operands better, but a block count that is not a multiple of 256 leaves CUs idle in the last round.
+struct TileCfg { int bm, bn; float eff; };
+constexpr TileCfg kMenu[] = {
+    {128, 128, 1.00f}, {96, 128, 0.97f}, {64, 128, 0.93f}, {128, 64, 0.93f}, {96, 64, 0.90f}, {64, 64, 0.85f},
+    {128, 32, 0.80f},  {96, 32, 0.78f},  {64, 32, 0.72f},  {32, 64, 0.72f},  {32, 32, 0.55f},
+};
+constexpr int kNumCU = 256;
+
+int g_forced_bm = -1, g_forced_bn = -1;   // tuning aid (tools/tune_conv.py): SIMQ_IGEMM_TILE=BMxBN or simq_tune_force_tile()
+
+int forced_tile(int* bm, int* bn) {
+    if (g_forced_bm == -1) {
+        g_forced_bm = 0;
+        const char* s = getenv("SIMQ_IGEMM_TILE");
+        if (s && sscanf(s, "%dx%d", &g_forced_bm, &g_forced_bn) != 2) g_forced_bm = 0;
+    }
+    *bm = g_forced_bm; *bn = g_forced_bn;
+    return g_forced_bm > 0;
+}
+
+template <bool VEC>
+int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream) {
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream)
+    if constexpr (VEC) {
+        SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
+        SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
+    } else {
+        SIMQ_TILE(128, 64); SIMQ_TILE(64, 64); SIMQ_TILE(32, 64);
+    }
+#undef SIMQ_TILE
+    set_error("conv_igemm: no kernel for tile %dx%d", bm, bn);
+    return -1;
 }
 
 }  // namespace
@@ -304,18 +343,24 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     SIMQ_REQUIRE(g.Cout % 32 == 0, "conv_igemm: Cout=%d must be a multiple of 32", g.Cout);
     const bool vec = (g.Cin % BK) == 0;
-    // fill the 256 CUs: prefer the 128-row tile only when it still yields >= 256 blocks
-    const int bn = (g.Cout % 128 == 0) ? 128 : (g.Cout % 64 == 0 ? 64 : 32);
-    const long blocks128 = (long)((a.M + 127) / 128) * (g.Cout / bn);
-    const bool big = blocks128 >= 256;
-    if (vec) {
-        if (bn == 128) return big ? run<128, 128, 2, 2, true>(a, stream) : run<64, 128, 2, 2, true>(a, stream);
-        if (bn == 64) return big ? run<128, 64, 2, 2, true>(a, stream) : run<64, 64, 2, 2, true>(a, stream);
-        return run<128, 32, 4, 1, true>(a, stream);
+    SIMQ_REQUIRE(vec || g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);
+    int bm = 0, bn = 0;
+    if (!forced_tile(&bm, &bn) || g.Cout % bn != 0 || (!vec && !(bn == 64 && (bm == 128 || bm == 64 || bm == 32)))) {
+        double best = 1e300;
+        for (const TileCfg& t : kMenu) {
+            if (g.Cout % t.bn != 0) continue;
+            if (!vec && !(t.bn == 64 && (t.bm == 128 || t.bm == 64 || t.bm == 32))) continue;
+            const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (g.Cout / t.bn);
+            const long rounds = (blocks + kNumCU - 1) / kNumCU;
+            double cost = (double)rounds * t.bm * t.bn / t.eff;
+            if (rounds == 1) cost *= 1.25;      // a lone block per CU cannot hide its barriers behind another block
+            if (cost < best) { best = cost; bm = t.bm; bn = t.bn; }
+        }
     }
-    SIMQ_REQUIRE(g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);
-    return big ? run<128, 64, 2, 2, false>(a, stream) : run<64, 64, 2, 2, false>(a, stream);
+    return vec ? dispatch<true>(bm, bn, a, stream) : dispatch<false>(bm, bn, a, stream);
 }
+
+void tune_force_tile(int bm, int bn) { g_forced_bm = bm > 0 ? bm : 0; g_forced_bn = bn; }
 
 int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, hipStream_t stream) {
     size_t total = (size_t)cout * taps * cin;

@@ -208,11 +208,19 @@ int run(const WgradArgs& a, hipStream_t stream) {
     p.tilesI = p.Cout / TI;
     p.tilesJ = VEC ? p.R * p.S * (p.Cin / TJ) : (p.K + TJ - 1) / TJ;
     const int tiles = p.tilesI * p.tilesJ;
-    // enough blocks to fill 256 CUs a few times over, but keep >= 8 reduction steps per block
-    int splits = (1024 + tiles - 1) / tiles;
-    int max_splits = (p.M + BR * 8 - 1) / (BR * 8);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    // Split the pixel reduction so that the block count fills the 256 CUs in whole rounds:
+    // time ~ ceil(tiles*s / 256) * (reduction steps per block + fixed prologue/atomic-epilogue cost).
+    const int rsteps = (p.M + BR - 1) / BR;
+    int max_splits = rsteps / 8;                     // keep >= 8 reduction steps per block
+    if (max_splits > 96) max_splits = 96;
+    if (max_splits < 1) max_splits = 1;
+    int splits = 1;
+    double best = 1e300;
+    for (int s = 1; s <= max_splits; ++s) {
+        const long rounds = ((long)tiles * s + 255) / 256;
+        const double cost = (double)rounds * ((rsteps + s - 1) / s + 6);
+        if (cost < best * 0.999) { best = cost; splits = s; }
+    }
     int rps = (p.M + splits - 1) / splits;
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;

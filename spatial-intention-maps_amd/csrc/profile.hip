@@ -66,4 +66,9 @@ int simq_profile_stop(double* out, int max_kinds) {
     return 0;
 }
 
+int simq_tune_force_tile(int bm, int bn) {
+    simq::tune_force_tile(bm, bn);
+    return 0;
+}
+
 }  // extern "C"

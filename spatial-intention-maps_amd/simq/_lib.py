@@ -60,6 +60,7 @@ _SIGS = {
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_profile_start': (c_int, []),
     'simq_profile_stop': (c_int, [c_void_p, c_int]),
+    'simq_tune_force_tile': (c_int, [c_int, c_int]),
 }
 
 EXPORTS = tuple(_SIGS)
