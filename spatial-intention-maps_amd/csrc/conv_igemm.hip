@@ -25,6 +25,7 @@
 // BatchNorm (fp64 atomics of per-block partials), folded-BN affine, residual add, ReLU.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -92,17 +93,20 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
 
     const int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
 
-    // ---- staging registers ----
+    // ---- staging registers: TWO sets, so global loads run two K-steps ahead of the MFMAs ----
     constexpr int A_PASSES_V = (BM + 63) / 64, B_PASSES_V = (BN + 63) / 64;
     constexpr int A_PASSES_S = BM / 16, B_PASSES_S = BN / 16;
-    float4 va[VEC ? A_PASSES_V : 1], vb[VEC ? B_PASSES_V : 1];
-    float sa[VEC ? 1 : A_PASSES_S], sb[VEC ? 1 : B_PASSES_S];
+    float4 va[2][VEC ? A_PASSES_V : 1], vb[2][VEC ? B_PASSES_V : 1];
+    float sa[2][VEC ? 1 : A_PASSES_S], sb[2][VEC ? 1 : B_PASSES_S];
 
     const int lrow = tid >> 2, kq = tid & 3;    // VEC: 4 threads x float4 per row, 64 rows per pass
     const int srow = tid >> 4, kl = tid & 15;   // SCALAR: 16 threads per row, 16 rows per pass
-    int tap = 0, c0 = 0, ky = 0, kx = 0;        // VEC: position of the current K-tile
+    // VEC K order: channel chunk outer, filter tap inner -- the R*S taps of one 16-channel chunk re-read the
+    // same 64-B lines of x (shifted rows), so they hit L1/L2 instead of streaming x once per tap.
+    int tap = 0, c0 = 0, ky = 0, kx = 0;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](auto set_c, int kt) {
+        constexpr int SET = decltype(set_c)::value;
         if constexpr (VEC) {
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
                         v = *reinterpret_cast<const float4*>(p.x + off);
                     }
                 }
-                va[ps] = v;
+                va[SET][ps] = v;
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
                     size_t off = (size_t)(n0 + n) * p.K + (size_t)tap * p.Cin + c0 + kq * 4;
                     v = *reinterpret_cast<const float4*>(p.w + off);
                 }
-                vb[ps] = v;
+                vb[SET][ps] = v;
             }
         } else {
             int k = kt * BK + kl;
@@ -138,59 +142,47 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
                 int4 ri = rowinfo[srow + 16 * ps];
                 int iy = ri.y + yy, ix = ri.z + xx;
                 bool ok = kok && ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                sa[ps] = ok ? p.x[(size_t)(ri.x + iy * p.Win + ix) * p.Cin + ci] : 0.f;
+                sa[SET][ps] = ok ? p.x[(size_t)(ri.x + iy * p.Win + ix) * p.Cin + ci] : 0.f;
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_S; ++ps) {
                 int n = srow + 16 * ps;
-                sb[ps] = kok ? p.w[(size_t)(n0 + n) * p.K + k] : 0.f;
+                sb[SET][ps] = kok ? p.w[(size_t)(n0 + n) * p.K + k] : 0.f;
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
         float* As = smem + buf * STAGE_FLOATS;
         float* Bs = As + A_FLOATS;
         if constexpr (VEC) {
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
                 const int r = lrow + 64 * ps;
-                if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(As + r * LDK + kq * 4) = va[ps];
+                if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(As + r * LDK + kq * 4) = va[SET][ps];
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
                 const int n = lrow + 64 * ps;
-                if (BN % 64 == 0 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + kq * 4) = vb[ps];
+                if (BN % 64 == 0 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + kq * 4) = vb[SET][ps];
             }
         } else {
 #pragma unroll
-            for (int ps = 0; ps < A_PASSES_S; ++ps) As[(srow + 16 * ps) * LDK + kl] = sa[ps];
+            for (int ps = 0; ps < A_PASSES_S; ++ps) As[(srow + 16 * ps) * LDK + kl] = sa[SET][ps];
 #pragma unroll
-            for (int ps = 0; ps < B_PASSES_S; ++ps) Bs[(srow + 16 * ps) * LDK + kl] = sb[ps];
+            for (int ps = 0; ps < B_PASSES_S; ++ps) Bs[(srow + 16 * ps) * LDK + kl] = sb[SET][ps];
         }
     };
-    auto advance = [&]() {   // VEC: next K-tile position
-        c0 += BK;
-        if (c0 >= p.Cin) {
-            c0 = 0;
-            ++tap;
-            ++kx;
-            if (kx >= p.S) { kx = 0; ++ky; }
-        }
+    auto advance = [&]() {   // VEC: next K-tile position (tap inner, channel chunk outer)
+        ++tap;
+        ++kx;
+        if (kx >= p.S) { kx = 0; ++ky; }
+        if (tap >= p.R * p.S) { tap = 0; kx = 0; ky = 0; c0 += BK; }
     };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
 
     // v_mfma_f32_16x16x4_f32 operands: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]
     const int fi = lane & 15, fq = lane >> 4;
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            if constexpr (VEC) advance();
-            load_tile(kt + 1);
-        }
+    auto compute = [&](int buf) {
         const float* As = smem + buf * STAGE_FLOATS;
         const float* Bs = As + A_FLOATS;
         floatx4 af[TM], bf[TN];
@@ -207,10 +199,39 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    // prologue: tile 0 -> LDS stage 0; tile 1 in flight in register set 1
+    load_tile(S0{}, 0);
+    store_tile(S0{}, 0);
+    if (nk > 1) {
+        if constexpr (VEC) advance();
+        load_tile(S1{}, 1);
     }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        // even step: tile kt is in stage 0, tile kt+1 is in flight in set 1; start tile kt+2 into set 0
+        if (kt + 2 < nk) {
+            if constexpr (VEC) advance();
+            load_tile(S0{}, kt + 2);
+        }
+        compute(0);
+        store_tile(S1{}, 1);
+        __syncthreads();
+        // odd step: tile kt+1 is in stage 1, tile kt+2 is in flight in set 0; start tile kt+3 into set 1
+        if (kt + 3 < nk) {
+            if constexpr (VEC) advance();
+            load_tile(S1{}, kt + 3);
+        }
+        compute(1);
+        if (kt + 2 < nk) store_tile(S0{}, 0);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);   // odd tile count: the last tile sits in stage 0
+    __syncthreads();
 
     // ---- epilogue ----
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
