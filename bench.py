@@ -36,6 +36,7 @@ GAMMA, LR, MOMENTUM, WD, CLIP = 0.75, 0.01, 0.9, 1e-4, 100.0
 REPLAY_ITEMS = 1024                      # synthetic transitions resident in the HBM ring per rank
 FLOP_M1, FLOP_M2 = 38.963e9, 64.976e9    # per transition, SURVEY 8d [probe-derived] (fwd+bwd / full train())
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA (not the 2:1-sparse marketing figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -46,6 +47,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+                    help="arithmetic of the 3x3/1x1 convolutions; the default 'fp32' (exact) is the BASELINE configs[1] workload")
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='transitions per GPU per step (default: configs[1])')
+    ap.add_argument('--cin', type=int, default=CIN)
     return ap.parse_args()
 
 
@@ -109,7 +114,10 @@ def main():
     from simq._lib import lib
     from simq.learner import _opt_state, train_step
 
-    policy, target = simq.FCN(CIN, COUT, device=dev), simq.FCN(CIN, COUT, device=dev)
+    global CIN, BATCH_PER_GPU
+    CIN, BATCH_PER_GPU = args.cin, args.batch
+    policy = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
+    target = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
     sd = {k: torch.from_numpy(v) if v.shape != () else torch.tensor(int(v)) for k, v in synth.make_state_dict(CIN, COUT, 1).items()}
     policy.load_state_dict(sd)          # identical weights on every rank (DataParallel replicas)
     target.copy_state_from(policy)
@@ -166,33 +174,38 @@ def main():
         ig = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}
         wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}
         ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
+        PEAK = PEAK_FP32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+        kname = {'fp32': 'igemm_conv_kernel (implicit-GEMM conv forward + dgrad, v_mfma_f32_16x16x4_f32)',
+                 'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
+                           'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
+                 'bf16': 'igemm_bf16_kernel<NP=1> (bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16)'}[args.precision]
         roof = {
-            'bound': 'mfma', 'kernel': 'igemm_conv_kernel (implicit-GEMM conv forward + dgrad, v_mfma_f32_32x32x2_f32)',
-            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            'bound': 'mfma', 'kernel': kname,
+            'achieved': round(ach, 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK, 4),
             'traffic': None,
             'launches_per_step': ig['launches'] / args.steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
             'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
             'kernel_ms_per_step': round(ig['ms'] / args.steps, 4),
             'wgrad': {'launches_per_step': wg['launches'] / args.steps, 'kernel_ms_per_step': round(wg['ms'] / args.steps, 4),
                       'achieved': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2) if wg['ms'] > 0 else 0.0,
-                      'frac': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if wg['ms'] > 0 else 0.0},
-            'whole_step': {'mfma_frac_M2': round(value / world * FLOP_M2 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                      'frac': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12 / PEAK, 4) if wg['ms'] > 0 else 0.0},
+            'whole_step': {'mfma_frac_M2': round(value / world * FLOP_M2 / (PEAK * 1e12), 4),
                            'hbm_frac_activation_lower_bound': round(value / world * 61.9e6 / (PEAK_HBM_GBS * 1e9), 5)},
             'ms_per_step_instrumented': round(dt_inst / args.steps * 1e3, 3),
         }
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(BATCH_PER_GPU)
+        cpu = cpu_baseline(min(BATCH_PER_GPU, 32))
 
     if rank == 0:
         line = {
             'metric': 'Q-map transitions/sec (full train() step: 3 fwd + bwd + clip + SGD, 96x96)',
             'value': round(value, 2), 'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'lifting_1-small_empty (Cin=4, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
-                                   'device-resident replay of %d transitions' % (BATCH_PER_GPU, REPLAY_ITEMS),
+            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMA products, f32 accumulate)', 'bf16': 'bf16 (f32 accumulate / BN / optimiser)'}[args.precision], 'data': 'synthetic',
+            'config': {'workload': '%s (Cin=%d, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
+                                   'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
                        'global_batch': gB, 'parallelism': 'dp%d' % world,
                        'flop_per_transition': FLOP_M2, 'last_loss': info['loss'], 'last_td_error': info['td_error']},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -50,13 +50,21 @@ extern "C" {
 #define SIMQ_KIND_BN_W 2
 #define SIMQ_KIND_BN_B 3
 
+/* arithmetic of the 3x3 / 1x1 convolutions (BatchNorm statistics, accumulation, master weights, optimiser: always fp32;
+ * the 7x7 stem on the Cin = 3..10 image and the 32 -> Cout head conv3 always run in fp32) */
+#define SIMQ_PREC_FP32 0            /* v_mfma_f32_16x16x4_f32: exact fp32 FMA chains                                   */
+#define SIMQ_PREC_BF16X3 1          /* split-bf16: v = hi + lo, hi*hi + hi*lo + lo*hi on the bf16 matrix cores (~2^-17) */
+#define SIMQ_PREC_BF16 2            /* plain bf16 operands, fp32 accumulate (BASELINE configs 3 and 5)                  */
+
 typedef struct simq_plan simq_plan;
 
 int simq_version(void);
 const char* simq_last_error(void);
 
 /* ---- plan: the network of networks.py:7-14 for (Cin, Cout); replaces FCN.__init__ ---------- */
-int simq_plan_create(int num_input_channels, int num_output_channels, simq_plan** out);
+int simq_plan_create(int num_input_channels, int num_output_channels, simq_plan** out);   /* SIMQ_PREC_FP32 */
+int simq_plan_create_ex(int num_input_channels, int num_output_channels, int precision, simq_plan** out);
+int simq_plan_precision(const simq_plan* plan);
 void simq_plan_destroy(simq_plan* plan);
 
 /* Flat parameter buffer layout.  All tensors that receive a gradient (70 in the
@@ -76,6 +84,11 @@ int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_ca
 
 /* Bytes of workspace simq_forward/simq_backward need for `batch` samples. */
 int64_t simq_workspace_bytes(const simq_plan* plan, int batch);
+
+/* Inspection aid (parity bisecting): where a saved NHWC fp32 activation lives inside the workspace after simq_forward.
+ * name: "stem.conv" | "stem.pool" | "layer<1-4>.<0-1>" (BasicBlock outputs) | "head.a1" | "head.a2".              */
+int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems,
+                          int* channels);
 
 /* ---- FCN.forward (networks.py:16-26) ---------------------------------------------------------
  * d_x      [batch][96][96][Cin] fp32 NHWC  (== the reference's HWC replay states, stacked)
@@ -134,6 +147,13 @@ int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scra
 int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* zeroed by callee */,
                       int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
                       void* stream);
+/* bf16 matrix-core variants: the fp32 inputs are split into bf16 planes in d_scratch first
+ * (nplanes 1: plain bf16; 2: split-bf16 hi/lo, 3 MFMA products).  d_scratch: 2*(|x|+|w|) resp. 2*(|x|+|dy|) uint16. */
+int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y, int batch, int hin, int win,
+                         int cin, int cout, int r, int s, int stride, int pad, int nplanes, void* d_scratch, double* d_stats,
+                         void* stream);
+int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
+                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream);
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream);
 int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
 

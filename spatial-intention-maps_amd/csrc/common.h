@@ -55,8 +55,20 @@ void tune_force_tile(int bm, int bn);   // conv_igemm.hip: force one tile of the
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
+int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
+// bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
+int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,
+                           const ConvEpilogue& e, hipStream_t stream);
+int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
+                           hipStream_t stream);
+int launch_split_planes(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t stream);
+int launch_weight_planes(const float* w, uint16_t* w_hi, uint16_t* w_lo, uint16_t* wt_hi, uint16_t* wt_lo, int cout, int taps,
+                         int cin, hipStream_t stream);
 // wt[ci][R*S-1-t][co] = w[co][t][ci]
 int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, hipStream_t stream);
+
+// optional bf16 plane outputs of the elementwise producers (hi == nullptr: none; lo == nullptr: plain bf16)
+struct Planes { uint16_t* hi = nullptr; uint16_t* lo = nullptr; };
 
 // ---- channel-last elementwise / reduction kernels (elementwise.hip) -------------------------------
 // BN finalize.  train: mean/var from stats[2C] over `rows`, running update, writes scale/shift/mean/invstd.
@@ -68,10 +80,10 @@ int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const 
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res,
                     const float* rscale, const float* rshift, int relu, float* out, int64_t rows, int C,
-                    hipStream_t stream);
+                    hipStream_t stream, Planes pl = Planes());
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
 int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx,
-                         int B, int H, int W, int C, hipStream_t stream);
+                         int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
                          int C, hipStream_t stream);
@@ -81,11 +93,11 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 // dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
-                        float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream);
+                        float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes());
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);
-int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream);
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
 int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream);
 int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t stream);
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t stream);

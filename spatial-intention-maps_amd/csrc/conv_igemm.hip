@@ -381,6 +381,8 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     return vec ? dispatch<true>(bm, bn, a, stream) : dispatch<false>(bm, bn, a, stream);
 }
 
+int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }
+
 void tune_force_tile(int bm, int bn) { g_forced_bm = bm > 0 ? bm : 0; g_forced_bn = bn; }
 
 int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, hipStream_t stream) {

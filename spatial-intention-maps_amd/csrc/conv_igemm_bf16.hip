@@ -1,0 +1,315 @@
+// Implicit-GEMM convolution on the bf16 matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Same contraction and tiling idea as conv_igemm.hip (reference operators: every nn.Conv2d forward of
+// networks.py:18-26 / resnet.py:94-102 except the 7x7 stem, and every dgrad of train.py:132), but the
+// operands arrive as bf16 PLANES:
+//   NP = 1  plain bf16 inputs (BASELINE configs 3 and 5)
+//   NP = 2  "split-bf16": every fp32 operand v is stored as hi = bf16(v), lo = bf16(v - hi) and the product
+//           is formed as hi*hi + hi*lo + lo*hi on the matrix cores (3 MFMAs, fp32 accumulate).  The dropped
+//           lo*lo term and the 16-bit truncation of lo bound the relative error of each product by ~3 * 2^-18
+//           (1.1e-5) -- fp32-class results at 16/3 x the fp32 MFMA rate.
+// Planes are produced by the elementwise kernels that write the activation / gradient anyway
+// (split_planes.hip), so the GEMM loop contains no conversion work.
+//
+// Block: 256 threads = 2 x 2 wave64, tile BM x BN (multiples of 32), K-step 32 (one MFMA k-extent); each wave
+// owns (BM/2) x (BN/2) as TM x TN 16x16 tiles.  LDS rows are 64 B (32 bf16) with an XOR slot swizzle
+// (slot ^ f(row>>2), f = {0,2,3,1}) that makes every 16-lane group of the ds_read_b128 fragment loads hit 16
+// distinct 16-B slots without padding; 2 stages, one barrier per K-step, global loads two K-steps ahead.
+// Output is fp32 (it feeds BatchNorm statistics / elementwise consumers); epilogue as in conv_igemm.hip.
+#include <type_traits>
+
+#include "common.h"
+
+namespace simq {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BKB = 32;            // K-step in elements
+constexpr int ROWB = 64;           // bytes per LDS row (32 bf16)
+
+struct IgemmBfArgs {
+    const uint16_t* x[2];          // activation planes [pixels][Cin] (hi, lo)
+    const uint16_t* w[2];          // weight planes [Cout][R*S*Cin]   (hi, lo)
+    float* y;
+    const float* bias;
+    double* stats;
+    const float* scale;
+    const float* shift;
+    const float* addend;
+    int relu;
+    int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
+    int M, K;
+    int tilesN;
+};
+
+__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // f = {0,2,3,1}
+
+template <int BM, int BN, int NP>
+__global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int PLANE_BYTES = A_BYTES + B_BYTES;
+    constexpr int STAGE_BYTES = NP * PLANE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 16 * BM];
+    int4* rowinfo = reinterpret_cast<int4*>(smem + 2 * STAGE_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_m = blockIdx.x / p.tilesN, tile_n = blockIdx.x % p.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    for (int r = tid; r < BM; r += 256) {
+        int m = m0 + r;
+        int4 ri = make_int4(0, 0, 0, 0);
+        if (m < p.M) {
+            int hw = p.Hout * p.Wout;
+            int b = m / hw, rem = m - b * hw;
+            int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            ri.x = b * p.Hin * p.Win;
+            ri.y = oy * p.stride - p.pad;
+            ri.z = ox * p.stride - p.pad;
+            ri.w = 1;
+        }
+        rowinfo[r] = ri;
+    }
+    __syncthreads();
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BKB;
+    constexpr int A_PASSES = (BM + 63) / 64, B_PASSES = (BN + 63) / 64;   // 4 lanes x 16 B per row, 64 rows per pass
+    uint4 va[2][NP][A_PASSES], vb[2][NP][B_PASSES];
+    const int lrow = tid >> 2, kq = tid & 3;
+    int tap = 0, c0 = 0, ky = 0, kx = 0;    // K order: 32-channel chunk outer, filter tap inner (x lines re-used across taps)
+
+    auto load_tile = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            const int r = lrow + 64 * ps;
+            bool ok = false;
+            size_t off = 0;
+            if (BM % 64 == 0 || r < BM) {
+                int4 ri = rowinfo[r];
+                int iy = ri.y + ky, ix = ri.z + kx;
+                ok = ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                off = (size_t)(ri.x + iy * p.Win + ix) * p.Cin + c0 + kq * 8;
+            }
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                va[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.x[pl] + off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            const int n = lrow + 64 * ps;
+            const bool ok = (BN % 64 == 0 || n < BN);
+            const size_t off = (size_t)(n0 + n) * p.K + (size_t)tap * p.Cin + c0 + kq * 8;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                vb[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.w[pl] + off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
+        char* st = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int r = lrow + 64 * ps;
+                if (BM % 64 == 0 || r < BM)
+                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + r * ROWB + ((kq ^ swz(r)) << 4)) = va[SET][pl][ps];
+            }
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) {
+                const int n = lrow + 64 * ps;
+                if (BN % 64 == 0 || n < BN)
+                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + A_BYTES + n * ROWB + ((kq ^ swz(n)) << 4)) = vb[SET][pl][ps];
+            }
+        }
+    };
+    auto advance = [&]() {
+        ++tap;
+        ++kx;
+        if (kx >= p.S) { kx = 0; ++ky; }
+        if (tap >= p.R * p.S) { tap = 0; kx = 0; ky = 0; c0 += BKB; }
+    };
+
+    // v_mfma_f32_16x16x32_bf16 operands: lane l holds A[i = l & 15][k = 8*(l>>4) .. +7], B[k = 8*(l>>4) .. +7][j = l & 15]
+    const int fi = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* st = smem + buf * STAGE_BYTES;
+        bf16x8 af[NP][TM], bf[NP][TN];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / 2) + i * 16 + fi;
+                af[pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + r * ROWB + ((fq ^ swz(r)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fi;
+                bf[pl][j] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + A_BYTES + r * ROWB + ((fq ^ swz(r)) << 4));
+            }
+        }
+        if constexpr (NP == 2) {   // small cross terms first, then the leading term
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    load_tile(S0{});
+    store_tile(S0{}, 0);
+    if (nk > 1) { advance(); load_tile(S1{}); }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        if (kt + 2 < nk) { advance(); load_tile(S0{}); }
+        compute(0);
+        store_tile(S1{}, 1);
+        __syncthreads();
+        if (kt + 3 < nk) { advance(); load_tile(S1{}); }
+        compute(1);
+        if (kt + 2 < nk) store_tile(S0{}, 0);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+    __syncthreads();
+
+    // ---- epilogue (C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg) ----
+    float ssum[TN], ssq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fi;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.scale ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * fq + r;
+                if (m < p.M) {
+                    float v = acc[i][j][r] + bias;
+                    ssum[j] += v;
+                    ssq[j] += v * v;
+                    v = v * sc + sh;
+                    const size_t o = (size_t)m * p.Cout + n;
+                    if (p.addend) v += p.addend[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[o] = v;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        double* red = reinterpret_cast<double*>(smem);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = ssum[j], q = ssq[j];
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (fq == 0) {
+                int c = wn * (BN / 2) + j * 16 + fi;
+                red[(wm * BN + c) * 2 + 0] = (double)s;
+                red[(wm * BN + c) * 2 + 1] = (double)q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            double s = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+            double q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            unsafeAtomicAdd(p.stats + n0 + tid, s);
+            unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, q);
+        }
+    }
+}
+
+template <int BM, int BN, int NP>
+int run(const IgemmBfArgs& a, hipStream_t stream) {
+    IgemmBfArgs p = a;
+    p.tilesN = p.Cout / BN;
+    int tilesM = (p.M + BM - 1) / BM;
+    prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
+                      4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
+                      stream);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NP>), dim3((unsigned)(tilesM * p.tilesN)), dim3(256), 0, stream, p);
+    prof_launch_end(stream);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+struct TileCfg { int bm, bn; float eff; };
+constexpr TileCfg kMenu[] = {
+    {128, 128, 1.00f}, {96, 128, 0.97f}, {64, 128, 0.92f}, {128, 64, 0.92f}, {96, 64, 0.88f}, {64, 64, 0.82f},
+    {128, 32, 0.75f},  {96, 32, 0.72f},  {64, 32, 0.65f},  {32, 64, 0.65f},  {32, 32, 0.50f},
+};
+
+template <int NP>
+int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, NP>(a, stream)
+    SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
+    SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
+#undef SIMQ_TILE
+    set_error("conv_igemm_bf16: no kernel for tile %dx%d", bm, bn);
+    return -1;
+}
+
+}  // namespace
+
+int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,
+                           const ConvEpilogue& e, hipStream_t stream) {
+    IgemmBfArgs a;
+    a.x[0] = x[0]; a.x[1] = nplanes == 2 ? x[1] : x[0];
+    a.w[0] = w[0]; a.w[1] = nplanes == 2 ? w[1] : w[0];
+    a.y = y;
+    a.bias = e.bias; a.stats = e.stats; a.scale = e.scale; a.shift = e.shift; a.addend = e.addend; a.relu = e.relu;
+    a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
+    a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
+    a.M = g.M(); a.K = g.K(); a.tilesN = 0;
+    SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
+    SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_igemm_bf16: nplanes must be 1 or 2");
+    SIMQ_REQUIRE(g.Cout % 32 == 0 && g.Cin % BKB == 0, "conv_igemm_bf16: Cin=%d Cout=%d must be multiples of 32", g.Cin, g.Cout);
+    int bm = 0, bn = 0;
+    int fbm = 0, fbn = 0;
+    if (tune_forced_tile(&fbm, &fbn) && g.Cout % fbn == 0) { bm = fbm; bn = fbn; }
+    else {
+        double best = 1e300;
+        for (const TileCfg& t : kMenu) {
+            if (g.Cout % t.bn != 0) continue;
+            const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (g.Cout / t.bn);
+            const long rounds = (blocks + 255) / 256;
+            double cost = (double)rounds * t.bm * t.bn / t.eff;
+            if (rounds == 1) cost *= 1.25;
+            if (cost < best) { best = cost; bm = t.bm; bn = t.bn; }
+        }
+    }
+    return nplanes == 2 ? dispatch<2>(bm, bn, a, stream) : dispatch<1>(bm, bn, a, stream);
+}
+
+}  // namespace simq

@@ -53,6 +53,19 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 s, float4 t) {
     return make_float4(fmaf(a.x, s.x, t.x), fmaf(a.y, s.y, t.y), fmaf(a.z, s.z, t.z), fmaf(a.w, s.w, t.w));
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// optional bf16 plane outputs (hi = bf16(v), lo = bf16(v - hi)) for the matrix-core convolution paths
+__device__ __forceinline__ uint16_t to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ void st_planes(const Planes& pl, size_t i4, float4 v) {
+    if (!pl.hi) return;
+    ushort4 h = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+    *reinterpret_cast<ushort4*>(pl.hi + i4 * 4) = h;
+    if (pl.lo) {
+        ushort4 l = make_ushort4(to_bf16(v.x - from_bf16(h.x)), to_bf16(v.y - from_bf16(h.y)),
+                                 to_bf16(v.z - from_bf16(h.z)), to_bf16(v.w - from_bf16(h.w)));
+        *reinterpret_cast<ushort4*>(pl.lo + i4 * 4) = l;
+    }
+}
 __device__ __forceinline__ float4 relu4(float4 a) {
     return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
 }
@@ -61,7 +74,7 @@ __device__ __forceinline__ float4 relu4(float4 a) {
 __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ res,
                                 const float* __restrict__ rscale, const float* __restrict__ rshift, int relu,
-                                float* __restrict__ out, size_t total4, int C4) {
+                                float* __restrict__ out, Planes pl, size_t total4, int C4) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         int c = (int)(i % C4) * 4;
         float4 v = fma4(ld4(y + i * 4), ld4(scale + c), ld4(shift + c));
@@ -72,13 +85,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
         }
         if (relu) v = relu4(v);
         st4(out + i * 4, v);
+        st_planes(pl, i, v);
     }
 }
 
 // stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
 __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ pooled,
-                                     uint8_t* __restrict__ idx, int B, int H, int W, int C4) {
+                                     uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -107,6 +121,7 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* _
             }
         }
         st4(pooled + i * 4, best);
+        st_planes(pl, i, best);
         *reinterpret_cast<uchar4*>(idx + i * 4) = bi;
     }
 }
@@ -202,7 +217,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
-                                    float* __restrict__ dz_out, float* dgamma, float* dbeta, size_t rows, int C4) {
+                                    float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -230,6 +245,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
         o.z = ga.z * is.z * (dz.z - db[2] * inv_rows - (yv.z - mu.z) * is.z * dg[2] * inv_rows);
         o.w = ga.w * is.w * (dz.w - db[3] * inv_rows - (yv.w - mu.w) * is.w * dg[3] * inv_rows);
         st4(dy + i * 4, o);
+        st_planes(pl, i, o);
     }
 }
 
@@ -251,7 +267,7 @@ __device__ __forceinline__ Lerp lerp_coord(int o, int in_size, float scale) {
     return r;
 }
 
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, Planes pl, int B, int H, int W,
                                       int C4) {
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
@@ -272,6 +288,7 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
         o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
         o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
         st4(out + i * 4, o);
+        st_planes(pl, i, o);
     }
 }
 
@@ -357,21 +374,21 @@ int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const 
 }
 
 int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rscale,
-                    const float* rshift, int relu, float* out, int64_t rows, int C, hipStream_t stream) {
+                    const float* rshift, int relu, float* out, int64_t rows, int C, hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, scale, shift, res, rscale,
-                       rshift, relu, out, total4, C / 4);
+                       rshift, relu, out, pl, total4, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, int B,
-                         int H, int W, int C, hipStream_t stream) {
+                         int H, int W, int C, hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "stem_pool: bad shape");
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, scale, shift, pooled, idx,
-                       B, H, W, C / 4);
+                       pl, B, H, W, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -404,10 +421,10 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
-                        int64_t rows, int C, hipStream_t stream) {
+                        int64_t rows, int C, hipStream_t stream, Planes pl) {
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, y, mean, invstd,
-                       gamma, red, dy, dz_out, dgamma, dbeta, (size_t)rows, C / 4);
+                       gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -427,10 +444,10 @@ int launch_colsum_finish(const double* red, float* out, int C, hipStream_t strea
     return 0;
 }
 
-int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream) {
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
     size_t total = (size_t)B * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out, B, H, W, C / 4);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out, pl, B, H, W, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -31,6 +31,7 @@ struct ConvL {
     std::string name;
     int64_t w_off = -1, b_off = -1;   // into the flat parameter buffer
     int64_t wt_off = -1;              // into the transposed-weight scratch (dgrad), -1: no dgrad
+    int64_t wp_off = -1;              // into the bf16 weight-plane scratch (matrix-core precisions), -1: stays fp32
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int64_t wcount() const { return (int64_t)cout * k * k * cin; }
 };
@@ -59,12 +60,14 @@ using namespace simq;
 
 struct simq_plan {
     int cin, cout;
+    int precision = SIMQ_PREC_FP32;   // arithmetic of the 3x3 / 1x1 convolutions (stem and conv3 are always fp32)
+    int np() const { return precision == SIMQ_PREC_BF16X3 ? 2 : 1; }
     ConvL stem, h1, h2, h3;
     BnL stem_bn, hb1, hb2;
     BlockL blocks[8];
     std::vector<TensorInfo> tensors;
     std::vector<BnL*> bns;
-    int64_t nparams = 0, nbnbuf = 0, wt_total = 0, aux_total = 0, red_total = 0;
+    int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0;
 };
 
 namespace {
@@ -81,7 +84,7 @@ struct Builder {
             p->tensors.push_back({name + ".bias", c.b_off, {cout, 1, 1, 1}, SIMQ_KIND_CONV_B});
             p->nparams += cout;
         }
-        if (dgrad) { c.wt_off = p->wt_total; p->wt_total += c.wcount(); }
+        if (dgrad) { c.wt_off = p->wt_total; p->wt_total += c.wcount(); c.wp_off = p->wp_total; p->wp_total += c.wcount(); }
     }
     void bn(BnL& b, const std::string& name, int C) {
         b.name = name; b.C = C;
@@ -99,10 +102,12 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // Workspace layout for a given batch (byte offsets, 256-B aligned).
 struct Layout {
     int64_t x, y0, pooled, idx;
-    struct Blk { int64_t y1, a1, y2, yd, out; } blk[8];
+    struct Blk { int64_t y1, a1, y2, yd, out, p_a1, p_out; } blk[8];
     int64_t yh1, ah1, up1, yh2, ah2, up2;
     int64_t aux, red, wt, colsum;
     int64_t S[4];
+    // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
+    int64_t p_pooled, p_up1, DP[2], wpl, wtpl;
     int64_t total;
 };
 
@@ -131,9 +136,30 @@ Layout make_layout(const simq_plan* p, int B) {
     L.colsum = take(512 * sizeof(double));
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
     for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
+    L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = L.wpl = L.wtpl = -1;
+    for (int i = 0; i < 8; ++i) L.blk[i].p_a1 = L.blk[i].p_out = -1;
+    if (p->precision != SIMQ_PREC_FP32) {
+        const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
+        L.p_pooled = take((int64_t)B * 576 * 64 * h);
+        for (int i = 0; i < 8; ++i) {
+            const int64_t n = (int64_t)B * 576 * p->blocks[i].planes * h;
+            L.blk[i].p_a1 = take(n);
+            L.blk[i].p_out = take(n);
+        }
+        L.p_up1 = take((int64_t)B * 2304 * 128 * h);
+        L.DP[0] = take((int64_t)B * 294912 * h);
+        L.DP[1] = take((int64_t)B * 294912 * h);
+        L.wpl = take(p->wp_total * h);
+        L.wtpl = take(p->wp_total * h);
+    }
     L.total = off;
     return L;
 }
+
+struct Act {          // a tensor some convolution reads: fp32 view + (matrix-core precisions) its bf16 planes
+    float* f = nullptr;
+    Planes pl;
+};
 
 struct Ctx {
     const simq_plan* p;
@@ -147,6 +173,22 @@ struct Ctx {
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
     float* aux(const BnL& b, int which) const { return f(L.aux) + b.aux_off + (int64_t)which * b.C; }   // 0 scale 1 shift 2 mean 3 invstd
     double* red(const BnL& b) const { return reinterpret_cast<double*>(ws + L.red) + b.red_off; }
+    bool mc() const { return p->precision != SIMQ_PREC_FP32; }      // matrix-core bf16 / split-bf16 convolutions
+    Planes planes(int64_t off, int64_t elems) const {
+        Planes pl;
+        if (mc() && off >= 0) {
+            pl.hi = reinterpret_cast<uint16_t*>(ws + off);
+            pl.lo = p->np() == 2 ? pl.hi + elems : nullptr;
+        }
+        return pl;
+    }
+    Act act(int64_t off, int64_t poff, int64_t elems) const { Act a; a.f = f(off); a.pl = planes(poff, elems); return a; }
+    // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
+    void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
+        uint16_t* base = reinterpret_cast<uint16_t*>(ws + (transposed ? L.wtpl : L.wpl));
+        out[0] = base + cv.wp_off;
+        out[1] = p->np() == 2 ? base + p->wp_total + cv.wp_off : out[0];
+    }
 };
 
 ConvGeom geom(const ConvL& c, int B, int hin) {
@@ -156,14 +198,25 @@ ConvGeom geom(const ConvL& c, int B, int hin) {
     return g;
 }
 
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e) {
+    if (c.mc() && cv.wp_off >= 0) {
+        const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
+        const uint16_t* wsp[2];
+        c.wplanes(cv, false, wsp);
+        return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
+    }
+    return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream);
+}
+
 // conv (+bias) with train-mode statistics or plain; then BN finalize for the mode
-int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const float* x, float* y, int hin) {
+int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x, float* y, int hin) {
     ConvGeom g = geom(cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
-    int rc = launch_conv_igemm(x, c.params + cv.w_off, y, g, e, c.stream);
-    if (rc) return rc;
+    RC(conv_fwd(c, cv, x, y, g, e));
     if (mode != SIMQ_MODE_EVAL)
         return launch_bn_finalize_train(c.red(bn), bn.C, (int64_t)g.M(), c.params + bn.g_off, c.params + bn.b_off,
                                         c.bnbuf + bn.buf_off, c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1),
@@ -172,7 +225,15 @@ int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const float*
                                    c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1), c.stream);
 }
 
-#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+template <typename F>
+int for_each_mc_conv(const simq_plan* p, F fn) {
+    for (int i = 0; i < 8; ++i) {
+        RC(fn(p->blocks[i].c1)); RC(fn(p->blocks[i].c2));
+        if (p->blocks[i].has_ds) RC(fn(p->blocks[i].ds));
+    }
+    RC(fn(p->h1)); RC(fn(p->h2));
+    return 0;
+}
 
 int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const simq_plan* p = c.p;
@@ -181,57 +242,84 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
     if (mode != SIMQ_MODE_EVAL)
         SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
-    // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97)
-    RC(conv_bn(c, p->stem, p->stem_bn, mode, c.f(L.x), c.f(L.y0), 96));
-    RC(launch_stem_pool_fwd(c.f(L.y0), c.aux(p->stem_bn, 0), c.aux(p->stem_bn, 1), c.f(L.pooled),
-                            reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream));
-    const float* cur = c.f(L.pooled);
+    if (c.mc()) {   // bf16 planes of the (fp32 master) weights, plain and flipped/transposed, once per call
+        uint16_t* wb = reinterpret_cast<uint16_t*>(c.ws + L.wpl);
+        uint16_t* wtb = reinterpret_cast<uint16_t*>(c.ws + L.wtpl);
+        const bool two = p->np() == 2;
+        RC(for_each_mc_conv(p, [&](const ConvL& cv) {
+            return launch_weight_planes(c.params + cv.w_off, wb + cv.wp_off, two ? wb + p->wp_total + cv.wp_off : nullptr,
+                                        mode == SIMQ_MODE_TRAIN ? wtb + cv.wp_off : nullptr,
+                                        (mode == SIMQ_MODE_TRAIN && two) ? wtb + p->wp_total + cv.wp_off : nullptr, cv.cout,
+                                        cv.k * cv.k, cv.cin, c.stream);
+        }));
+    }
     const int64_t rows = (int64_t)B * 576;
+    // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97); always the fp32 kernel (Cin is 3..10)
+    Act x0; x0.f = c.f(L.x);
+    RC(conv_bn(c, p->stem, p->stem_bn, mode, x0, c.f(L.y0), 96));
+    Act cur = c.act(L.pooled, L.p_pooled, rows * 64);
+    RC(launch_stem_pool_fwd(c.f(L.y0), c.aux(p->stem_bn, 0), c.aux(p->stem_bn, 1), cur.f,
+                            reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl));
     for (int i = 0; i < 8; ++i) {   // BasicBlock.forward, resnet.py:31-47
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
+        const int64_t n = rows * b.planes;
+        Act a1 = c.act(o.a1, o.p_a1, n), out = c.act(o.out, o.p_out, n);
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
-        RC(launch_bn_apply(c.f(o.y1), c.aux(b.b1, 0), c.aux(b.b1, 1), nullptr, nullptr, nullptr, 1, c.f(o.a1), rows, b.planes, c.stream));
-        RC(conv_bn(c, b.c2, b.b2, mode, c.f(o.a1), c.f(o.y2), 24));
+        RC(launch_bn_apply(c.f(o.y1), c.aux(b.b1, 0), c.aux(b.b1, 1), nullptr, nullptr, nullptr, 1, a1.f, rows, b.planes, c.stream, a1.pl));
+        RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
         if (b.has_ds) {
             RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
             RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), c.f(o.yd), c.aux(b.bds, 0), c.aux(b.bds, 1), 1,
-                               c.f(o.out), rows, b.planes, c.stream));
+                               out.f, rows, b.planes, c.stream, out.pl));
         } else {
-            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), cur, nullptr, nullptr, 1, c.f(o.out), rows, b.planes, c.stream));
+            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), cur.f, nullptr, nullptr, 1, out.f, rows, b.planes, c.stream, out.pl));
         }
-        cur = c.f(o.out);
+        cur = out;
     }
     // head, networks.py:18-26
     RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
     RC(launch_bn_apply(c.f(L.yh1), c.aux(p->hb1, 0), c.aux(p->hb1, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
-    RC(launch_upsample2x_fwd(c.f(L.ah1), c.f(L.up1), B, 24, 24, 128, c.stream));
-    RC(conv_bn(c, p->h2, p->hb2, mode, c.f(L.up1), c.f(L.yh2), 48));
+    Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
+    RC(launch_upsample2x_fwd(c.f(L.ah1), up1.f, B, 24, 24, 128, c.stream, up1.pl));
+    RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
     RC(launch_bn_apply(c.f(L.yh2), c.aux(p->hb2, 0), c.aux(p->hb2, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
     RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
     RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
     return 0;
 }
 
-// BatchNorm backward (train mode) fused with the ReLU mask of the activation that followed it.
-int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, float* dy, float* dz_out, int64_t rows) {
+// BatchNorm backward (train mode) fused with the ReLU mask of the activation that followed it; dy also as planes.
+int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows) {
     RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
-    return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy, dz_out,
-                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream);
+    return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.f, dz_out,
+                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl);
 }
 
-int conv_wgrad(const Ctx& c, const ConvL& cv, const float* x, const float* dy, int hin) {
-    return launch_conv_wgrad(x, dy, c.grads + cv.w_off, geom(cv, c.B, hin), c.stream);
+int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
+    ConvGeom g = geom(cv, c.B, hin);
+    if (c.mc() && cv.wp_off >= 0) {
+        const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
+        const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
+        return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
+    }
+    return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
 }
 
 // dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
-int conv_dgrad(const Ctx& c, const ConvL& cv, const float* dy, float* dx, const float* addend, int hin) {
+int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const float* addend, int hin) {
     ConvGeom g;
     g.B = c.B; g.Hin = hin; g.Win = hin; g.Cin = cv.cout; g.Cout = cv.cin; g.Hout = hin; g.Wout = hin;
     g.R = cv.k; g.S = cv.k; g.stride = 1; g.pad = cv.k - 1 - cv.pad;
     ConvEpilogue e;
     e.addend = addend;
-    return launch_conv_igemm(dy, c.f(c.L.wt) + cv.wt_off, dx, g, e, c.stream);
+    if (c.mc() && cv.wp_off >= 0) {
+        const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
+        const uint16_t* wsp[2];
+        c.wplanes(cv, true, wsp);
+        return launch_conv_igemm_bf16(ds, wsp, c.p->np(), dx, g, e, c.stream);
+    }
+    return launch_conv_igemm(dy.f, c.f(c.L.wt) + cv.wt_off, dx, g, e, c.stream);
 }
 
 int backward_impl(const Ctx& c, const float* d_dq) {
@@ -240,43 +328,44 @@ int backward_impl(const Ctx& c, const float* d_dq) {
     const int B = c.B;
     SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
     SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
-    // flipped / transposed weights for every convolution that needs a data gradient
-    auto wt = [&](const ConvL& cv) {
-        return launch_weight_transpose(c.params + cv.w_off, c.f(L.wt) + cv.wt_off, cv.cout, cv.k * cv.k, cv.cin, c.stream);
-    };
-    for (int i = 0; i < 8; ++i) {
-        RC(wt(p->blocks[i].c1)); RC(wt(p->blocks[i].c2));
-        if (p->blocks[i].has_ds) RC(wt(p->blocks[i].ds));
-    }
-    RC(wt(p->h1)); RC(wt(p->h2));
+    if (!c.mc()) {   // fp32: flipped / transposed weights for every convolution that needs a data gradient
+        RC(for_each_mc_conv(p, [&](const ConvL& cv) {
+            return launch_weight_transpose(c.params + cv.w_off, c.f(L.wt) + cv.wt_off, cv.cout, cv.k * cv.k, cv.cin, c.stream);
+        }));
+    }   // (matrix-core precisions: the planes written by the TRAIN forward of this workspace are still valid)
     float* S[4] = {c.f(L.S[0]), c.f(L.S[1]), c.f(L.S[2]), c.f(L.S[3])};
+    const int64_t smax = (int64_t)B * 294912;
+    auto dyact = [&](float* buf, int which) { Act a; a.f = buf; a.pl = c.planes(L.DP[which], smax); return a; };
     double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
+    const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
     RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
     RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
-    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), S[0], nullptr, (int64_t)B * 2304));
+    Act dyh = dyact(S[0], 0);
+    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dyh, nullptr, (int64_t)B * 2304));
     RC(launch_colsum(S[0], cs, c.grads + p->h2.b_off, (int64_t)B * 2304, 32, c.stream));
-    RC(conv_wgrad(c, p->h2, c.f(L.up1), S[0], 48));
-    RC(conv_dgrad(c, p->h2, S[0], S[1], nullptr, 48));
+    RC(conv_wgrad(c, p->h2, c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128), dyh, 48));
+    RC(conv_dgrad(c, p->h2, dyh, S[1], nullptr, 48));
     RC(launch_upsample2x_bwd(S[1], S[2], B, 24, 24, 128, c.stream));
-    const int64_t rows = (int64_t)B * 576;
-    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), S[0], nullptr, rows));
+    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
-    RC(conv_wgrad(c, p->h1, c.f(L.blk[7].out), S[0], 24));
-    RC(conv_dgrad(c, p->h1, S[0], S[1], nullptr, 24));
-    int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
+    RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
+    RC(conv_dgrad(c, p->h1, dyh, S[1], nullptr, 24));
+    const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
     for (int i = 7; i >= 0; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
-        const float* xin = i == 0 ? c.f(L.pooled) : c.f(L.blk[i - 1].out);
+        const Act xin = i == 0 ? c.act(L.pooled, L.p_pooled, rows * 64)
+                               : c.act(L.blk[i - 1].out, L.blk[i - 1].p_out, rows * p->blocks[i - 1].planes);
+        const Act a1 = c.act(o.a1, o.p_a1, rows * b.planes);
         float* G = S[gi];
-        float* T0 = S[(gi + 1) & 3];
-        float* T1 = S[(gi + 2) & 3];
+        Act T0 = dyact(S[(gi + 1) & 3], 0);
+        Act T1 = dyact(S[(gi + 2) & 3], 1);
         float* T2 = S[(gi + 3) & 3];
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
-        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1, rows));
+        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows));
         if (b.has_ds) RC(bn_bwd(c, b.bds, G, c.f(o.out), c.f(o.yd), T1, nullptr, rows));
-        RC(conv_wgrad(c, b.c2, c.f(o.a1), T0, 24));
+        RC(conv_wgrad(c, b.c2, a1, T0, 24));
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24));
         RC(bn_bwd(c, b.b1, T2, c.f(o.a1), c.f(o.y1), T0, nullptr, rows));
         RC(conv_wgrad(c, b.c1, xin, T0, 24));
@@ -285,17 +374,18 @@ int backward_impl(const Ctx& c, const float* d_dq) {
             RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24));
             RC(conv_dgrad(c, b.c1, T0, G, G, 24));
         } else {
-            RC(conv_dgrad(c, b.c1, T0, G, T1, 24));
+            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24));
         }
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
-    // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient ----
+    // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient; fp32 kernels ----
     float* G = S[gi];
     float* T0 = S[(gi + 1) & 3];
-    float* T1 = S[(gi + 2) & 3];
+    Act T1; T1.f = S[(gi + 2) & 3];
+    Act x0; x0.f = c.f(L.x);
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream));
     RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304));
-    RC(conv_wgrad(c, p->stem, c.f(L.x), T1, 96));
+    RC(conv_wgrad(c, p->stem, x0, T1, 96));
     return 0;
 }
 
@@ -313,12 +403,13 @@ extern "C" {
 int simq_version(void) { return SIMQ_VERSION; }
 const char* simq_last_error(void) { return simq::g_error; }
 
-int simq_plan_create(int cin, int cout, simq_plan** out) {
+int simq_plan_create_ex(int cin, int cout, int precision, simq_plan** out) {
     SIMQ_REQUIRE(out != nullptr, "plan_create: out is NULL");
     SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
     SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);
+    SIMQ_REQUIRE(precision >= SIMQ_PREC_FP32 && precision <= SIMQ_PREC_BF16, "plan_create: bad precision %d", precision);
     simq_plan* p = new simq_plan();
-    p->cin = cin; p->cout = cout;
+    p->cin = cin; p->cout = cout; p->precision = precision;
     Builder bd{p};
     bd.conv(p->stem, "resnet18.conv1", cin, 64, 7, 2, 3, false, false);
     bd.bn(p->stem_bn, "resnet18.bn1", 64);
@@ -358,7 +449,11 @@ int simq_plan_create(int cin, int cout, simq_plan** out) {
     return 0;
 }
 
+int simq_plan_create(int cin, int cout, simq_plan** out) { return simq_plan_create_ex(cin, cout, SIMQ_PREC_FP32, out); }
+
 void simq_plan_destroy(simq_plan* plan) { delete plan; }
+
+int simq_plan_precision(const simq_plan* plan) { return plan ? plan->precision : -1; }
 
 int64_t simq_param_count(const simq_plan* plan) { return plan ? plan->nparams : -1; }
 int simq_param_num_tensors(const simq_plan* plan) { return plan ? (int)plan->tensors.size() : -1; }
@@ -388,6 +483,30 @@ int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_ca
 int64_t simq_workspace_bytes(const simq_plan* plan, int batch) {
     if (!plan || batch < 1) return -1;
     return make_layout(plan, batch).total;
+}
+
+int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels) {
+    SIMQ_REQUIRE(plan && name && batch >= 1, "workspace_tensor: bad argument");
+    const Layout L = make_layout(plan, batch);
+    const std::string n(name);
+    int64_t off = -1, cnt = 0;
+    int ch = 0;
+    if (n == "stem.conv") { off = L.y0; ch = 64; cnt = (int64_t)batch * 2304 * 64; }
+    else if (n == "stem.pool") { off = L.pooled; ch = 64; cnt = (int64_t)batch * 576 * 64; }
+    else if (n == "head.a1") { off = L.ah1; ch = 128; cnt = (int64_t)batch * 576 * 128; }
+    else if (n == "head.a2") { off = L.ah2; ch = 32; cnt = (int64_t)batch * 2304 * 32; }
+    else {
+        int li = 0, bi = 0;
+        if (sscanf(name, "layer%d.%d", &li, &bi) == 2 && li >= 1 && li <= 4 && bi >= 0 && bi <= 1) {
+            const int i = (li - 1) * 2 + bi;
+            off = L.blk[i].out; ch = plan->blocks[i].planes; cnt = (int64_t)batch * 576 * ch;
+        }
+    }
+    SIMQ_REQUIRE(off >= 0, "workspace_tensor: unknown tensor '%s'", name);
+    if (byte_offset) *byte_offset = off;
+    if (elems) *elems = cnt;
+    if (channels) *channels = ch;
+    return 0;
 }
 
 int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, float* d_bnbuf, const float* d_x,
@@ -477,6 +596,40 @@ int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw, int batc
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
     return launch_conv_wgrad(d_x, d_dy, d_dw, g, st);
+}
+
+int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
+                         int cin, int cout, int r, int s, int stride, int pad, int nplanes, void* d_scratch, double* d_stats,
+                         void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    const int64_t nx = (int64_t)batch * hin * win * cin, nw = (int64_t)cout * r * s * cin;
+    uint16_t* base = static_cast<uint16_t*>(d_scratch);   // [x_hi | x_lo | w_hi | w_lo]
+    uint16_t* xp[2] = {base, base + nx};
+    uint16_t* wp[2] = {base + 2 * nx, base + 2 * nx + nw};
+    RC(launch_split_planes(d_x, xp[0], nplanes == 2 ? xp[1] : nullptr, nx, st));
+    RC(launch_split_planes(d_w, wp[0], nplanes == 2 ? wp[1] : nullptr, nw, st));
+    ConvEpilogue e;
+    e.bias = d_bias; e.stats = d_stats;
+    return launch_conv_igemm_bf16(xp, wp, nplanes, d_y, g, e, st);
+}
+
+int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
+                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    const int64_t nx = (int64_t)batch * hin * win * cin, ny = (int64_t)batch * g.Hout * g.Wout * cout;
+    uint16_t* base = static_cast<uint16_t*>(d_scratch);   // [x_hi | x_lo | dy_hi | dy_lo]
+    uint16_t* xp[2] = {base, base + nx};
+    uint16_t* yp[2] = {base + 2 * nx, base + 2 * nx + ny};
+    RC(launch_split_planes(d_x, xp[0], nplanes == 2 ? xp[1] : nullptr, nx, st));
+    RC(launch_split_planes(d_dy, yp[0], nplanes == 2 ? yp[1] : nullptr, ny, st));
+    SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
+    return launch_conv_wgrad_bf16(xp, yp, nplanes, d_dw, g, st);
 }
 
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream) {

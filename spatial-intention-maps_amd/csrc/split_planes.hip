@@ -1,0 +1,75 @@
+// bf16 plane producers for the matrix-core convolution paths (conv_igemm_bf16.hip / conv_wgrad_bf16.hip).
+//   hi = bf16(v) (round-to-nearest-even), lo = bf16(v - float(hi))   -> v ~= hi + lo to ~2^-17 relative.
+// Standalone splitters (weights once per optimiser step; generic tensors in the unit tests); the activation /
+// gradient planes of the network are written by the fused elementwise kernels (elementwise.hip) instead.
+#include "common.h"
+
+namespace simq {
+
+namespace {
+
+__device__ __forceinline__ uint16_t to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+__global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        ushort4 h = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+        *reinterpret_cast<ushort4*>(hi + i * 4) = h;
+        if (lo) {
+            ushort4 l = make_ushort4(to_bf16(v.x - from_bf16(h.x)), to_bf16(v.y - from_bf16(h.y)),
+                                     to_bf16(v.z - from_bf16(h.z)), to_bf16(v.w - from_bf16(h.w)));
+            *reinterpret_cast<ushort4*>(lo + i * 4) = l;
+        }
+    }
+}
+
+// weights: planes of w (OHWI) and of the flipped/transposed copy wt[ci][taps-1-t][co] used by dgrad
+__global__ void weight_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ w_hi, uint16_t* __restrict__ w_lo,
+                                     uint16_t* __restrict__ wt_hi, uint16_t* __restrict__ wt_lo, int cout, int taps, int cin) {
+    size_t total = (size_t)cout * taps * cin;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the transposed layout (co fastest) so that its writes coalesce; the OHWI planes are written from
+        // the same thread at the source index (strided, but this kernel moves 45 MB once per step)
+        int co = (int)(i % cout);
+        size_t r = i / cout;
+        int tf = (int)(r % taps);
+        int ci = (int)(r / taps);
+        size_t src = ((size_t)co * taps + (taps - 1 - tf)) * cin + ci;
+        float v = w[src];
+        uint16_t h = to_bf16(v);
+        uint16_t l = to_bf16(v - from_bf16(h));
+        w_hi[src] = h;
+        if (w_lo) w_lo[src] = l;
+        if (wt_hi) {
+            wt_hi[i] = h;
+            if (wt_lo) wt_lo[i] = l;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_split_planes(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t stream) {
+    SIMQ_REQUIRE(n % 4 == 0, "split_planes: n must be a multiple of 4");
+    size_t n4 = (size_t)n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, hi, lo, n4);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_weight_planes(const float* w, uint16_t* w_hi, uint16_t* w_lo, uint16_t* wt_hi, uint16_t* wt_lo, int cout, int taps,
+                         int cin, hipStream_t stream) {
+    size_t total = (size_t)cout * taps * cin;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, w_hi, w_lo, wt_hi, wt_lo, cout,
+                       taps, cin);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace simq

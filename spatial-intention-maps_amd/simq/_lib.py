@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libsimq.so')
 
 MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD = 0, 1, 2
 KIND_CONV_W, KIND_CONV_B, KIND_BN_W, KIND_BN_B = 0, 1, 2, 3
+PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16': 2}
 
 
 class SimqError(RuntimeError):
@@ -33,6 +34,8 @@ _SIGS = {
     'simq_version': (c_int, []),
     'simq_last_error': (c_char_p, []),
     'simq_plan_create': (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    'simq_plan_create_ex': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    'simq_plan_precision': (c_int, [c_void_p]),
     'simq_plan_destroy': (None, [c_void_p]),
     'simq_param_count': (c_int64, [c_void_p]),
     'simq_param_num_tensors': (c_int, [c_void_p]),
@@ -41,6 +44,7 @@ _SIGS = {
     'simq_bn_num_layers': (c_int, [c_void_p]),
     'simq_bn_layer_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int)]),
     'simq_workspace_bytes': (c_int64, [c_void_p, c_int]),
+    'simq_workspace_tensor': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     'simq_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -56,6 +60,8 @@ _SIGS = {
     'simq_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     'simq_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'simq_conv2d_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_wgrad_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p]),
     'simq_upsample2x_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_profile_start': (c_int, []),
@@ -106,10 +112,13 @@ lib = Lib()
 class Plan:
     """Owns a simq_plan* and exposes its buffer layout."""
 
-    def __init__(self, num_input_channels, num_output_channels):
+    def __init__(self, num_input_channels, num_output_channels, precision='fp32'):
         self.cin, self.cout = int(num_input_channels), int(num_output_channels)
+        if precision not in PRECISIONS:
+            raise SimqError('unknown precision %r (choose from %s)' % (precision, sorted(PRECISIONS)))
+        self.precision = precision
         h = c_void_p()
-        check(_c.simq_plan_create(self.cin, self.cout, ctypes.byref(h)), 'simq_plan_create')
+        check(_c.simq_plan_create_ex(self.cin, self.cout, PRECISIONS[precision], ctypes.byref(h)), 'simq_plan_create_ex')
         self.handle = h
         self.param_count = _c.simq_param_count(h)
         self.bnbuf_count = _c.simq_bnbuf_count(h)

@@ -48,7 +48,7 @@ class _FCNFunction(torch.autograd.Function):
 
 
 class FCN(torch.nn.Module):
-    def __init__(self, num_input_channels=3, num_output_channels=1, device=None, dataparallel_keys=True):
+    def __init__(self, num_input_channels=3, num_output_channels=1, device=None, dataparallel_keys=True, precision='fp32'):
         super().__init__()
         if device is None:
             device = torch.device('cuda')
@@ -57,7 +57,8 @@ class FCN(torch.nn.Module):
             raise SimqError('simq.FCN needs a GPU device (got %s); there is no CPU path' % device)
         self.num_input_channels, self.num_output_channels = int(num_input_channels), int(num_output_channels)
         self.key_prefix = arch.PREFIX if dataparallel_keys else ''
-        self.plan = Plan(num_input_channels, num_output_channels)
+        self.precision = precision   # 'fp32' (exact fp32 MFMA) | 'bf16x3' (split-bf16, fp32-class) | 'bf16'
+        self.plan = Plan(num_input_channels, num_output_channels, precision)
         P = self.plan.param_count
         self.flat_params = torch.zeros(P, dtype=torch.float32, device=self.device_)
         self.flat_grads = torch.zeros(P, dtype=torch.float32, device=self.device_)
@@ -262,3 +263,13 @@ class FCN(torch.nn.Module):
         idx = torch.empty(1, dtype=torch.int64, device=self.device_)
         lib.call('simq_q_argmax', ptr(q), 1, q.numel(), ptr(idx), None, stream_ptr(self.device_))
         return int(idx.item())
+
+    def saved_activation(self, name, batch, slot='tmp'):
+        """NHWC view [B,H,W,C] of an activation the last forward left in its workspace
+        ('stem.pool', 'layer<1-4>.<0-1>', 'head.a1', 'head.a2') -- parity bisecting aid."""
+        import ctypes
+        off, n, ch = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        lib.call('simq_workspace_tensor', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch))
+        ws = self._ws[slot]
+        hw = int(round((n.value // (batch * ch.value)) ** 0.5))
+        return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(batch, hw, hw, ch.value)

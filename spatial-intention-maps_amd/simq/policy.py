@@ -44,7 +44,8 @@ class DQNPolicy:
         for robot_type in self.robot_group_types:
             num_output_channels = arch.get_num_output_channels(robot_type)
             policy_nets.append(FCN(num_input_channels=self.cfg.num_input_channels,
-                                   num_output_channels=num_output_channels, device=self.device))
+                                   num_output_channels=num_output_channels, device=self.device,
+                                   precision=getattr(self.cfg, 'simq_precision', 'fp32')))
         return policy_nets
 
     build_network = build_policy_nets      # BASELINE.json's name for the same call

@@ -242,3 +242,46 @@ def test_error_reporting(L):
     assert rc != 0 and 'num_output_channels' in L.last_error()
     with pytest.raises(L.SimqError):
         L.Plan(0, 1)
+
+
+BF16_CASES = [
+    # B, H, Cin, Cout, k, pad, bias
+    (4, 24, 128, 256, 3, 1, False),
+    (2, 24, 512, 512, 3, 1, False),
+    (3, 24, 64, 64, 3, 1, False),          # M = 1728: ragged tiles
+    (2, 24, 512, 128, 1, 0, True),         # head conv1
+    (2, 48, 128, 32, 1, 0, True),          # head conv2 (N = 32)
+    (2, 24, 256, 512, 1, 0, False),        # downsample
+]
+
+
+@pytest.mark.parametrize('nplanes,tol_fwd', [(2, 5e-5), (1, 3e-2)], ids=['split_bf16x3', 'bf16'])
+@pytest.mark.parametrize('case', BF16_CASES, ids=lambda c: 'B%d_H%d_%dto%d_k%d' % (c[0], c[1], c[2], c[3], c[4]))
+def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
+    """bf16 MFMA kernels (plain bf16 and split-bf16 hi/lo with 3 products) vs an fp64 convolution.
+    split-bf16 must be fp32-class (<= 5e-5 of max|y|, typically 3e-6); plain bf16 is bf16-class."""
+    B, H, Cin, Cout, k, pad, bias = case
+    g = torch.Generator().manual_seed(99 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xd64 = x.double().requires_grad_(True)
+    wd64 = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xd64, wd64, None if b is None else b.double(), padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    st = L.stream_ptr()
+    xd, wd, dyd = nhwc(x), ohwi(w), nhwc(dy)
+    bd = dev(b) if bias else None
+    yd = torch.empty(B, H, H, Cout, device='cuda')
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(2 * (x.numel() + max(w.numel(), dy.numel())) + 64, dtype=torch.int16, device='cuda')
+    L.lib.call('simq_conv2d_fwd_bf16', L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(yd), B, H, H, Cin, Cout, k, k, 1, pad, nplanes,
+               L.ptr(scratch), L.ptr(stats), st)
+    y_nhwc = y_ref.detach().permute(0, 2, 3, 1)
+    assert rel(yd, y_nhwc) < tol_fwd
+    assert rel(stats[:Cout], yd.double().reshape(-1, Cout).sum(0)) < 1e-5      # statistics of what was written
+    dwd = torch.full((Cout, k, k, Cin), 7.0, device='cuda')
+    L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(xd), L.ptr(dyd), L.ptr(dwd), B, H, H, Cin, Cout, k, k, 1, pad, nplanes,
+               L.ptr(scratch), st)
+    assert rel(dwd, wd64.grad.permute(0, 2, 3, 1)) < tol_fwd

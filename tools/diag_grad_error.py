@@ -8,6 +8,7 @@ from simq import synth, arch
 from oracle import cases, fcn as ofcn, learner as ol
 
 name, cin, cout, B, wseed, dseed = cases.TRAIN_CASES[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
+PREC = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
 cfg = cases.make_cfg(B); batch = cases.make_batch(cin, cout, B, dseed); spec = ofcn.state_spec(cin, cout)
 ex = {}
 for dt in (torch.float32, torch.float64):
@@ -15,8 +16,8 @@ for dt in (torch.float32, torch.float64):
     e = {}
     ol.train_step(cfg, st, tg, spec, [None] * len(ol.grad_keys(spec)), batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, dtype=dt, extras=e)
     ex[dt] = e
-policy = simq.FCN(cin, cout); policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed))); policy.train()
-target = simq.FCN(cin, cout); target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed + 1000))); target.eval()
+policy = simq.FCN(cin, cout, precision=PREC); policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed))); policy.train()
+target = simq.FCN(cin, cout, precision=PREC); target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed + 1000))); target.eval()
 opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
 simq.train(cfg, policy, target, opt, batch, None, cases.GAMMA)
 tn = float(policy._simq_opt_state.total_norm.item()); coef = min(1.0, cases.CLIP / (tn + 1e-6))

@@ -45,3 +45,20 @@ for name, H, Cin, Cout, k, stride, pad in SHAPES:
     res.sort(reverse=True)
     print('%-7s M=%6d N=%4d K=%5d  auto %6.1f TF (%.3f ms) | wgrad %6.1f TF (%.3f ms) | ' % (name, B * Ho * Ho, Cout, k * k * Cin, flops / ms_auto / 1e9, ms_auto, flops / ms_wg / 1e9, ms_wg)
           + '  '.join('%dx%d:%.1f' % (bm, bn, tf) for tf, bm, bn, _ in res))
+
+print('--- bf16 matrix-core paths (algorithmic TFLOP/s = 2MNK / time; split-bf16 issues 3 MFMAs per product) ---')
+for name, H, Cin, Cout, k, stride, pad in SHAPES:
+    if Cin % 32 or stride != 1:
+        continue
+    x = torch.randn(B, H, H, Cin, device='cuda'); w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
+    y = torch.empty(B, H, H, Cout, device='cuda'); dy = torch.randn(B, H, H, Cout, device='cuda'); dw = torch.empty_like(w)
+    scratch = torch.empty(2 * (x.numel() + max(w.numel(), dy.numel())) + 64, dtype=torch.int16, device='cuda')
+    flops = 2.0 * B * H * H * Cout * k * k * Cin
+    # the entry points re-split the fp32 inputs on every call: time the splitters alone and subtract
+    out = []
+    for npl in (2, 1):
+        L.lib.call('simq_tune_force_tile', 0, 0)
+        ms_f = timeit(lambda: L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), None, st))
+        ms_w = timeit(lambda: L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(x), L.ptr(dy), L.ptr(dw), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), st))
+        out.append('np=%d fwd %.3f ms (%.0f TF incl. split)  wgrad %.3f ms (%.0f TF incl. split)' % (npl, ms_f, flops / ms_f / 1e9, ms_w, flops / ms_w / 1e9))
+    print('%-7s M=%6d N=%4d K=%5d  ' % (name, B * H * H, Cout, k * k * Cin) + ' | '.join(out))
