@@ -49,6 +49,7 @@ struct IgemmArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesN;
+    unsigned x_bytes, w_bytes;   // sizes of x / w for the bounds-checked buffer loads
 };
 
 template <int BM, int BN, bool VEC>
@@ -104,37 +105,43 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     // VEC K order: channel chunk outer, filter tap inner -- the R*S taps of one 16-channel chunk re-read the
     // same 64-B lines of x (shifted rows), so they hit L1/L2 instead of streaming x once per tap.
     int tap = 0, c0 = 0, ky = 0, kx = 0;
+    // VEC: this thread's rows (pixel base / top-left input coordinate) live in registers; invalid rows can never
+    // pass the bounds test
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    int rpix[VEC ? A_PASSES_V : 1], riy[VEC ? A_PASSES_V : 1], rix[VEC ? A_PASSES_V : 1];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES_V; ++ps) {
+            const int r = lrow + 64 * ps;
+            int4 ri = (BM % 64 == 0 || r < BM) ? rowinfo[r] : make_int4(0, 0, 0, 0);
+            rpix[ps] = ri.x;
+            riy[ps] = ri.w ? ri.y : -(1 << 20);
+            rix[ps] = ri.z;
+        }
+    }
 
-    auto load_tile = [&](auto set_c, int kt) {
+    auto load_tile = [&](auto set_c, int kt, bool live) {   // live == false: past the last K-tile, every lane reads zeros
         constexpr int SET = decltype(set_c)::value;
         if constexpr (VEC) {
+            // branch-free: out-of-image taps / ragged rows get byte offset 0xFFFFFFFF, which the buffer bounds
+            // check turns into a zero fill
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
-                const int r = lrow + 64 * ps;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (BM % 64 == 0 || r < BM) {
-                    int4 ri = rowinfo[r];
-                    int iy = ri.y + ky, ix = ri.z + kx;
-                    if (ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
-                        size_t off = (size_t)(ri.x + iy * p.Win + ix) * p.Cin + c0 + kq * 4;
-                        v = *reinterpret_cast<const float4*>(p.x + off);
-                    }
-                }
-                va[SET][ps] = v;
+                const int iy = riy[ps] + ky, ix = rix[ps] + kx;
+                const bool ok = live && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                const unsigned voff = ok ? (unsigned)((rpix[ps] + iy * p.Win + ix) * p.Cin + c0 + kq * 4) * 4u : 0xFFFFFFFFu;
+                va[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
                 const int n = lrow + 64 * ps;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (BN % 64 == 0 || n < BN) {
-                    size_t off = (size_t)(n0 + n) * p.K + (size_t)tap * p.Cin + c0 + kq * 4;
-                    v = *reinterpret_cast<const float4*>(p.w + off);
-                }
-                vb[SET][ps] = v;
+                const unsigned voff = (live && (BN % 64 == 0 || n < BN)) ? (unsigned)((n0 + n) * p.K + tap * p.Cin + c0 + kq * 4) * 4u : 0xFFFFFFFFu;
+                vb[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, 0, 0));
             }
         } else {
             int k = kt * BK + kl;
-            bool kok = k < p.K;
+            bool kok = live && k < p.K;
             int t = k / p.Cin, ci = k - t * p.Cin;
             int yy = t / p.S, xx = t - yy * p.S;
 #pragma unroll
@@ -203,31 +210,27 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    // prologue: tile 0 -> LDS stage 0; tile 1 in flight in register set 1
-    load_tile(S0{}, 0);
+    // prologue: tile 0 -> LDS stage 0; tile 1 in flight in register set 1.  Loads and stores are issued
+    // UNCONDITIONALLY (tiles past the end read zeros) so that the compiler can count outstanding loads and wait
+    // only for the older register set (s_waitcnt vmcnt(n) with n = loads of the newer set) at each LDS store.
+    load_tile(S0{}, 0, true);
     store_tile(S0{}, 0);
-    if (nk > 1) {
-        if constexpr (VEC) advance();
-        load_tile(S1{}, 1);
-    }
+    if constexpr (VEC) advance();
+    load_tile(S1{}, 1, nk > 1);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         // even step: tile kt is in stage 0, tile kt+1 is in flight in set 1; start tile kt+2 into set 0
-        if (kt + 2 < nk) {
-            if constexpr (VEC) advance();
-            load_tile(S0{}, kt + 2);
-        }
+        if constexpr (VEC) advance();
+        load_tile(S0{}, kt + 2, kt + 2 < nk);
         compute(0);
         store_tile(S1{}, 1);
         __syncthreads();
         // odd step: tile kt+1 is in stage 1, tile kt+2 is in flight in set 0; start tile kt+3 into set 1
-        if (kt + 3 < nk) {
-            if constexpr (VEC) advance();
-            load_tile(S1{}, kt + 3);
-        }
+        if constexpr (VEC) advance();
+        load_tile(S1{}, kt + 3, kt + 3 < nk);
         compute(1);
-        if (kt + 2 < nk) store_tile(S0{}, 0);
+        store_tile(S0{}, 0);
         __syncthreads();
     }
     if (kt < nk) compute(0);   // odd tile count: the last tile sits in stage 0
@@ -362,6 +365,9 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
+    const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, wb = 4.0 * g.Cout * a.K;
+    SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     SIMQ_REQUIRE(g.Cout % 32 == 0, "conv_igemm: Cout=%d must be a multiple of 32", g.Cout);
     const bool vec = (g.Cin % BK) == 0;
     SIMQ_REQUIRE(vec || g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);

@@ -42,6 +42,7 @@ struct IgemmBfArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesN;
+    unsigned x_bytes, w_bytes;     // plane sizes for the bounds-checked buffer loads
 };
 
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // f = {0,2,3,1}
@@ -89,31 +90,41 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
     const int lrow = tid >> 2, kq = tid & 3;
     int tap = 0, c0 = 0, ky = 0, kx = 0;    // K order: 32-channel chunk outer, filter tap inner (x lines re-used across taps)
 
-    auto load_tile = [&](auto set_c) {
+    // branch-free loads: out-of-image taps / ragged rows / tiles past the end use byte offset 0xFFFFFFFF, which the
+    // buffer bounds check zero-fills; rows of this thread live in registers
+    __amdgpu_buffer_rsrc_t xr[NP], wr[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        xr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x[pl]), 0, p.x_bytes, 0x00020000);
+        wr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w[pl]), 0, p.w_bytes, 0x00020000);
+    }
+    int rpix[A_PASSES], riy[A_PASSES], rix[A_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < A_PASSES; ++ps) {
+        const int r = lrow + 64 * ps;
+        int4 ri = (BM % 64 == 0 || r < BM) ? rowinfo[r] : make_int4(0, 0, 0, 0);
+        rpix[ps] = ri.x;
+        riy[ps] = ri.w ? ri.y : -(1 << 20);
+        rix[ps] = ri.z;
+    }
+    auto load_tile = [&](auto set_c, bool live) {
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
-            const int r = lrow + 64 * ps;
-            bool ok = false;
-            size_t off = 0;
-            if (BM % 64 == 0 || r < BM) {
-                int4 ri = rowinfo[r];
-                int iy = ri.y + ky, ix = ri.z + kx;
-                ok = ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = (size_t)(ri.x + iy * p.Win + ix) * p.Cin + c0 + kq * 8;
-            }
+            const int iy = riy[ps] + ky, ix = rix[ps] + kx;
+            const bool ok = live && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const unsigned voff = ok ? (unsigned)((rpix[ps] + iy * p.Win + ix) * p.Cin + c0 + kq * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                va[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.x[pl] + off) : make_uint4(0, 0, 0, 0);
+                va[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr[pl], voff, 0, 0));
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             const int n = lrow + 64 * ps;
-            const bool ok = (BN % 64 == 0 || n < BN);
-            const size_t off = (size_t)(n0 + n) * p.K + (size_t)tap * p.Cin + c0 + kq * 8;
+            const unsigned voff = (live && (BN % 64 == 0 || n < BN)) ? (unsigned)((n0 + n) * p.K + tap * p.Cin + c0 + kq * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                vb[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.w[pl] + off) : make_uint4(0, 0, 0, 0);
+                vb[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr[pl], voff, 0, 0));
         }
     };
     auto store_tile = [&](auto set_c, int buf) {
@@ -181,19 +192,20 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    load_tile(S0{});
+    // loads / stores are unconditional (zeros past the end) so the compiler can wait for the OLDER register set only
+    load_tile(S0{}, true);
     store_tile(S0{}, 0);
-    if (nk > 1) { advance(); load_tile(S1{}); }
+    advance(); load_tile(S1{}, nk > 1);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        if (kt + 2 < nk) { advance(); load_tile(S0{}); }
+        advance(); load_tile(S0{}, kt + 2 < nk);
         compute(0);
         store_tile(S1{}, 1);
         __syncthreads();
-        if (kt + 3 < nk) { advance(); load_tile(S1{}); }
+        advance(); load_tile(S1{}, kt + 3 < nk);
         compute(1);
-        if (kt + 2 < nk) store_tile(S0{}, 0);
+        store_tile(S0{}, 0);
         __syncthreads();
     }
     if (kt < nk) compute(0);
@@ -293,6 +305,9 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
+    const double xb = 2.0 * g.B * g.Hin * g.Win * g.Cin, wb = 2.0 * g.Cout * a.K;
+    SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm_bf16: tensor exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_igemm_bf16: nplanes must be 1 or 2");
     SIMQ_REQUIRE(g.Cout % 32 == 0 && g.Cin % BKB == 0, "conv_igemm_bf16: Cin=%d Cout=%d must be multiples of 32", g.Cin, g.Cout);
     int bm = 0, bn = 0;

@@ -7,9 +7,12 @@
 // r = output pixel.  Both operands are read exactly as they sit in HBM (NHWC: a pixel's
 // channels are contiguous, 16-B vector loads), staged to LDS as [pixel][channel] and fed to
 // v_mfma_f32_32x32x2_f32 with one conflict-free ds_read_b32 per operand (lane (i,h) reads
-// channel i of pixel 2*kk+h).  The pixel reduction is split over `splits` blocks per output
-// tile (the output is tiny compared with the reduction) and combined with hardware fp32
-// atomics into the zero-initialised gradient buffer.
+// channel i of pixel 2*kk+h).  The pixel reduction is split over blocks (the output is tiny
+// compared with the reduction) and combined with hardware fp32 atomics into the
+// zero-initialised gradient buffer.  Loads are bounds-checked buffer loads (no branches, zero
+// fill for padding / ragged ends) issued two reduction steps ahead of the MFMAs.
+#include <type_traits>
+
 #include "common.h"
 
 namespace simq {
@@ -25,6 +28,7 @@ struct WgradArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesI, tilesJ, rows_per_split;
+    unsigned x_bytes, dy_bytes;
 };
 
 template <int TI, int TJ, int WI, int WJ, bool VEC>
@@ -76,87 +80,73 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int Y_F4 = BR * TI / 4, X_F4 = BR * TJ / 4;
     constexpr int Y_PASSES = (Y_F4 + 255) / 256, X_PASSES_V = (X_F4 + 255) / 256;
     constexpr int X_PASSES_S = BR * TJ / 256;
-    float4 vy[Y_PASSES], vx[VEC ? X_PASSES_V : 1];
-    float sx[VEC ? 1 : X_PASSES_S];
+    float4 vy[2][Y_PASSES], vx[2][VEC ? X_PASSES_V : 1];
+    float sx[2][VEC ? 1 : X_PASSES_S];
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
 
-    auto load_tile = [&](int r0) {
+    auto load_tile = [&](auto set_c, int r0) {   // rows >= rend read zeros (byte offset 0xFFFFFFFF is out of bounds)
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int ps = 0; ps < Y_PASSES; ++ps) {
-            int idx = tid + 256 * ps;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (Y_F4 % 256 == 0 || idx < Y_F4) {
-                int row = idx / (TI / 4), c4 = idx - row * (TI / 4);
-                int r = r0 + row;
-                if (r < rend) v = *reinterpret_cast<const float4*>(p.dy + (size_t)r * p.Cout + i0 + c4 * 4);
-            }
-            vy[ps] = v;
+            const int idx = tid + 256 * ps;
+            const int row = idx / (TI / 4), c4 = idx - row * (TI / 4);
+            const int r = r0 + row;
+            const bool ok = (Y_F4 % 256 == 0 || idx < Y_F4) && r < rend;
+            const unsigned voff = ok ? (unsigned)(r * p.Cout + i0 + c4 * 4) * 4u : 0xFFFFFFFFu;
+            vy[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yr, voff, 0, 0));
         }
         if constexpr (VEC) {
 #pragma unroll
             for (int ps = 0; ps < X_PASSES_V; ++ps) {
-                int idx = tid + 256 * ps;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (X_F4 % 256 == 0 || idx < X_F4) {
-                    int row = idx / (TJ / 4), c4 = idx - row * (TJ / 4);
-                    int r = r0 + row;
-                    if (r < rend) {
-                        int b = r / hw, rem = r - b * hw;
-                        int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                        int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-                            v = *reinterpret_cast<const float4*>(
-                                p.x + ((size_t)(b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c4 * 4);
-                    }
-                }
-                vx[ps] = v;
+                const int idx = tid + 256 * ps;
+                const int row = idx / (TJ / 4), c4 = idx - row * (TJ / 4);
+                const int r = r0 + row;
+                const int b = r / hw, rem = r - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                const bool ok = (X_F4 % 256 == 0 || idx < X_F4) && r < rend && (unsigned)iy < (unsigned)p.Hin &&
+                                (unsigned)ix < (unsigned)p.Win;
+                const unsigned voff = ok ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c4 * 4) * 4u : 0xFFFFFFFFu;
+                vx[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
             }
         } else {
 #pragma unroll
             for (int ps = 0; ps < X_PASSES_S; ++ps) {
-                int row = tid / TJ + (256 / TJ) * ps;
-                int r = r0 + row;
-                float v = 0.f;
-                if (skok && r < rend) {
-                    int b = r / hw, rem = r - b * hw;
-                    int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                    int iy = oy * p.stride - p.pad + sky, ix = ox * p.stride - p.pad + skx;
-                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-                        v = p.x[((size_t)(b * p.Hin + iy) * p.Win + ix) * p.Cin + sci];
-                }
-                sx[ps] = v;
+                const int row = tid / TJ + (256 / TJ) * ps;
+                const int r = r0 + row;
+                const int b = r / hw, rem = r - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int iy = oy * p.stride - p.pad + sky, ix = ox * p.stride - p.pad + skx;
+                const bool ok = skok && r < rend && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                const unsigned voff = ok ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin + sci) * 4u : 0xFFFFFFFFu;
+                sx[SET][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, 0, 0));
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
         float* Ys = smem + buf * STAGE;
         float* Xs = Ys + BR * TI;
 #pragma unroll
         for (int ps = 0; ps < Y_PASSES; ++ps) {
             int idx = tid + 256 * ps;
-            if (Y_F4 % 256 == 0 || idx < Y_F4) *reinterpret_cast<float4*>(Ys + idx * 4) = vy[ps];
+            if (Y_F4 % 256 == 0 || idx < Y_F4) *reinterpret_cast<float4*>(Ys + idx * 4) = vy[SET][ps];
         }
         if constexpr (VEC) {
 #pragma unroll
             for (int ps = 0; ps < X_PASSES_V; ++ps) {
                 int idx = tid + 256 * ps;
-                if (X_F4 % 256 == 0 || idx < X_F4) *reinterpret_cast<float4*>(Xs + idx * 4) = vx[ps];
+                if (X_F4 % 256 == 0 || idx < X_F4) *reinterpret_cast<float4*>(Xs + idx * 4) = vx[SET][ps];
             }
         } else {
 #pragma unroll
-            for (int ps = 0; ps < X_PASSES_S; ++ps) Xs[(tid / TJ + (256 / TJ) * ps) * TJ + (tid % TJ)] = sx[ps];
+            for (int ps = 0; ps < X_PASSES_S; ++ps) Xs[(tid / TJ + (256 / TJ) * ps) * TJ + (tid % TJ)] = sx[SET][ps];
         }
     };
 
     const int fi = lane & 31, fh = lane >> 5;
-    if (rbeg < rend) {
-        load_tile(rbeg);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int r0 = rbeg; r0 < rend; r0 += BR) {
-        const bool more = (r0 + BR) < rend;
-        if (more) load_tile(r0 + BR);
+    auto compute = [&](int buf) {
         const float* Ys = smem + buf * STAGE;
         const float* Xs = Ys + BR * TI;
 #pragma unroll
@@ -172,11 +162,28 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                 for (int b = 0; b < NJ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    if (rbeg >= rend) return;   // block-uniform
+    const int nk = (rend - rbeg + BR - 1) / BR;
+    load_tile(S0{}, rbeg);
+    store_tile(S0{}, 0);
+    load_tile(S1{}, rbeg + BR);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {   // unconditional prefetch: counted vmcnt waits, loads 2 steps ahead
+        load_tile(S0{}, rbeg + (kt + 2) * BR);
+        compute(0);
+        store_tile(S1{}, 1);
         __syncthreads();
-        buf ^= 1;
+        load_tile(S1{}, rbeg + (kt + 3) * BR);
+        compute(1);
+        store_tile(S0{}, 0);
+        __syncthreads();
     }
-    if (rbeg >= rend) return;
+    if (kt < nk) compute(0);
 
     // C/D layout: col = lane & 31 (-> ci, contiguous in memory), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (-> co)
 #pragma unroll
@@ -245,6 +252,9 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
     a.tilesI = a.tilesJ = a.rows_per_split = 0;
     SIMQ_REQUIRE(a.M > 0, "wgrad: empty problem");
     SIMQ_REQUIRE(g.Cout % 32 == 0, "conv_wgrad: Cout=%d must be a multiple of 32", g.Cout);
+    const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, yb = 4.0 * a.M * g.Cout;
+    SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "conv_wgrad: tensor exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     const bool vec = (g.Cin % 64) == 0;
     if (vec) {
         if (g.Cout % 128 == 0) {

@@ -30,6 +30,7 @@ struct WgradBfArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesI, tilesJ, rows_per_split;
+    unsigned x_bytes, dy_bytes;
 };
 
 // swizzle of the 32-B (16-channel) chunk index by pixel row; CH = chunks per row
@@ -79,7 +80,14 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const WgradBfArgs p) {
     constexpr int Y_PASSES = (Y_V + 255) / 256, X_PASSES = (X_V + 255) / 256;
     uint4 vy[2][NP][Y_PASSES], vx[2][NP][X_PASSES];
 
-    auto load_tile = [&](auto set_c, int r0) {
+    // branch-free bounds-checked loads (byte offset 0xFFFFFFFF -> zero fill)
+    __amdgpu_buffer_rsrc_t xr[NP], yr[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        xr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x[pl]), 0, p.x_bytes, 0x00020000);
+        yr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy[pl]), 0, p.dy_bytes, 0x00020000);
+    }
+    auto load_tile = [&](auto set_c, int r0) {   // r0 >= rend: everything reads zeros
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int ps = 0; ps < Y_PASSES; ++ps) {
@@ -87,28 +95,24 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const WgradBfArgs p) {
             const int row = idx / Y_LANES, c8 = idx - row * Y_LANES;
             const int r = r0 + row;
             const bool ok = (Y_V % 256 == 0 || idx < Y_V) && r < rend;
-            const size_t off = (size_t)r * p.Cout + i0 + c8 * 8;
+            const unsigned voff = ok ? (unsigned)(r * p.Cout + i0 + c8 * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                vy[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.dy[pl] + off) : make_uint4(0, 0, 0, 0);
+                vy[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr[pl], voff, 0, 0));
         }
 #pragma unroll
         for (int ps = 0; ps < X_PASSES; ++ps) {
             const int idx = tid + 256 * ps;
             const int row = idx / X_LANES, c8 = idx - row * X_LANES;
             const int r = r0 + row;
-            bool ok = (X_V % 256 == 0 || idx < X_V) && r < rend;
-            size_t off = 0;
-            if (ok) {
-                int b = r / hw, rem = r - b * hw;
-                int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-                ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = ((size_t)(b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c8 * 8;
-            }
+            const int b = r / hw, rem = r - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+            const bool ok = (X_V % 256 == 0 || idx < X_V) && r < rend && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const unsigned voff = ok ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c8 * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                vx[SET][pl][ps] = ok ? *reinterpret_cast<const uint4*>(p.x[pl] + off) : make_uint4(0, 0, 0, 0);
+                vx[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr[pl], voff, 0, 0));
         }
     };
     auto store_tile = [&](auto set_c, int buf) {
@@ -185,17 +189,17 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const WgradBfArgs p) {
     const int nk = (rend - rbeg + BRB - 1) / BRB;
     load_tile(S0{}, rbeg);
     store_tile(S0{}, 0);
-    if (nk > 1) load_tile(S1{}, rbeg + BRB);
+    load_tile(S1{}, rbeg + BRB);
     __syncthreads();
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        if (kt + 2 < nk) load_tile(S0{}, rbeg + (kt + 2) * BRB);
+    for (; kt + 1 < nk; kt += 2) {     // unconditional prefetch (zeros past rend): counted vmcnt waits
+        load_tile(S0{}, rbeg + (kt + 2) * BRB);
         compute(0);
         store_tile(S1{}, 1);
         __syncthreads();
-        if (kt + 3 < nk) load_tile(S1{}, rbeg + (kt + 3) * BRB);
+        load_tile(S1{}, rbeg + (kt + 3) * BRB);
         compute(1);
-        if (kt + 2 < nk) store_tile(S0{}, 0);
+        store_tile(S0{}, 0);
         __syncthreads();
     }
     if (kt < nk) compute(0);
@@ -270,6 +274,9 @@ int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[
     a.M = g.M(); a.K = g.K();
     a.tilesI = a.tilesJ = a.rows_per_split = 0;
     SIMQ_REQUIRE(a.M > 0, "wgrad: empty problem");
+    const double xb = 2.0 * g.B * g.Hin * g.Win * g.Cin, yb = 2.0 * a.M * g.Cout;
+    SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "conv_wgrad_bf16: tensor exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_wgrad_bf16: nplanes must be 1 or 2");
     return nplanes == 2 ? dispatch<2>(a, stream) : dispatch<1>(a, stream);
 }
