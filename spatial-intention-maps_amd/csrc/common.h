@@ -45,6 +45,11 @@ struct ConvEpilogue {
     const float* shift = nullptr;    // [Cout]
     const float* addend = nullptr;   // [M][Cout] (may alias the output)
     int relu = 0;
+    // dgrad only: fused reduction of the NEXT BatchNorm backward (sum dz, sum dz*xhat with dz = out * (mask > 0)),
+    // optionally against a second (downsample-branch) BN that shares the mask.  See igemm_epilogue.h.
+    const float* bnr_mask = nullptr;
+    const float* bnr_y1 = nullptr; const float* bnr_mean1 = nullptr; const float* bnr_invstd1 = nullptr; double* bnr_red1 = nullptr;
+    const float* bnr_y2 = nullptr; const float* bnr_mean2 = nullptr; const float* bnr_invstd2 = nullptr; double* bnr_red2 = nullptr;
 };
 
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)

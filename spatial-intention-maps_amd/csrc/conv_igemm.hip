@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "igemm_epilogue.h"
 
 namespace simq {
 
@@ -39,13 +40,7 @@ constexpr int LDK = 24;  // padded row stride (floats): 96 B -> conflict-free ds
 struct IgemmArgs {
     const float* x;
     const float* w;
-    float* y;
-    const float* bias;
-    double* stats;
-    const float* scale;
-    const float* shift;
-    const float* addend;
-    int relu;
+    EpiArgs epi;
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesN;
@@ -236,56 +231,8 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     if (kt < nk) compute(0);   // odd tile count: the last tile sits in stage 0
     __syncthreads();
 
-    // ---- epilogue ----
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
-    float ssum[TN], ssq[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fi;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.scale ? p.shift[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * fq + r;
-                if (m < p.M) {
-                    float v = acc[i][j][r] + bias;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
-                    v = v * sc + sh;
-                    const size_t o = (size_t)m * p.Cout + n;
-                    if (p.addend) v += p.addend[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
-                }
-            }
-        }
-    }
-    if (p.stats) {   // block-uniform
-        double* red = reinterpret_cast<double*>(smem);   // [2 wave rows][BN][2], reuses the (now idle) stage buffers
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = ssum[j], q = ssq[j];
-            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (fq == 0) {
-                int c = wn * (BN / 2) + j * 16 + fi;
-                red[(wm * BN + c) * 2 + 0] = (double)s;
-                red[(wm * BN + c) * 2 + 1] = (double)q;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            double s = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
-            double q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            unsafeAtomicAdd(p.stats + n0 + tid, s);
-            unsafeAtomicAdd(p.stats + p.Cout + n0 + tid, q);
-        }
-    }
+    // ---- epilogue (igemm_epilogue.h); the stage buffers are idle now and serve as its reduction scratch ----
+    igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int taps,
@@ -359,8 +306,8 @@ int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream) {
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream) {
     IgemmArgs a;
-    a.x = x; a.w = w; a.y = y;
-    a.bias = e.bias; a.stats = e.stats; a.scale = e.scale; a.shift = e.shift; a.addend = e.addend; a.relu = e.relu;
+    a.x = x; a.w = w;
+    a.epi = make_epi(y, e);
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;

@@ -9,6 +9,7 @@
 //   simq_backward  == the autograd graph torch builds for it (loss.backward(), train.py:132)
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -290,8 +291,10 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 }
 
 // BatchNorm backward (train mode) fused with the ReLU mask of the activation that followed it; dy also as planes.
-int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows) {
-    RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
+// `reduced`: the sums (red slot) were already accumulated by the epilogue of the dgrad launch that produced g.
+int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
+           bool reduced = false) {
+    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.f, dz_out,
                                c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl);
 }
@@ -307,11 +310,13 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
 }
 
 // dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
-int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const float* addend, int hin) {
+// `fuse`: optional BN-backward reduction over the produced gradient (igemm_epilogue.h)
+int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const float* addend, int hin,
+               const ConvEpilogue& fuse = ConvEpilogue()) {
     ConvGeom g;
     g.B = c.B; g.Hin = hin; g.Win = hin; g.Cin = cv.cout; g.Cout = cv.cin; g.Hout = hin; g.Wout = hin;
     g.R = cv.k; g.S = cv.k; g.stride = 1; g.pad = cv.k - 1 - cv.pad;
-    ConvEpilogue e;
+    ConvEpilogue e = fuse;
     e.addend = addend;
     if (c.mc() && cv.wp_off >= 0) {
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
@@ -350,7 +355,21 @@ int backward_impl(const Ctx& c, const float* d_dq) {
     RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
-    RC(conv_dgrad(c, p->h1, dyh, S[1], nullptr, 24));
+    // every dgrad that completes the gradient of a block output (or of a block's inner activation) also
+    // accumulates sum(dz), sum(dz*xhat) of the BatchNorm(s) that consume that gradient next
+    static const bool no_fuse = getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // diagnostics: separate reduction kernels
+    auto fuse_block_out = [&](int bi) {   // bn2 (+ downsample BN) of block bi: mask = its output
+        ConvEpilogue e;
+        if (no_fuse) return e;
+        const BlockL& bb = p->blocks[bi];
+        e.bnr_mask = c.f(L.blk[bi].out);
+        e.bnr_y1 = c.f(L.blk[bi].y2); e.bnr_mean1 = c.aux(bb.b2, 2); e.bnr_invstd1 = c.aux(bb.b2, 3); e.bnr_red1 = c.red(bb.b2);
+        if (bb.has_ds) {
+            e.bnr_y2 = c.f(L.blk[bi].yd); e.bnr_mean2 = c.aux(bb.bds, 2); e.bnr_invstd2 = c.aux(bb.bds, 3); e.bnr_red2 = c.red(bb.bds);
+        }
+        return e;
+    };
+    RC(conv_dgrad(c, p->h1, dyh, S[1], nullptr, 24, fuse_block_out(7)));
     const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
     for (int i = 7; i >= 0; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
         const BlockL& b = p->blocks[i];
@@ -363,18 +382,23 @@ int backward_impl(const Ctx& c, const float* d_dq) {
         Act T1 = dyact(S[(gi + 2) & 3], 1);
         float* T2 = S[(gi + 3) & 3];
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
-        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows));
-        if (b.has_ds) RC(bn_bwd(c, b.bds, G, c.f(o.out), c.f(o.yd), T1, nullptr, rows));
+        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse));
+        if (b.has_ds) RC(bn_bwd(c, b.bds, G, c.f(o.out), c.f(o.yd), T1, nullptr, rows, !no_fuse));
         RC(conv_wgrad(c, b.c2, a1, T0, 24));
-        RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24));
-        RC(bn_bwd(c, b.b1, T2, c.f(o.a1), c.f(o.y1), T0, nullptr, rows));
+        ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
+        if (!no_fuse) {
+        f1.bnr_mask = c.f(o.a1); f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
+        }
+        RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1));
+        RC(bn_bwd(c, b.b1, T2, c.f(o.a1), c.f(o.y1), T0, nullptr, rows, !no_fuse));
         RC(conv_wgrad(c, b.c1, xin, T0, 24));
+        const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {
             RC(conv_wgrad(c, b.ds, xin, T1, 24));
             RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24));
-            RC(conv_dgrad(c, b.c1, T0, G, G, 24));
+            RC(conv_dgrad(c, b.c1, T0, G, G, 24, fin));
         } else {
-            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24));
+            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24, fin));
         }
         // G (same buffer) now holds the gradient w.r.t. the block input
     }

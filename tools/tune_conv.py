@@ -59,6 +59,7 @@ for name, H, Cin, Cout, k, stride, pad in SHAPES:
     for npl in (2, 1):
         L.lib.call('simq_tune_force_tile', 0, 0)
         ms_f = timeit(lambda: L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), None, st))
+        if Cin % 64 and not (Cout % 32 == 0 and Cin % 128 == 0): continue
         ms_w = timeit(lambda: L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(x), L.ptr(dy), L.ptr(dw), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), st))
         out.append('np=%d fwd %.3f ms (%.0f TF incl. split)  wgrad %.3f ms (%.0f TF incl. split)' % (npl, ms_f, flops / ms_f / 1e9, ms_w, flops / ms_w / 1e9))
     print('%-7s M=%6d N=%4d K=%5d  ' % (name, B * H * H, Cout, k * k * Cin) + ' | '.join(out))
