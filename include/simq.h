@@ -85,6 +85,12 @@ int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_ca
 /* Bytes of workspace simq_forward/simq_backward need for `batch` samples. */
 int64_t simq_workspace_bytes(const simq_plan* plan, int batch);
 
+/* Weight cache: derived copies of the convolution weights (flipped/transposed for dgrad; bf16 planes for the matrix-core
+ * precisions).  Caller-owned buffer of simq_wcache_bytes(); call simq_weights_prepare after EVERY change of d_params
+ * (optimiser step, load_state_dict, target sync) and pass the buffer to simq_forward / simq_backward.               */
+int64_t simq_wcache_bytes(const simq_plan* plan);
+int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_wcache, void* stream);
+
 /* Inspection aid (parity bisecting): where a saved NHWC fp32 activation lives inside the workspace after simq_forward.
  * name: "stem.conv" | "stem.pool" | "layer<1-4>.<0-1>" (BasicBlock outputs) | "head.a1" | "head.a2".              */
 int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems,
@@ -95,14 +101,14 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
  * d_q      [batch][Cout][96][96] fp32 NCHW
  * d_bnbuf  running stats; updated in place in TRAIN / TRAIN_NOGRAD modes (momentum 0.1,
  *          unbiased variance), read-only in EVAL.                                            */
-int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, float* d_bnbuf,
+int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf,
                  const float* d_x, float* d_q, void* d_workspace, void* stream);
 
 /* ---- autograd backward of FCN.forward (loss.backward(), train.py:132) ----------------------------
  * d_workspace must be the one used by the matching simq_forward(mode=TRAIN) call.
  * d_dq     [batch][Cout][96][96] upstream gradient (dense).
  * d_grads  flat gradient buffer (param layout); OVERWRITTEN.                                  */
-int simq_backward(const simq_plan* plan, int batch, const float* d_params, const float* d_dq,
+int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream);
 
 /* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */

@@ -66,6 +66,11 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
                            const ConvEpilogue& e, hipStream_t stream);
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
                            hipStream_t stream);
+// every convolution's weight transforms in one launch (see split_planes.hip)
+struct WeightPrepDesc { int64_t w_off, wt_off, wp_off; int cout, taps, cin, pad_; };
+struct WeightPrepTable { WeightPrepDesc d[24]; int n; };
+int launch_weight_prep_all(const float* params, const WeightPrepTable& t, float* wt_f32, uint16_t* wpl, uint16_t* wtpl, int np,
+                           int64_t wp_total, hipStream_t stream);
 int launch_split_planes(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t stream);
 int launch_weight_planes(const float* w, uint16_t* w_hi, uint16_t* w_lo, uint16_t* wt_hi, uint16_t* wt_lo, int cout, int taps,
                          int cin, hipStream_t stream);
@@ -76,19 +81,27 @@ int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int c
 struct Planes { uint16_t* hi = nullptr; uint16_t* lo = nullptr; };
 
 // ---- channel-last elementwise / reduction kernels (elementwise.hip) -------------------------------
-// BN finalize.  train: mean/var from stats[2C] over `rows`, running update, writes scale/shift/mean/invstd.
-int launch_bn_finalize_train(const double* stats, int C, int64_t rows, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float* scale, float* shift,
-                             float* save_mean, float* save_invstd, hipStream_t stream);
-int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
-                            const float* running_var, float* scale, float* shift, hipStream_t stream);
+// One BatchNorm layer as its consumers see it: train mode = fp64 sum / sum-of-squares over `rows` written by the producing
+// convolution's epilogue (stats != nullptr; the consumer also saves mean / invstd for backward and updates the running
+// statistics), eval mode = running statistics (stats == nullptr).
+struct BnRef {
+    const double* stats = nullptr;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* rmean = nullptr;
+    float* rvar = nullptr;
+    float* save_mean = nullptr;
+    float* save_invstd = nullptr;
+    double rows = 0.0, inv_rows = 0.0;
+    int C = 0;
+};
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
-int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res,
-                    const float* rscale, const float* rshift, int relu, float* out, int64_t rows, int C,
-                    hipStream_t stream, Planes pl = Planes());
+// out = [relu]( bn(y) [+ res | + rbn(res)] )
+int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
+                    int C, hipStream_t stream, Planes pl = Planes());
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
-int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx,
-                         int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
+int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
+                         hipStream_t stream, Planes pl = Planes());
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
                          int C, hipStream_t stream);

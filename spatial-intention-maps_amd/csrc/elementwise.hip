@@ -17,34 +17,46 @@ namespace {
 constexpr float BN_EPS = 1e-5f;
 constexpr double BN_MOMENTUM = 0.1;
 
-__global__ void bn_finalize_train_kernel(const double* __restrict__ stats, int C, double rows,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* running_mean, float* running_var, float* scale, float* shift,
-                                         float* save_mean, float* save_invstd) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mean = stats[c] / rows;
-    double var = stats[C + c] / rows - mean * mean;     // biased (normalisation) variance
-    if (var < 0.0) var = 0.0;
-    double invstd = 1.0 / sqrt(var + (double)BN_EPS);
-    float sc = (float)((double)gamma[c] * invstd);
-    scale[c] = sc;
-    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)invstd;
-    double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
-    running_mean[c] = (float)(BN_MOMENTUM * mean + (1.0 - BN_MOMENTUM) * (double)running_mean[c]);
-    running_var[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)running_var[c]);
+// ---- BatchNorm coefficients computed where they are consumed (no separate finalize launch) -------------------------
+// train: mean / biased var from the conv epilogue's fp64 sum / sum-of-squares; eval: running statistics.
+__device__ __forceinline__ void bn_coeff(const BnRef& b, int c, float& scale, float& shift, float& mean_f, float& invstd_f,
+                                         double& mean_d, double& var_d) {
+    double mean, var;
+    if (b.stats) {
+        mean = b.stats[c] * b.inv_rows;
+        var = b.stats[b.C + c] * b.inv_rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)b.rmean[c];
+        var = (double)b.rvar[c];
+    }
+    // 1/sqrt in fp64 without the (slow) fp64 sqrt / divide: fp32 rsqrt seed + two Newton steps (error < 1e-15)
+    const double v = var + (double)BN_EPS;
+    double invstd = (double)rsqrtf((float)v);
+    invstd = invstd * (1.5 - 0.5 * v * invstd * invstd);
+    invstd = invstd * (1.5 - 0.5 * v * invstd * invstd);
+    scale = (float)((double)b.gamma[c] * invstd);
+    shift = (float)((double)b.beta[c] - mean * (double)b.gamma[c] * invstd);
+    mean_f = (float)mean; invstd_f = (float)invstd; mean_d = mean; var_d = var;
 }
-
-__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                        const float* __restrict__ running_mean,
-                                        const float* __restrict__ running_var, float* scale, float* shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double invstd = 1.0 / sqrt((double)running_var[c] + (double)BN_EPS);
-    scale[c] = (float)((double)gamma[c] * invstd);
-    shift[c] = (float)((double)beta[c] - (double)running_mean[c] * (double)gamma[c] * invstd);
+__device__ __forceinline__ void bn_coeff4(const BnRef& b, int c, float4& sc, float4& sh) {
+    float m, i; double md, vd;
+    bn_coeff(b, c, sc.x, sh.x, m, i, md, vd); bn_coeff(b, c + 1, sc.y, sh.y, m, i, md, vd);
+    bn_coeff(b, c + 2, sc.z, sh.z, m, i, md, vd); bn_coeff(b, c + 3, sc.w, sh.w, m, i, md, vd);
+}
+// once per launch (block 0): save mean / invstd for backward and update the running statistics (momentum 0.1,
+// unbiased variance, in fp64 like ATen's CPU kernel)
+__device__ __forceinline__ void bn_commit(const BnRef& b) {
+    if (!b.stats || blockIdx.x != 0) return;
+    for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
+        float sc, sh, m, i; double md, vd;
+        bn_coeff(b, c, sc, sh, m, i, md, vd);
+        b.save_mean[c] = m;
+        b.save_invstd[c] = i;
+        const double unbiased = b.rows > 1.0 ? vd * b.rows / (b.rows - 1.0) : vd;
+        b.rmean[c] = (float)(BN_MOMENTUM * md + (1.0 - BN_MOMENTUM) * (double)b.rmean[c]);
+        b.rvar[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)b.rvar[c]);
+    }
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -71,27 +83,31 @@ __device__ __forceinline__ float4 relu4(float4 a) {
 }
 
 // out = [relu]( y*scale+shift [+ res | + res*rscale+rshift] ), one float4 per thread-iteration
-__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const float* __restrict__ res,
-                                const float* __restrict__ rscale, const float* __restrict__ rshift, int relu,
-                                float* __restrict__ out, Planes pl, size_t total4, int C4) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % C4) * 4;
-        float4 v = fma4(ld4(y + i * 4), ld4(scale + c), ld4(shift + c));
+__global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const float* __restrict__ res, BnRef rbn, int has_rbn,
+                                int relu, float* __restrict__ out, Planes pl, size_t total4, int C4) {
+    // the grid stride (gridDim*blockDim) is a multiple of C4, so a thread keeps its 4 channels: coefficients once
+    const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % C4) * 4;
+    float4 sc, sh, rsc, rsh;
+    bn_coeff4(bn, c, sc, sh);
+    if (has_rbn) bn_coeff4(rbn, c, rsc, rsh);
+    for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = fma4(ld4(y + i * 4), sc, sh);
         if (res) {
             float4 r = ld4(res + i * 4);
-            if (rscale) r = fma4(r, ld4(rscale + c), ld4(rshift + c));
+            if (has_rbn) r = fma4(r, rsc, rsh);
             v = add4(v, r);
         }
         if (relu) v = relu4(v);
         st4(out + i * 4, v);
         st_planes(pl, i, v);
     }
+    bn_commit(bn);
+    if (has_rbn) bn_commit(rbn);
 }
 
 // stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
-__global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, float* __restrict__ pooled,
+__global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, float* __restrict__ pooled,
                                      uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * Ho * Wo * C4;
@@ -101,7 +117,8 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* _
         int px = (int)(r % Wo); r /= Wo;
         int py = (int)(r % Ho);
         int b = (int)(r / Ho);
-        float4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+        float4 sc, sh;
+        bn_coeff4(bn, c4 * 4, sc, sh);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         uchar4 bi = make_uchar4(0, 0, 0, 0);
 #pragma unroll
@@ -124,6 +141,7 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, const float* _
         st_planes(pl, i, best);
         *reinterpret_cast<uchar4*>(idx + i * 4) = bi;
     }
+    bn_commit(bn);
 }
 
 // gather form of maxpool backward fused with the ReLU mask: dz at HxW from g at (H/2)x(W/2)
@@ -356,39 +374,22 @@ inline int grid_for(size_t work_items, int block = 256, int cap = 256 * 8) {
 
 }  // namespace
 
-int launch_bn_finalize_train(const double* stats, int C, int64_t rows, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float* scale, float* shift,
-                             float* save_mean, float* save_invstd, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, stats, C, (double)rows,
-                       gamma, beta, running_mean, running_var, scale, shift, save_mean, save_invstd);
-    SIMQ_CHECK_LAUNCH();
-    return 0;
-}
-
-int launch_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
-                            const float* running_var, float* scale, float* shift, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, C, gamma, beta,
-                       running_mean, running_var, scale, shift);
-    SIMQ_CHECK_LAUNCH();
-    return 0;
-}
-
-int launch_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rscale,
-                    const float* rshift, int relu, float* out, int64_t rows, int C, hipStream_t stream, Planes pl) {
-    SIMQ_REQUIRE(C % 4 == 0, "bn_apply: C=%d must be a multiple of 4", C);
+int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
+                    int C, hipStream_t stream, Planes pl) {
+    SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_apply: C=%d unsupported", C);
     size_t total4 = (size_t)rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, scale, shift, res, rscale,
-                       rshift, relu, out, pl, total4, C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, rbn ? *rbn : bn,
+                       rbn ? 1 : 0, relu, out, pl, total4, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_stem_pool_fwd(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, int B,
-                         int H, int W, int C, hipStream_t stream, Planes pl) {
+int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
+                         hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "stem_pool: bad shape");
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, scale, shift, pooled, idx,
-                       pl, B, H, W, C / 4);
+    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, bn, pooled, idx, pl, B, H,
+                       W, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

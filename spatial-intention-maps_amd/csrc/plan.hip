@@ -105,10 +105,10 @@ struct Layout {
     int64_t x, y0, pooled, idx;
     struct Blk { int64_t y1, a1, y2, yd, out, p_a1, p_out; } blk[8];
     int64_t yh1, ah1, up1, yh2, ah2, up2;
-    int64_t aux, red, wt, colsum;
+    int64_t aux, red, colsum;
     int64_t S[4];
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
-    int64_t p_pooled, p_up1, DP[2], wpl, wtpl;
+    int64_t p_pooled, p_up1, DP[2];
     int64_t total;
 };
 
@@ -133,11 +133,10 @@ Layout make_layout(const simq_plan* p, int B) {
     L.up2 = take((int64_t)B * 9216 * 32 * f);
     L.aux = take(p->aux_total * f);
     L.red = take(p->red_total * (int64_t)sizeof(double));
-    L.wt = take(p->wt_total * f);
     L.colsum = take(512 * sizeof(double));
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
     for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
-    L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = L.wpl = L.wtpl = -1;
+    L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = -1;
     for (int i = 0; i < 8; ++i) L.blk[i].p_a1 = L.blk[i].p_out = -1;
     if (p->precision != SIMQ_PREC_FP32) {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
@@ -150,11 +149,29 @@ Layout make_layout(const simq_plan* p, int B) {
         L.p_up1 = take((int64_t)B * 2304 * 128 * h);
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
-        L.wpl = take(p->wp_total * h);
-        L.wtpl = take(p->wp_total * h);
     }
     L.total = off;
     return L;
+}
+
+// Weight cache (caller-owned, one per parameter set): derived copies of the convolution weights that only change when
+// the parameters do -- fp32: flipped/transposed weights for dgrad; matrix-core precisions: bf16 planes of the weights
+// and of their flipped/transposed form.  Filled by simq_weights_prepare.
+struct WLayout { int64_t wt, wpl, wtpl, total; };
+WLayout make_wlayout(const simq_plan* p) {
+    WLayout W;
+    W.wt = W.wpl = W.wtpl = -1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+    if (p->precision == SIMQ_PREC_FP32) {
+        W.wt = take(p->wt_total * (int64_t)sizeof(float));
+    } else {
+        const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
+        W.wpl = take(p->wp_total * h);
+        W.wtpl = take(p->wp_total * h);
+    }
+    W.total = off;
+    return W;
 }
 
 struct Act {          // a tensor some convolution reads: fp32 view + (matrix-core precisions) its bf16 planes
@@ -171,6 +188,8 @@ struct Ctx {
     char* ws;
     Layout L;
     hipStream_t stream;
+    char* wc = nullptr;      // weight cache
+    WLayout W = WLayout();
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
     float* aux(const BnL& b, int which) const { return f(L.aux) + b.aux_off + (int64_t)which * b.C; }   // 0 scale 1 shift 2 mean 3 invstd
     double* red(const BnL& b) const { return reinterpret_cast<double*>(ws + L.red) + b.red_off; }
@@ -186,7 +205,7 @@ struct Ctx {
     Act act(int64_t off, int64_t poff, int64_t elems) const { Act a; a.f = f(off); a.pl = planes(poff, elems); return a; }
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
-        uint16_t* base = reinterpret_cast<uint16_t*>(ws + (transposed ? L.wtpl : L.wpl));
+        uint16_t* base = reinterpret_cast<uint16_t*>(wc + (transposed ? W.wtpl : W.wpl));
         out[0] = base + cv.wp_off;
         out[1] = p->np() == 2 ? base + p->wp_total + cv.wp_off : out[0];
     }
@@ -211,19 +230,24 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
     return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream);
 }
 
-// conv (+bias) with train-mode statistics or plain; then BN finalize for the mode
+// conv (+bias); in train modes its epilogue accumulates the BatchNorm batch statistics of `bn`
 int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x, float* y, int hin) {
     ConvGeom g = geom(cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
-    RC(conv_fwd(c, cv, x, y, g, e));
-    if (mode != SIMQ_MODE_EVAL)
-        return launch_bn_finalize_train(c.red(bn), bn.C, (int64_t)g.M(), c.params + bn.g_off, c.params + bn.b_off,
-                                        c.bnbuf + bn.buf_off, c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1),
-                                        c.aux(bn, 2), c.aux(bn, 3), c.stream);
-    return launch_bn_finalize_eval(bn.C, c.params + bn.g_off, c.params + bn.b_off, c.bnbuf + bn.buf_off,
-                                   c.bnbuf + bn.buf_off + bn.C, c.aux(bn, 0), c.aux(bn, 1), c.stream);
+    return conv_fwd(c, cv, x, y, g, e);
+}
+
+// how the consumer of a BatchNorm output sees the layer (coefficients are computed in the consuming kernel)
+BnRef bnref(const Ctx& c, const BnL& bn, int mode, int64_t rows) {
+    BnRef r;
+    r.stats = mode != SIMQ_MODE_EVAL ? c.red(bn) : nullptr;
+    r.gamma = c.params + bn.g_off; r.beta = c.params + bn.b_off;
+    r.rmean = c.bnbuf + bn.buf_off; r.rvar = c.bnbuf + bn.buf_off + bn.C;
+    r.save_mean = c.aux(bn, 2); r.save_invstd = c.aux(bn, 3);
+    r.rows = (double)rows; r.inv_rows = 1.0 / (double)rows; r.C = bn.C;
+    return r;
 }
 
 template <typename F>
@@ -236,6 +260,17 @@ int for_each_mc_conv(const simq_plan* p, F fn) {
     return 0;
 }
 
+WeightPrepTable weight_table(const simq_plan* p) {
+    WeightPrepTable t;
+    t.n = 0;
+    (void)for_each_mc_conv(p, [&](const ConvL& cv) {
+        WeightPrepDesc& d = t.d[t.n++];
+        d.w_off = cv.w_off; d.wt_off = cv.wt_off; d.wp_off = cv.wp_off; d.cout = cv.cout; d.taps = cv.k * cv.k; d.cin = cv.cin; d.pad_ = 0;
+        return 0;
+    });
+    return t;
+}
+
 int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
@@ -243,23 +278,12 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
     if (mode != SIMQ_MODE_EVAL)
         SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
-    if (c.mc()) {   // bf16 planes of the (fp32 master) weights, plain and flipped/transposed, once per call
-        uint16_t* wb = reinterpret_cast<uint16_t*>(c.ws + L.wpl);
-        uint16_t* wtb = reinterpret_cast<uint16_t*>(c.ws + L.wtpl);
-        const bool two = p->np() == 2;
-        RC(for_each_mc_conv(p, [&](const ConvL& cv) {
-            return launch_weight_planes(c.params + cv.w_off, wb + cv.wp_off, two ? wb + p->wp_total + cv.wp_off : nullptr,
-                                        mode == SIMQ_MODE_TRAIN ? wtb + cv.wp_off : nullptr,
-                                        (mode == SIMQ_MODE_TRAIN && two) ? wtb + p->wp_total + cv.wp_off : nullptr, cv.cout,
-                                        cv.k * cv.k, cv.cin, c.stream);
-        }));
-    }
     const int64_t rows = (int64_t)B * 576;
     // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97); always the fp32 kernel (Cin is 3..10)
     Act x0; x0.f = c.f(L.x);
     RC(conv_bn(c, p->stem, p->stem_bn, mode, x0, c.f(L.y0), 96));
     Act cur = c.act(L.pooled, L.p_pooled, rows * 64);
-    RC(launch_stem_pool_fwd(c.f(L.y0), c.aux(p->stem_bn, 0), c.aux(p->stem_bn, 1), cur.f,
+    RC(launch_stem_pool_fwd(c.f(L.y0), bnref(c, p->stem_bn, mode, (int64_t)B * 2304), cur.f,
                             reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl));
     for (int i = 0; i < 8; ++i) {   // BasicBlock.forward, resnet.py:31-47
         const BlockL& b = p->blocks[i];
@@ -267,24 +291,24 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         const int64_t n = rows * b.planes;
         Act a1 = c.act(o.a1, o.p_a1, n), out = c.act(o.out, o.p_out, n);
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
-        RC(launch_bn_apply(c.f(o.y1), c.aux(b.b1, 0), c.aux(b.b1, 1), nullptr, nullptr, nullptr, 1, a1.f, rows, b.planes, c.stream, a1.pl));
+        RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.f, rows, b.planes, c.stream, a1.pl));
         RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
         if (b.has_ds) {
             RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
-            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), c.f(o.yd), c.aux(b.bds, 0), c.aux(b.bds, 1), 1,
-                               out.f, rows, b.planes, c.stream, out.pl));
+            const BnRef rd = bnref(c, b.bds, mode, rows);
+            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), c.f(o.yd), &rd, 1, out.f, rows, b.planes, c.stream, out.pl));
         } else {
-            RC(launch_bn_apply(c.f(o.y2), c.aux(b.b2, 0), c.aux(b.b2, 1), cur.f, nullptr, nullptr, 1, out.f, rows, b.planes, c.stream, out.pl));
+            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), cur.f, nullptr, 1, out.f, rows, b.planes, c.stream, out.pl));
         }
         cur = out;
     }
     // head, networks.py:18-26
     RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-    RC(launch_bn_apply(c.f(L.yh1), c.aux(p->hb1, 0), c.aux(p->hb1, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
+    RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
     Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
     RC(launch_upsample2x_fwd(c.f(L.ah1), up1.f, B, 24, 24, 128, c.stream, up1.pl));
     RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
-    RC(launch_bn_apply(c.f(L.yh2), c.aux(p->hb2, 0), c.aux(p->hb2, 1), nullptr, nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
+    RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
     RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
     RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
     return 0;
@@ -324,7 +348,7 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
         c.wplanes(cv, true, wsp);
         return launch_conv_igemm_bf16(ds, wsp, c.p->np(), dx, g, e, c.stream);
     }
-    return launch_conv_igemm(dy.f, c.f(c.L.wt) + cv.wt_off, dx, g, e, c.stream);
+    return launch_conv_igemm(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wt) + cv.wt_off, dx, g, e, c.stream);
 }
 
 int backward_impl(const Ctx& c, const float* d_dq) {
@@ -333,11 +357,6 @@ int backward_impl(const Ctx& c, const float* d_dq) {
     const int B = c.B;
     SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
     SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
-    if (!c.mc()) {   // fp32: flipped / transposed weights for every convolution that needs a data gradient
-        RC(for_each_mc_conv(p, [&](const ConvL& cv) {
-            return launch_weight_transpose(c.params + cv.w_off, c.f(L.wt) + cv.wt_off, cv.cout, cv.k * cv.k, cv.cin, c.stream);
-        }));
-    }   // (matrix-core precisions: the planes written by the TRAIN forward of this workspace are still valid)
     float* S[4] = {c.f(L.S[0]), c.f(L.S[1]), c.f(L.S[2]), c.f(L.S[3])};
     const int64_t smax = (int64_t)B * 294912;
     auto dyact = [&](float* buf, int which) { Act a; a.f = buf; a.pl = c.planes(L.DP[which], smax); return a; };
@@ -533,20 +552,36 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
     return 0;
 }
 
-int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, float* d_bnbuf, const float* d_x,
-                 float* d_q, void* d_workspace, void* stream) {
-    SIMQ_REQUIRE(plan && d_params && d_bnbuf && d_x && d_q && d_workspace, "forward: NULL argument");
+int64_t simq_wcache_bytes(const simq_plan* plan) { return plan ? make_wlayout(plan).total : -1; }
+
+int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_wcache, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache, "weights_prepare: NULL argument");
+    const WLayout W = make_wlayout(plan);
+    char* wc = static_cast<char*>(d_wcache);
+    if (plan->precision == SIMQ_PREC_FP32)
+        return launch_weight_prep_all(d_params, weight_table(plan), reinterpret_cast<float*>(wc + W.wt), nullptr, nullptr, 1, 0,
+                                      static_cast<hipStream_t>(stream));
+    return launch_weight_prep_all(d_params, weight_table(plan), nullptr, reinterpret_cast<uint16_t*>(wc + W.wpl),
+                                  reinterpret_cast<uint16_t*>(wc + W.wtpl), plan->np(), plan->wp_total,
+                                  static_cast<hipStream_t>(stream));
+}
+
+int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf,
+                 const float* d_x, float* d_q, void* d_workspace, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_bnbuf && d_x && d_q && d_workspace, "forward: NULL argument");
     SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "forward: batch=%d out of range", batch);
     SIMQ_REQUIRE(mode >= 0 && mode <= 2, "forward: bad mode %d", mode);
     Ctx c{plan, batch, d_params, nullptr, d_bnbuf, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     return forward_impl(c, mode, d_x, d_q);
 }
 
-int simq_backward(const simq_plan* plan, int batch, const float* d_params, const float* d_dq, float* d_grads,
-                  void* d_workspace, void* stream) {
-    SIMQ_REQUIRE(plan && d_params && d_dq && d_grads && d_workspace, "backward: NULL argument");
+int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                  float* d_grads, void* d_workspace, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_dq && d_grads && d_workspace, "backward: NULL argument");
     SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     return backward_impl(c, d_dq);
 }
 

@@ -48,7 +48,49 @@ __global__ void weight_planes_kernel(const float* __restrict__ w, uint16_t* __re
     }
 }
 
+// All convolutions of the network in ONE launch (blockIdx.y = convolution): per step this replaces 21-22 tiny launches.
+// For every weight element: optional fp32 flipped/transposed copy (fp32 dgrad), optional bf16 planes of the OHWI
+// weight and of the flipped/transposed weight (matrix-core precisions).
+__global__ void weight_prep_all_kernel(const float* __restrict__ params, WeightPrepTable t, float* __restrict__ wt_f32,
+                                       uint16_t* __restrict__ wpl, uint16_t* __restrict__ wtpl, int np, int64_t wp_total) {
+    const WeightPrepDesc d = t.d[blockIdx.y];
+    const float* w = params + d.w_off;
+    const size_t total = (size_t)d.cout * d.taps * d.cin;
+    if (blockIdx.z == 0) {          // OHWI order: coalesced reads and plane writes
+        if (!wpl) return;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const float v = w[i];
+            const uint16_t h = to_bf16(v);
+            wpl[d.wp_off + i] = h;
+            if (np == 2) wpl[wp_total + d.wp_off + i] = to_bf16(v - from_bf16(h));
+        }
+        return;
+    }
+    if (!wt_f32 && !wtpl) return;   // flipped / transposed order: strided (L2-resident) reads, coalesced writes
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % d.cout);
+        const size_t r = i / d.cout;
+        const int tf = (int)(r % d.taps);
+        const int ci = (int)(r / d.taps);
+        const float v = w[((size_t)co * d.taps + (d.taps - 1 - tf)) * d.cin + ci];
+        if (wt_f32) wt_f32[d.wt_off + i] = v;
+        if (wtpl) {
+            const uint16_t h = to_bf16(v);
+            wtpl[d.wp_off + i] = h;
+            if (np == 2) wtpl[wp_total + d.wp_off + i] = to_bf16(v - from_bf16(h));
+        }
+    }
+}
+
 }  // namespace
+
+int launch_weight_prep_all(const float* params, const WeightPrepTable& t, float* wt_f32, uint16_t* wpl, uint16_t* wtpl, int np,
+                           int64_t wp_total, hipStream_t stream) {
+    if (t.n == 0) return 0;
+    hipLaunchKernelGGL(weight_prep_all_kernel, dim3(128, t.n, 2), dim3(256), 0, stream, params, t, wt_f32, wpl, wtpl, np, wp_total);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_split_planes(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t stream) {
     SIMQ_REQUIRE(n % 4 == 0, "split_planes: n must be a multiple of 4");

@@ -45,8 +45,10 @@ _SIGS = {
     'simq_bn_layer_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int)]),
     'simq_workspace_bytes': (c_int64, [c_void_p, c_int]),
     'simq_workspace_tensor': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
-    'simq_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_wcache_bytes': (c_int64, [c_void_p]),
+    'simq_weights_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_scatter_next_values': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

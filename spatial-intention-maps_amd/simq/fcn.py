@@ -84,6 +84,8 @@ class FCN(torch.nn.Module):
                 self.fc_bias = torch.nn.Parameter(torch.zeros(1000, device=self.device_))
         self._ws = {}
         self._train_generation = 0
+        self.wcache = torch.empty(max(int(lib.c.simq_wcache_bytes(self.plan.handle)), 16), dtype=torch.uint8, device=self.device_)
+        self.weights_dirty = True      # set whenever flat_params changes; the next forward refreshes the weight cache
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / (de)serialisation
@@ -183,6 +185,7 @@ class FCN(torch.nn.Module):
                     self.fc_weight.copy_(v.to(self.device_))
                 else:
                     self.fc_bias.copy_(v.to(self.device_))
+        self.weights_dirty = True
         if strict and missing:
             raise SimqError('load_state_dict: missing keys %s' % missing[:5])
         return torch.nn.modules.module._IncompatibleKeys(missing, [])
@@ -195,6 +198,7 @@ class FCN(torch.nn.Module):
             self.fc_weight.copy_(other.fc_weight)
             self.fc_bias.copy_(other.fc_bias)
         self.num_batches_tracked = OrderedDict(other.num_batches_tracked)
+        self.weights_dirty = True
 
     # ------------------------------------------------------------------ raw kernels over flat buffers
     def _workspace(self, slot, batch):
@@ -204,6 +208,11 @@ class FCN(torch.nn.Module):
             ws = torch.empty(need, dtype=torch.uint8, device=self.device_)
             self._ws[slot] = ws
         return ws
+
+    def _ensure_weights(self):
+        if self.weights_dirty:
+            lib.call('simq_weights_prepare', self.plan.handle, ptr(self.flat_params), ptr(self.wcache), stream_ptr(self.device_))
+            self.weights_dirty = False
 
     def _forward_raw(self, x_nhwc, mode):
         """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96]."""
@@ -219,7 +228,8 @@ class FCN(torch.nn.Module):
             self._train_generation += 1
         ws = self._workspace('train' if mode == MODE_TRAIN else 'tmp', B)
         q = torch.empty((B, self.num_output_channels, W, W), dtype=torch.float32, device=self.device_)
-        lib.call('simq_forward', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.bn_buffers), ptr(x_nhwc),
+        self._ensure_weights()
+        lib.call('simq_forward', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.wcache), ptr(self.bn_buffers), ptr(x_nhwc),
                  ptr(q), ptr(ws), stream_ptr(self.device_))
         if mode != MODE_EVAL:
             for k in self.num_batches_tracked:
@@ -231,7 +241,7 @@ class FCN(torch.nn.Module):
         ws = self._ws.get('train')
         if ws is None:
             raise SimqError('simq.FCN: backward without a grad-mode forward')
-        lib.call('simq_backward', self.plan.handle, batch, ptr(self.flat_params), ptr(dq), ptr(self.flat_grads), ptr(ws),
+        lib.call('simq_backward', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq), ptr(self.flat_grads), ptr(ws),
                  stream_ptr(self.device_))
         return self.flat_grads
 
@@ -250,6 +260,10 @@ class FCN(torch.nn.Module):
 
     def forward_nhwc(self, x_nhwc):
         """Same as forward() for inputs already in the replay/HWC layout [B,96,96,Cin]."""
+        # public entry point: an external optimiser (torch.optim.SGD over .parameters()) may have stepped the flat
+        # buffer since the last call, so the derived weight cache is refreshed every time (~0.1 ms); the fused
+        # learner (simq.train) calls _forward_raw and tracks the dirty flag itself
+        self.weights_dirty = True
         if not self.training:
             return self._forward_raw(x_nhwc, MODE_EVAL)
         if not torch.is_grad_enabled():

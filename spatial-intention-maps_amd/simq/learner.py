@@ -253,6 +253,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
              policy_net.plan.param_count, float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0,
              lr, momentum, weight_decay, 0 if st_opt.initialised else 1, ptr(st_opt.scratch), ptr(st_opt.total_norm), st)
     st_opt.initialised = True
+    policy_net.weights_dirty = True      # parameters moved: the next forward refreshes the derived weight cache
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q}
     if not sync:
         return out4

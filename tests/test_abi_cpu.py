@@ -62,7 +62,7 @@ def test_argument_errors_are_reported_not_thrown(L):
     with pytest.raises(L.SimqError):
         L.Plan(0, 1)
     plan = L.Plan(4, 2)
-    assert L.lib.c.simq_forward(plan.handle, 1, 2, None, None, None, None, None, None) != 0
+    assert L.lib.c.simq_forward(plan.handle, 1, 2, None, None, None, None, None, None, None) != 0
     assert 'NULL' in L.last_error()
 
 
