@@ -51,6 +51,8 @@ def parse():
                     help="arithmetic of the 3x3/1x1 convolutions; the default 'fp32' (exact) is the BASELINE configs[1] workload")
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='transitions per GPU per step (default: configs[1])')
     ap.add_argument('--cin', type=int, default=CIN)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo only to debug the rank logic on one GPU)')
     return ap.parse_args()
 
 
@@ -89,6 +91,19 @@ def cpu_baseline(batch):
                       % (batch, warm, steps, dt, os.cpu_count() or 0, avail)}
 
 
+def pmc_traffic(precision):
+    """HBM-side bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes) from the committed
+    rocprofv3 PMC passes over this same command (profiles/r01_pmc_traffic.json, tools/pmc_traffic.py); PMC counters cannot
+    be read from inside the timed process, so the value is the recorded one, or None when the file is absent."""
+    if precision != 'fp32':
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        return round(t['igemm_conv_kernel<96, 128, true>']['bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -100,13 +115,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no GPU visible); there is no CPU product path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    if world > 1 and args.backend == 'nccl' and ndev < world:
+        sys.exit('bench.py: %d ranks need %d GPUs, only %d visible' % (world, world, ndev))
+    local_dev = local_rank % ndev       # (gloo debugging may stack ranks on one GPU)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     import simq
@@ -182,7 +204,7 @@ def main():
         roof = {
             'bound': 'mfma', 'kernel': kname,
             'achieved': round(ach, 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK, 4),
-            'traffic': None,
+            'traffic': pmc_traffic(args.precision),
             'launches_per_step': ig['launches'] / args.steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
             'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
             'kernel_ms_per_step': round(ig['ms'] / args.steps, 4),
