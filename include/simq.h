@@ -111,6 +111,12 @@ int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_para
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream);
 
+/* Two-phase form for data-parallel callers: phase 1 (zero-fill + head + layer4) leaves d_grads[simq_grad_bucket_split() ..]
+ * final, so its all-reduce can overlap phase 2 (layers 3..1 + stem, which completes d_grads[0 .. split)).  phase 0 = both. */
+int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                        float* d_grads, void* d_workspace, int phase, void* stream);
+int64_t simq_grad_bucket_split(const simq_plan* plan);
+
 /* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */
 /* flat max / first-index argmax over each row of d_q [rows][n]  (train.py:121,124; policies.py:64) */
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream);

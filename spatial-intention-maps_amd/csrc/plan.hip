@@ -351,18 +351,26 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
     return launch_conv_igemm(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wt) + cv.wt_off, dx, g, e, c.stream);
 }
 
-int backward_impl(const Ctx& c, const float* d_dq) {
+// phase 0: everything.  Phases 1 / 2 split the walk after layer4 so that a data-parallel caller can start the
+// all-reduce of the (already final) head + layer4 gradients -- 75 % of the bytes -- while layers 3..1 + stem still run:
+//   phase 1 = zero-fill, head, blocks 7..6 (layer4)      phase 2 = blocks 5..0, stem
+constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that belongs to phase 1
+
+int backward_impl(const Ctx& c, const float* d_dq, int phase) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
     const int B = c.B;
-    SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
-    SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
+    if (phase != 2) {
+        SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
+        SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
+    }
     float* S[4] = {c.f(L.S[0]), c.f(L.S[1]), c.f(L.S[2]), c.f(L.S[3])};
     const int64_t smax = (int64_t)B * 294912;
     auto dyact = [&](float* buf, int which) { Act a; a.f = buf; a.pl = c.planes(L.DP[which], smax); return a; };
     double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
+    if (phase != 2) {
     RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
     RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     Act dyh = dyact(S[0], 0);
@@ -374,6 +382,7 @@ int backward_impl(const Ctx& c, const float* d_dq) {
     RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
+    }
     // every dgrad that completes the gradient of a block output (or of a block's inner activation) also
     // accumulates sum(dz), sum(dz*xhat) of the BatchNorm(s) that consume that gradient next
     static const bool no_fuse = getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // diagnostics: separate reduction kernels
@@ -388,9 +397,10 @@ int backward_impl(const Ctx& c, const float* d_dq) {
         }
         return e;
     };
-    RC(conv_dgrad(c, p->h1, dyh, S[1], nullptr, 24, fuse_block_out(7)));
+    if (phase != 2) RC(conv_dgrad(c, p->h1, dyact(S[0], 0), S[1], nullptr, 24, fuse_block_out(7)));
     const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
-    for (int i = 7; i >= 0; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
+    const int i_hi = phase == 2 ? kPhaseSplitBlock - 1 : 7, i_lo = phase == 1 ? kPhaseSplitBlock : 0;
+    for (int i = i_hi; i >= i_lo; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
         const Act xin = i == 0 ? c.act(L.pooled, L.p_pooled, rows * 64)
@@ -421,6 +431,7 @@ int backward_impl(const Ctx& c, const float* d_dq) {
         }
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
+    if (phase == 1) return 0;
     // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient; fp32 kernels ----
     float* G = S[gi];
     float* T0 = S[(gi + 1) & 3];
@@ -576,14 +587,22 @@ int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_para
     return forward_impl(c, mode, d_x, d_q);
 }
 
-int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
-                  float* d_grads, void* d_workspace, void* stream) {
+int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                        float* d_grads, void* d_workspace, int phase, void* stream) {
     SIMQ_REQUIRE(plan && d_params && d_wcache && d_dq && d_grads && d_workspace, "backward: NULL argument");
+    SIMQ_REQUIRE(phase >= 0 && phase <= 2, "backward: bad phase %d", phase);
     SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
-    return backward_impl(c, d_dq);
+    return backward_impl(c, d_dq, phase);
 }
+
+int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                  float* d_grads, void* d_workspace, void* stream) {
+    return simq_backward_phase(plan, batch, d_params, d_wcache, d_dq, d_grads, d_workspace, 0, stream);
+}
+
+int64_t simq_grad_bucket_split(const simq_plan* plan) { return plan ? plan->blocks[kPhaseSplitBlock].c1.w_off : -1; }
 
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream) {
     SIMQ_REQUIRE(rows >= 0 && n >= 1, "q_argmax: bad shape");

@@ -44,6 +44,12 @@ def allreduce_gradients(flat_grads, loss_sums=None, group=None):
     return flat_grads
 
 
+def allreduce_async(tensor, group=None):
+    """Sum `tensor` over ranks in place without blocking the caller's stream; `.wait()` the returned work before the
+    result is consumed (NCCL/RCCL: makes the current stream wait for the collective's stream)."""
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def broadcast_bn_buffers(bn_buffers, group=None, src=0):
     """DataParallel keeps only device 0's running statistics: make every rank adopt rank `src`'s."""
     dist.broadcast(bn_buffers, src=src, group=group)

@@ -236,14 +236,20 @@ class FCN(torch.nn.Module):
                 self.num_batches_tracked[k] += 1
         return q
 
-    def _backward_raw(self, dq, batch):
-        """dq [B,Cout,96,96] -> flat gradient buffer (overwritten)."""
+    def _backward_raw(self, dq, batch, phase=0):
+        """dq [B,Cout,96,96] -> flat gradient buffer (overwritten).  phase 1 / 2: the two halves of the walk
+        (head + layer4, then the rest) for callers that overlap the gradient all-reduce with phase 2."""
         ws = self._ws.get('train')
         if ws is None:
             raise SimqError('simq.FCN: backward without a grad-mode forward')
-        lib.call('simq_backward', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq), ptr(self.flat_grads), ptr(ws),
-                 stream_ptr(self.device_))
+        lib.call('simq_backward_phase', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq),
+                 ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
         return self.flat_grads
+
+    @property
+    def grad_bucket_split(self):
+        """flat_grads[split:] (head + layer4, 75 % of the bytes) is final after backward phase 1."""
+        return int(lib.c.simq_grad_bucket_split(self.plan.handle))
 
     def to_nhwc(self, x_nchw):
         x = x_nchw.to(self.device_, torch.float32).contiguous()
