@@ -184,51 +184,67 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
 
     // v_mfma_f32_16x16x4_f32 operands: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]
     const int fi = lane & 15, fq = lane >> 4;
-    auto compute = [&](int buf) {
+    // Software pipeline: while the MFMAs of K-step k run from register fragment set (k & 1), the same wave already
+    // reads the fragments of step k+1 from LDS into the other set, has the global loads of tile k+3 in flight and
+    // writes tile k+2 to the LDS stage that step k's fragments came from -- a wave never leaves the matrix pipe idle
+    // waiting for LDS / HBM, so two waves per SIMD are enough to keep it saturated.
+    floatx4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
         const float* As = smem + buf * STAGE_FLOATS;
         const float* Bs = As + A_FLOATS;
-        floatx4 af[TM], bf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            af[i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / 2) + i * 16 + fi) * LDK + fq * 4);
+            af[SET][i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / 2) + i * 16 + fi) * LDK + fq * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            bf[j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / 2) + j * 16 + fi) * LDK + fq * 4);
+            bf[SET][j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / 2) + j * 16 + fi) * LDK + fq * 4);
+    };
+    auto mfma_step = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e)   // MFMA e contracts k = {e, 4+e, 8+e, 12+e} (same permutation for A and B)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[SET][i][e], bf[SET][j][e], acc[i][j], 0, 0, 0);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    // prologue: tile 0 -> LDS stage 0; tile 1 in flight in register set 1.  Loads and stores are issued
-    // UNCONDITIONALLY (tiles past the end read zeros) so that the compiler can count outstanding loads and wait
-    // only for the older register set (s_waitcnt vmcnt(n) with n = loads of the newer set) at each LDS store.
-    load_tile(S0{}, 0, true);
-    store_tile(S0{}, 0);
+    // prologue.  All loads / stores are issued UNCONDITIONALLY (tiles past the end read zeros) so that the compiler
+    // can count outstanding loads and wait only for the older register set at each LDS store.
+    load_tile(S0{}, 0, true);                         // tile 0
     if constexpr (VEC) advance();
-    load_tile(S1{}, 1, nk > 1);
+    load_tile(S1{}, 1, nk > 1);                       // tile 1
+    store_tile(S0{}, 0);                              // tile 0 -> stage 0
+    if constexpr (VEC) advance();
+    load_tile(S0{}, 2, nk > 2);                       // tile 2 in flight (set 0)
     __syncthreads();
+    read_frags(S0{}, 0);                              // fragments of step 0
+    store_tile(S1{}, 1);                              // tile 1 -> stage 1
+    if constexpr (VEC) advance();
+    load_tile(S1{}, 3, nk > 3);                       // tile 3 in flight (set 1)
+    __syncthreads();
+    // invariant at the top of step k (k even shown): fragments(k) in set 0; stage 1 holds tile k+1 (visible);
+    // stage 0 is free (every wave read fragments(k) before the last barrier); tile k+2 in global set 0, k+3 in set 1
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        // even step: tile kt is in stage 0, tile kt+1 is in flight in set 1; start tile kt+2 into set 0
+        read_frags(S1{}, 1);                          // fragments(k+1)
+        mfma_step(S0{});                              // step k
+        store_tile(S0{}, 0);                          // tile k+2 -> stage 0
         if constexpr (VEC) advance();
-        load_tile(S0{}, kt + 2, kt + 2 < nk);
-        compute(0);
-        store_tile(S1{}, 1);
+        load_tile(S0{}, kt + 4, kt + 4 < nk);
         __syncthreads();
-        // odd step: tile kt+1 is in stage 1, tile kt+2 is in flight in set 0; start tile kt+3 into set 1
+        read_frags(S0{}, 0);                          // fragments(k+2)
+        mfma_step(S1{});                              // step k+1
+        store_tile(S1{}, 1);                          // tile k+3 -> stage 1
         if constexpr (VEC) advance();
-        load_tile(S1{}, kt + 3, kt + 3 < nk);
-        compute(1);
-        store_tile(S0{}, 0);
+        load_tile(S1{}, kt + 5, kt + 5 < nk);
         __syncthreads();
     }
-    if (kt < nk) compute(0);   // odd tile count: the last tile sits in stage 0
+    if (kt < nk) mfma_step(S0{});                     // odd tile count: last step's fragments are in set 0
     __syncthreads();
 
     // ---- epilogue (igemm_epilogue.h); the stage buffers are idle now and serve as its reduction scratch ----

@@ -152,6 +152,16 @@ class DeviceReplayBuffer:
         return self.gather(self.sample_indices(batch_size))
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class _OptState:
     """Flat momentum buffer aliased into a torch.optim.SGD's per-parameter state so that
     optimizer.state_dict() / load_state_dict() (train.py:204,331) keep working."""
@@ -219,6 +229,13 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     n = policy_net.num_output_channels * W * W
     st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
 
+    # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes:
+    # it runs on a side stream so its blocks fill the CUs that the tail of each policy-net kernel leaves idle.
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
     # train.py:114 -- policy forward, train-mode BN, activations kept for backward
     q = policy_net._forward_raw(b.state, MODE_TRAIN)
     # train.py:116-124 -- bootstrap values of the non-final next states
@@ -230,11 +247,12 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
         q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD)
         best = torch.empty(Nn, dtype=torch.int64, device=dev)
         lib.call('simq_q_argmax', ptr(q_next), Nn, n, ptr(best), None, st)
-        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122 (target in eval mode)
+        main.wait_stream(side)
         lib.call('simq_q_gather', ptr(q_tgt), Nn, n, ptr(best), ptr(vals), st)
     else:
-        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:124
+        main.wait_stream(side)
         lib.call('simq_q_argmax', ptr(q_tgt), Nn, n, None, ptr(vals), st)
+    q_tgt.record_stream(main)
     lib.call('simq_scatter_next_values', ptr(vals), ptr(b.nonfinal_pos), Nn, ptr(nsv), B, st)
     # train.py:115,126-129 + the gradient autograd would hand to `output`
     q_sa = torch.empty(B, dtype=torch.float32, device=dev)
