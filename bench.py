@@ -184,6 +184,8 @@ def main():
     roof = None
     if not args.no_roofline:
         # live per-launch timing of the GEMM-class kernels (HIP events on the launch stream) over the same K steps
+        import simq.learner as slearner
+        slearner.OVERLAP_TARGET_FORWARD = False    # serial kernels: each HIP-event bracket then times one kernel alone
         lib.call('simq_profile_start')
         barrier()
         t1 = time.perf_counter()

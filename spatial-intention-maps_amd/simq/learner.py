@@ -153,6 +153,8 @@ class DeviceReplayBuffer:
 
 
 _SIDE_STREAMS = {}
+OVERLAP_TARGET_FORWARD = True    # run the (independent) target-net forward on a side stream; bench.py turns it off
+                                 # for its per-kernel HIP-event pass, where concurrent kernels would share the GPU
 
 
 def _side_stream(dev):
@@ -232,7 +234,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes:
     # it runs on a side stream so its blocks fill the CUs that the tail of each policy-net kernel leaves idle.
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev)
+    side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else main
     side.wait_stream(main)
     with torch.cuda.stream(side):
         q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
