@@ -1,0 +1,178 @@
+"""GPU: BASELINE.json's full sizes (configs[1]: B=32 fp32; configs[2]: B=128 Cin=5 bf16; configs[3]: two heterogeneous
+heads) through size-independent properties -- the CPU oracle would need minutes per step at these sizes:
+
+  * minibatch permutation invariance of loss / td-error / gradient (only the summation order changes),
+  * linearity of the backward pass in the upstream gradient,
+  * exact invariants of train-mode BatchNorm backward (sum_rows dy = 0  =>  the head-conv bias gradients vanish),
+  * clip_grad_norm_ post-condition (||g|| <= max_norm) and SGD first-step identity (momentum buffer == clipped g + wd*p),
+  * bit-reproducible eval forward / replay gather, first-index argmax on a constant Q-map,
+  * the per-group loop of train.py:255-257 on a lifting (Cout=2) + pushing (Cout=1) policy.
+"""
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from oracle import fcn as ofcn
+from simq import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def simq_mod():
+    import simq
+    from simq import _lib  # noqa: F401
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return simq
+
+
+def make_pair(simq_mod, cin, cout, seed, precision='fp32'):
+    policy, target = simq_mod.FCN(cin, cout, precision=precision), simq_mod.FCN(cin, cout, precision=precision)
+    policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, seed)))
+    target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, seed + 1)))
+    policy.train()
+    target.eval()
+    return policy, target
+
+
+def relnorm(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def run_step(simq_mod, cin, cout, transitions, B, seed, precision='fp32', clip=cases.CLIP):
+    from simq.learner import Transition, train_step
+    policy, target = make_pair(simq_mod, cin, cout, seed, precision)
+    batch = Transition(*zip(*transitions))
+    info = train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, clip)
+    return policy, info
+
+
+def test_b32_permutation_invariance_and_optimizer_invariants(simq_mod):
+    cin, cout, B = 4, 2, 32
+    trs = synth.make_transitions(B, cin, cout, 17, terminal_frac=0.1)
+    p0 = ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 5))
+    pol_a, info_a = run_step(simq_mod, cin, cout, trs, B, 5)
+    perm = list(range(B))
+    random.Random(3).shuffle(perm)
+    pol_b, info_b = run_step(simq_mod, cin, cout, [trs[i] for i in perm], B, 5)
+    assert abs(info_a['loss'] - info_b['loss']) <= 1e-5 * abs(info_a['loss'])
+    assert abs(info_a['td_error'] - info_b['td_error']) <= 1e-5 * abs(info_a['td_error'])
+    # same multiset of samples -> same gradient up to summation order (and the ill-conditioning documented in DESIGN 2)
+    assert relnorm(pol_a.flat_grads, pol_b.flat_grads) < 2e-2
+    assert relnorm(pol_a._last['q_sa'][perm], pol_b._last['q_sa']) < 1e-5
+    # clip post-condition and first SGD step identity: m = c*g + wd*p0 ; p1 = p0 - lr*m
+    tn = float(pol_a._simq_opt_state.total_norm.item())
+    assert tn > cases.CLIP                                   # clipping is active on this workload
+    gn = float(pol_a.flat_grads.double().norm())
+    assert abs(gn - cases.CLIP) <= 1e-4 * cases.CLIP
+    ref = make_pair(simq_mod, cin, cout, 5)[0]
+    m = pol_a._simq_opt_state.momentum
+    assert relnorm(m, pol_a.flat_grads + cases.WEIGHT_DECAY * ref.flat_params) < 1e-6
+    assert relnorm(pol_a.flat_params, ref.flat_params - cases.LR * m) < 1e-6
+    # BN-backward invariant: the conv biases that feed a train-mode BN get a (numerically) zero gradient
+    for (name, _, _), (off, n, _) in zip(pol_a._param_names, pol_a._grad_views):
+        if name in ('conv1.bias', 'conv2.bias'):
+            assert float(pol_a.flat_grads[off:off + n].abs().max()) < 1e-5
+    del p0
+
+
+def test_b32_backward_is_linear_in_upstream_gradient(simq_mod):
+    cin, cout, B = 4, 2, 32
+    policy, _ = make_pair(simq_mod, cin, cout, 9)
+    x = torch.from_numpy(synth.make_states(B, cin, 4)).cuda()
+    g = torch.Generator(device='cpu').manual_seed(1)
+    dq1 = (torch.randn(B, cout, 96, 96, generator=g) * 1e-3).cuda()
+    dq2 = (torch.randn(B, cout, 96, 96, generator=g) * 1e-3).cuda()
+    from simq._lib import MODE_TRAIN
+    policy._forward_raw(x, MODE_TRAIN)
+    g1 = policy._backward_raw(dq1, B).clone()
+    g2 = policy._backward_raw(dq2, B).clone()
+    g12 = policy._backward_raw(2.0 * dq1 - 3.0 * dq2, B).clone()
+    assert relnorm(g12, 2.0 * g1 - 3.0 * g2) < 1e-4
+
+
+def test_b32_eval_forward_reproducible_and_argmax(simq_mod):
+    cin, cout, B = 4, 2, 32
+    policy, _ = make_pair(simq_mod, cin, cout, 21)
+    policy.eval()
+    x = torch.from_numpy(synth.make_states(B, cin, 8)).cuda()
+    with torch.no_grad():
+        q1 = policy.forward_nhwc(x)
+        q2 = policy.forward_nhwc(x)
+        q_first = policy.forward_nhwc(x[:1].contiguous())
+    assert torch.equal(q1, q2)                                            # no atomics on the forward path
+    assert relnorm(q_first[0], q1[0]) < 1e-5                              # eval BN: samples are independent
+    assert policy.argmax(torch.zeros_like(q1[0])) == 0                    # ties -> first index (policies.py:64)
+    flat = q1[3].reshape(-1)
+    assert policy.argmax(q1[3]) == int(flat.argmax())
+
+
+def test_b128_bf16_config_runs_and_is_consistent(simq_mod):
+    """configs[2]: lifting_4-small_divider (Cin=5), batch 128, bf16 operands."""
+    cin, cout, B = 5, 2, 128
+    trs = synth.make_transitions(B, cin, cout, 31, terminal_frac=0.1)
+    pol_a, info_a = run_step(simq_mod, cin, cout, trs, B, 13, precision='bf16')
+    pol_f, info_f = run_step(simq_mod, cin, cout, trs, B, 13, precision='fp32')
+    assert np.isfinite(info_a['loss']) and abs(info_a['loss'] - info_f['loss']) <= 5e-2 * abs(info_f['loss'])
+    assert abs(info_a['td_error'] - info_f['td_error']) <= 5e-2 * abs(info_f['td_error'])
+    # bf16 Q-values of the taken actions vs the exact-fp32 path on the same batch
+    assert float((pol_a._last['q_sa'] - pol_f._last['q_sa']).abs().max() / pol_f._last['q_sa'].abs().max()) < 5e-2
+    sd = pol_a.state_dict()
+    assert all(int(sd[k]) == 2 for k in sd if k.endswith('num_batches_tracked'))
+    assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)
+
+
+def test_two_heterogeneous_heads_like_train_py_255(simq_mod):
+    """configs[3]: lifting_2_pushing_2 -- one net per robot group (Cout 2 and 1), trained in turn (train.py:255-257)."""
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 2}], num_input_channels=5,
+                                final_exploration=0.01, checkpoint_path=None, batch_size=16, use_double_dqn=True,
+                                grad_norm_clipping=100, discount_factors=[0.85, 0.85])
+    policy = simq_mod.DQNPolicy(cfg, train=True, random_seed=1)
+    targets = policy.build_policy_nets()
+    for i in range(policy.num_robot_groups):
+        targets[i].load_state_dict(policy.policy_nets[i].state_dict())      # train.py:213-216
+        targets[i].eval()
+        policy.policy_nets[i].train()
+    opts = [torch.optim.SGD(n.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4) for n in policy.policy_nets]
+    buffers = [simq_mod.ReplayBuffer(64), simq_mod.DeviceReplayBuffer(64, 5)]   # host ring and HBM ring side by side
+    for i, cout in enumerate((2, 1)):
+        for t in synth.make_transitions(40, 5, cout, 50 + i, terminal_frac=0.1):
+            buffers[i].push(*t)
+    random.seed(7)
+    infos = []
+    for step in range(2):
+        for i in range(policy.num_robot_groups):                                # train.py:255-257
+            batch = buffers[i].sample(cfg.batch_size)
+            infos.append(simq_mod.train(cfg, policy.policy_nets[i], targets[i], opts[i], batch, policy.apply_transform,
+                                        cfg.discount_factors[i]))
+    assert len(infos) == 4 and all(np.isfinite(v['loss']) and np.isfinite(v['td_error']) for v in infos)
+    assert [n.num_output_channels for n in policy.policy_nets] == [2, 1]
+    # each group's action space matches its head (envs.py:374-376)
+    s = synth.make_states(2, 5, 77)
+    acts = policy.step([[s[0], None], [None, s[1]]], exploration_eps=0.0)
+    assert 0 <= acts[0][0] < 2 * 96 * 96 and 0 <= acts[1][1] < 96 * 96 and acts[0][1] is None and acts[1][0] is None
+
+
+def test_ragged_and_degenerate_batches(simq_mod):
+    """B=1, all-but-one terminal, and the reference's own failure mode (no non-final next state, train.py:112)."""
+    from simq.learner import Transition, train_step
+    cin, cout = 4, 2
+    policy, target = make_pair(simq_mod, cin, cout, 3)
+    trs = synth.make_transitions(3, cin, cout, 23, terminal_frac=0.0)
+    one = Transition(*zip(*trs[:1]))
+    info = train_step(policy, target, one, cases.GAMMA, 1, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP)
+    assert np.isfinite(info['loss'])
+    mostly_terminal = [(s, a, r, None) for (s, a, r, _) in trs[:2]] + [trs[2]]
+    info = train_step(policy, target, Transition(*zip(*mostly_terminal)), cases.GAMMA, 3, cases.LR, cases.MOMENTUM,
+                      cases.WEIGHT_DECAY, cases.CLIP)
+    assert np.isfinite(info['loss'])
+    all_terminal = [(s, a, r, None) for (s, a, r, _) in trs]
+    with pytest.raises(simq_mod._lib.SimqError if hasattr(simq_mod, '_lib') else Exception):
+        train_step(policy, target, Transition(*zip(*all_terminal)), cases.GAMMA, 3, cases.LR, cases.MOMENTUM,
+                   cases.WEIGHT_DECAY, cases.CLIP)
+    with pytest.raises(Exception):
+        policy.forward_nhwc(torch.zeros(1, 96, 96, cin + 1, device='cuda'))      # wrong channel count
