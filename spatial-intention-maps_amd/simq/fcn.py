@@ -86,6 +86,7 @@ class FCN(torch.nn.Module):
         self._train_generation = 0
         self.wcache = torch.empty(max(int(lib.c.simq_wcache_bytes(self.plan.handle)), 16), dtype=torch.uint8, device=self.device_)
         self.weights_dirty = True      # set whenever flat_params changes; the next forward refreshes the weight cache
+        self._weights_stamp = 0
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / (de)serialisation
@@ -213,6 +214,7 @@ class FCN(torch.nn.Module):
         if self.weights_dirty:
             lib.call('simq_weights_prepare', self.plan.handle, ptr(self.flat_params), ptr(self.wcache), stream_ptr(self.device_))
             self.weights_dirty = False
+            self._weights_stamp += 1
 
     def _forward_raw(self, x_nhwc, mode):
         """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96]."""
@@ -293,3 +295,17 @@ class FCN(torch.nn.Module):
         ws = self._ws[slot]
         hw = int(round((n.value // (batch * ch.value)) ** 0.5))
         return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(batch, hw, hw, ch.value)
+
+    # ------------------------------------------------------------------ batch-1 inference (DQNPolicy.step hot loop)
+    def infer_argmax(self, state_hwc, need_q=False):
+        """Eval-mode forward of ONE HWC state + flat first-index argmax (policies.py:59-64: apply_transform -> net ->
+        view(1,-1).max(1)[1].item()).  Only the 8-byte index comes back; the Q-map is copied to the host only when
+        `need_q` (the reference's debug output, policies.py:66).  Measured alternatives that were SLOWER on this
+        runtime and are therefore not used: a hipGraph capture of the ~75 nodes (5.7 ms per replay vs 0.6 ms of eager
+        launches) and staging the state through a pinned host buffer (8 ms; CPU writes to pinned memory are slow)."""
+        if self.training:
+            raise SimqError('infer_argmax: the net must be in eval mode (policies.py:56)')
+        x = torch.from_numpy(state_hwc).unsqueeze(0).to(self.device_)
+        q = self.forward_nhwc(x)
+        a = self.argmax(q[0])
+        return (a, q[0].cpu().numpy()) if need_q else (a, None)

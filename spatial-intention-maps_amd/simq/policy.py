@@ -68,15 +68,15 @@ class DQNPolicy:
                 net.eval()
                 for j, s in enumerate(g):
                     if s is not None:
-                        # the reference goes HWC -> CHW -> device; the HIP net consumes HWC directly
-                        x = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).unsqueeze(0).to(self.device)
-                        o = net.forward_nhwc(x).squeeze(0)
+                        # the reference goes HWC -> CHW -> device -> net -> argmax -> .cpu(); here one captured hipGraph
+                        # does forward + argmax on the HWC state, and the Q-map only travels back when asked for
+                        greedy, q = net.infer_argmax(np.ascontiguousarray(s, dtype=np.float32), need_q=debug)
                         if random.random() < exploration_eps:
                             a = random.randrange(arch.get_action_space(robot_type))
                         else:
-                            a = net.argmax(o)
+                            a = greedy
                         action[i][j] = a
-                        output[i][j] = o.cpu().numpy()
+                        output[i][j] = q
                 if self.train:
                     net.train()
         if debug:
