@@ -27,9 +27,6 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BKB = 32;            // K-step in elements
-constexpr int ROWB = 64;           // bytes per LDS row (32 bf16)
-
 struct IgemmBfArgs {
     const uint16_t* x[2];          // activation planes [pixels][Cin] (hi, lo)
     const uint16_t* w[2];          // weight planes [Cout][R*S*Cin]   (hi, lo)
@@ -40,12 +37,23 @@ struct IgemmBfArgs {
     unsigned x_bytes, w_bytes;     // plane sizes for the bounds-checked buffer loads
 };
 
-__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // f = {0,2,3,1}
+// XOR swizzle of the 16-B slots of an LDS row so that every 16-lane group of a ds_read_b128 fragment load
+// (rows r..r+15 at one k-slot, two consecutive k-slots per group) hits 16 distinct slots of the 256-B bank row:
+//   64-B rows (4 slots):  slot ^ {0,2,3,1}[(row >> 2) & 3]        128-B rows (8 slots):  slot ^ ((row >> 1) & 7)
+template <int ROWB>
+__device__ __forceinline__ int swz(int row) {
+    if constexpr (ROWB == 64) return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;
+    else return (row >> 1) & 7;
+}
 
-template <int BM, int BN, int NP>
+// BKB = K elements per LDS stage (32 or 64); SUB = BKB / 32 MFMA k-steps per stage.
+template <int BM, int BN, int NP, int BKB>
 __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
+    static_assert(BKB == 32 || BKB == 64, "K-step");
     constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int ROWB = BKB * 2;                       // bytes per LDS row
+    constexpr int SLOTS = ROWB / 16, SUB = BKB / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int PLANE_BYTES = A_BYTES + B_BYTES;
     constexpr int STAGE_BYTES = NP * PLANE_BYTES;
@@ -80,10 +88,11 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BKB;
-    constexpr int A_PASSES = (BM + 63) / 64, B_PASSES = (BN + 63) / 64;   // 4 lanes x 16 B per row, 64 rows per pass
+    constexpr int RPP = 256 / SLOTS;                                        // rows per loader pass
+    constexpr int A_PASSES = (BM + RPP - 1) / RPP, B_PASSES = (BN + RPP - 1) / RPP;
     uint4 va[2][NP][A_PASSES], vb[2][NP][B_PASSES];
-    const int lrow = tid >> 2, kq = tid & 3;
-    int tap = 0, c0 = 0, ky = 0, kx = 0;    // K order: 32-channel chunk outer, filter tap inner (x lines re-used across taps)
+    const int lrow = tid / SLOTS, kq = tid % SLOTS;
+    int tap = 0, c0 = 0, ky = 0, kx = 0;    // K order: BKB-channel chunk outer, filter tap inner (x lines re-used across taps)
 
     // branch-free loads: out-of-image taps / ragged rows / tiles past the end use byte offset 0xFFFFFFFF, which the
     // buffer bounds check zero-fills; rows of this thread live in registers
@@ -96,8 +105,8 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
     int rpix[A_PASSES], riy[A_PASSES], rix[A_PASSES];
 #pragma unroll
     for (int ps = 0; ps < A_PASSES; ++ps) {
-        const int r = lrow + 64 * ps;
-        int4 ri = (BM % 64 == 0 || r < BM) ? rowinfo[r] : make_int4(0, 0, 0, 0);
+        const int r = lrow + RPP * ps;
+        int4 ri = (BM % RPP == 0 || r < BM) ? rowinfo[r] : make_int4(0, 0, 0, 0);
         rpix[ps] = ri.x;
         riy[ps] = ri.w ? ri.y : -(1 << 20);
         rix[ps] = ri.z;
@@ -115,8 +124,8 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
-            const int n = lrow + 64 * ps;
-            const unsigned voff = (live && (BN % 64 == 0 || n < BN)) ? (unsigned)((n0 + n) * p.K + tap * p.Cin + c0 + kq * 8) * 2u : 0xFFFFFFFFu;
+            const int n = lrow + RPP * ps;
+            const unsigned voff = (live && (BN % RPP == 0 || n < BN)) ? (unsigned)((n0 + n) * p.K + tap * p.Cin + c0 + kq * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 vb[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr[pl], voff, 0, 0));
@@ -129,15 +138,15 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
             for (int ps = 0; ps < A_PASSES; ++ps) {
-                const int r = lrow + 64 * ps;
-                if (BM % 64 == 0 || r < BM)
-                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + r * ROWB + ((kq ^ swz(r)) << 4)) = va[SET][pl][ps];
+                const int r = lrow + RPP * ps;
+                if (BM % RPP == 0 || r < BM)
+                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + r * ROWB + ((kq ^ swz<ROWB>(r)) << 4)) = va[SET][pl][ps];
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES; ++ps) {
-                const int n = lrow + 64 * ps;
-                if (BN % 64 == 0 || n < BN)
-                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + A_BYTES + n * ROWB + ((kq ^ swz(n)) << 4)) = vb[SET][pl][ps];
+                const int n = lrow + RPP * ps;
+                if (BN % RPP == 0 || n < BN)
+                    *reinterpret_cast<uint4*>(st + pl * PLANE_BYTES + A_BYTES + n * ROWB + ((kq ^ swz<ROWB>(n)) << 4)) = vb[SET][pl][ps];
             }
         }
     };
@@ -150,67 +159,103 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
 
     // v_mfma_f32_16x16x32_bf16 operands: lane l holds A[i = l & 15][k = 8*(l>>4) .. +7], B[k = 8*(l>>4) .. +7][j = l & 15]
     const int fi = lane & 15, fq = lane >> 4;
-    auto compute = [&](int buf) {
+    bf16x8 af[2][NP][TM], bf[2][NP][TN];
+    auto read_frags = [&](auto set_c, int buf, int sub) {          // fragments of MFMA k-step `sub` of LDS stage `buf`
+        constexpr int SET = decltype(set_c)::value;
         const char* st = smem + buf * STAGE_BYTES;
-        bf16x8 af[NP][TM], bf[NP][TN];
+        const int slot = sub * 4 + fq;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = wm * (BM / 2) + i * 16 + fi;
-                af[pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + r * ROWB + ((fq ^ swz(r)) << 4));
+                af[SET][pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + r * ROWB + ((slot ^ swz<ROWB>(r)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn * (BN / 2) + j * 16 + fi;
-                bf[pl][j] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + A_BYTES + r * ROWB + ((fq ^ swz(r)) << 4));
+                bf[SET][pl][j] = *reinterpret_cast<const bf16x8*>(st + pl * PLANE_BYTES + A_BYTES + r * ROWB + ((slot ^ swz<ROWB>(r)) << 4));
             }
         }
+    };
+    auto mfma_step = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         if constexpr (NP == 2) {   // small cross terms first, then the leading term
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SET][1][i], bf[SET][0][j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SET][0][i], bf[SET][1][j], acc[i][j], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[SET][0][i], bf[SET][0][j], acc[i][j], 0, 0, 0);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    // loads / stores are unconditional (zeros past the end) so the compiler can wait for the OLDER register set only
-    load_tile(S0{}, true);
-    store_tile(S0{}, 0);
-    advance(); load_tile(S1{}, nk > 1);
+    // Software pipeline over MFMA k-steps (SUB per LDS stage): while k-step t runs from fragment set t & 1 the wave
+    // reads the fragments of k-step t+1 (crossing into the next stage after the stage barrier), has tile k+3 in flight
+    // from HBM and stores tile k+2 into the stage that was just retired.  Loads / stores are unconditional (zeros past
+    // the end) so the compiler waits only for the OLDER global register set (counted vmcnt).
+    // One stage: store tile (held in global set GS) for stage k+1 early, run SUB-1 inner k-steps, barrier, last k-step.
+    auto stage = [&](auto fs_c, auto gs_c, int buf, bool live_next) {
+        constexpr int FS = decltype(fs_c)::value;             // fragment set holding k-step 0 of this stage
+        // tile k+1 (global set GS) -> other stage; then refill GS with tile k+3
+        store_tile(gs_c, buf ^ 1);
+        advance();
+        load_tile(gs_c, live_next);
+        if constexpr (SUB == 2) {
+            read_frags(std::integral_constant<int, FS ^ 1>{}, buf, 1);
+            mfma_step(std::integral_constant<int, FS>{});
+            __syncthreads();                                  // tile k+1 visible; every wave is done reading stage `buf`
+            read_frags(std::integral_constant<int, FS>{}, buf ^ 1, 0);
+            mfma_step(std::integral_constant<int, FS ^ 1>{});
+        } else {
+            __syncthreads();
+            read_frags(std::integral_constant<int, FS ^ 1>{}, buf ^ 1, 0);
+            mfma_step(std::integral_constant<int, FS>{});
+        }
+    };
+
+    load_tile(S0{}, true);                 // tile 0
+    advance();
+    load_tile(S1{}, nk > 1);               // tile 1
+    store_tile(S0{}, 0);                   // tile 0 -> stage 0
+    advance();
+    load_tile(S0{}, nk > 2);               // tile 2
     __syncthreads();
+    read_frags(S0{}, 0, 0);                // fragments of (stage 0, k-step 0)
+    // global sets: S1 holds tile 1, S0 holds tile 2.  stage(k) stores tile k+1 and reloads that set with tile k+3.
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        advance(); load_tile(S0{}, kt + 2 < nk);
-        compute(0);
-        store_tile(S1{}, 1);
-        __syncthreads();
-        advance(); load_tile(S1{}, kt + 3 < nk);
-        compute(1);
-        store_tile(S0{}, 0);
-        __syncthreads();
+    if constexpr (SUB == 2) {
+        // fragment set parity returns to 0 after every stage (2 k-steps per stage)
+        for (; kt + 1 < nk; kt += 2) {
+            stage(S0{}, S1{}, 0, kt + 3 < nk);
+            stage(S0{}, S0{}, 1, kt + 4 < nk);
+        }
+        if (kt < nk) stage(S0{}, S1{}, 0, false);
+    } else {
+        for (; kt + 1 < nk; kt += 2) {
+            stage(S0{}, S1{}, 0, kt + 3 < nk);
+            stage(S1{}, S0{}, 1, kt + 4 < nk);
+        }
+        if (kt < nk) stage(S0{}, S1{}, 0, false);
     }
-    if (kt < nk) compute(0);
     __syncthreads();
 
     // ---- epilogue (igemm_epilogue.h); the stage buffers are idle now and serve as its reduction scratch ----
     igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 
-template <int BM, int BN, int NP>
+template <int BM, int BN, int NP, int BKB>
 int run(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
@@ -218,7 +263,7 @@ int run(const IgemmBfArgs& a, hipStream_t stream) {
     prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NP>), dim3((unsigned)(tilesM * p.tilesN)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NP, BKB>), dim3((unsigned)(tilesM * p.tilesN)), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -230,9 +275,9 @@ constexpr TileCfg kMenu[] = {
     {128, 32, 0.75f},  {96, 32, 0.72f},  {64, 32, 0.65f},  {32, 64, 0.65f},  {32, 32, 0.50f},
 };
 
-template <int NP>
+template <int NP, int BKB>
 int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
-#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, NP>(a, stream)
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, NP, BKB>(a, stream)
     SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
     SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
 #undef SIMQ_TILE
@@ -256,7 +301,7 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm_bf16: tensor exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_igemm_bf16: nplanes must be 1 or 2");
-    SIMQ_REQUIRE(g.Cout % 32 == 0 && g.Cin % BKB == 0, "conv_igemm_bf16: Cin=%d Cout=%d must be multiples of 32", g.Cin, g.Cout);
+    SIMQ_REQUIRE(g.Cout % 32 == 0 && g.Cin % 32 == 0, "conv_igemm_bf16: Cin=%d Cout=%d must be multiples of 32", g.Cin, g.Cout);
     int bm = 0, bn = 0;
     int fbm = 0, fbn = 0;
     if (tune_forced_tile(&fbm, &fbn) && g.Cout % fbn == 0) { bm = fbm; bn = fbn; }
@@ -271,7 +316,9 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
             if (cost < best) { best = cost; bm = t.bm; bn = t.bn; }
         }
     }
-    return nplanes == 2 ? dispatch<2>(bm, bn, a, stream) : dispatch<1>(bm, bn, a, stream);
+    // plain bf16: 64-deep K stages (two MFMA k-steps per barrier) whenever the channel count allows; split-bf16 keeps 32
+    if (nplanes == 2) return dispatch<2, 32>(bm, bn, a, stream);
+    return (g.Cin % 64 == 0) ? dispatch<1, 64>(bm, bn, a, stream) : dispatch<1, 32>(bm, bn, a, stream);
 }
 
 }  // namespace simq
