@@ -138,10 +138,12 @@ def main():
 
     global CIN, BATCH_PER_GPU
     CIN, BATCH_PER_GPU = args.cin, args.batch
+    # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
+    # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
+    # stay O(1) so that many steps of synthetic training remain finite
+    torch.manual_seed(20260928)
     policy = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
     target = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
-    sd = {k: torch.from_numpy(v) if v.shape != () else torch.tensor(int(v)) for k, v in synth.make_state_dict(CIN, COUT, 1).items()}
-    policy.load_state_dict(sd)          # identical weights on every rank (DataParallel replicas)
     target.copy_state_from(policy)
     policy.train()
     target.eval()
@@ -180,6 +182,34 @@ def main():
     if not np.isfinite(info['loss']):
         sys.exit('bench: non-finite loss %r' % (info,))
     value = gB * args.steps / dt
+
+    # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
+    # backward only -- no next-state forwards, clip or SGD.  Reported beside the full-step `value`, never instead of it.
+    from simq._lib import MODE_TRAIN, ptr, stream_ptr
+    idx = ring.sample_indices(gB)
+    fb = ring.gather(sdist.shard_indices(idx, world, rank))
+    nq = COUT * 96 * 96
+    fb_out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
+    fb_o4 = torch.empty(4, dtype=torch.float32, device=dev)
+    fb_nsv = torch.zeros(B, dtype=torch.float32, device=dev)
+
+    def fwd_bwd():
+        q = policy._forward_raw(fb.state, MODE_TRAIN)
+        dq = torch.empty_like(q)
+        lib.call('simq_td_huber', ptr(q), B, nq, ptr(fb.action), ptr(fb.reward), ptr(fb_nsv), GAMMA, 1.0 / gB, ptr(fb_out[0]),
+                 ptr(fb_out[1]), ptr(fb_out[2]), ptr(fb_o4), ptr(dq), stream_ptr(dev))
+        policy._backward_raw(dq, B)
+
+    for _ in range(2):
+        fwd_bwd()
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd_bwd()
+    barrier()
+    dt_m1 = time.perf_counter() - t2
+    if pg is not None:
+        dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
 
     roof = None
     if not args.no_roofline:
@@ -231,7 +261,11 @@ def main():
             'config': {'workload': '%s (Cin=%d, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
                                    'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
                        'global_batch': gB, 'parallelism': 'dp%d' % world,
-                       'flop_per_transition': FLOP_M2, 'last_loss': info['loss'], 'last_td_error': info['td_error']},
+                       'flop_per_transition': FLOP_M2,
+                       'fwd_bwd_only': {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
+                                        'ms_per_step': round(dt_m1 / args.steps * 1e3, 3), 'flop_per_transition': FLOP_M1,
+                                        'note': 'policy forward + gather + Huber + backward only (M1 of SURVEY 8d); no '
+                                                'gradient all-reduce, clip or SGD'}, 'last_loss': info['loss'], 'last_td_error': info['td_error']},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
