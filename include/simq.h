@@ -146,6 +146,16 @@ int simq_clip_sgd_step(float* d_params, float* d_grads, float* d_momentum, int64
 int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* d_index, int count,
                        float* d_out, void* stream);
 
+/* ---- intention-prediction head (train_intention, train.py:143-158; step_intention, policies.py:97-117) ----------
+ * simq_bce_with_logits: nn.BCEWithLogitsLoss() ('mean') over n logits vs targets; *d_loss_sum (double) receives the SUM
+ *   (host divides by n), d_dlogits (may be NULL) the gradient (sigmoid(x) - t) / n.
+ * simq_split_last_channel: x [pixels][C] -> s[:, :, :-1] as [pixels][C-1] and s[:, :, -1] as [pixels].
+ * simq_sigmoid_concat: out [pixels][Cs+1] = concat(state [pixels][Cs], sigmoid(logit [pixels])); d_prob (may be NULL)
+ *   also receives the sigmoid map.                                                                               */
+int simq_bce_with_logits(const float* d_logits, const float* d_target, int64_t n, float* d_dlogits, double* d_loss_sum, void* stream);
+int simq_split_last_channel(const float* d_x, float* d_head, float* d_last, int64_t pixels, int channels, void* stream);
+int simq_sigmoid_concat(const float* d_state, const float* d_logit, float* d_out, float* d_prob, int64_t pixels, int channels, void* stream);
+
 /* layout helpers for callers that hold NCHW tensors (apply_transform, policies.py:44-45) */
 int simq_nchw_to_nhwc(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);
 int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);

@@ -25,6 +25,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(_HERE), 'tests', 'golden')
 # (name, cin, cout, batch, weight seed, data seed)
 FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), ('fwd_c5o1', 5, 1, 2, 13, 23)]
 TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
+INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 
 LR, MOMENTUM, WEIGHT_DECAY, CLIP, GAMMA = 0.01, 0.9, 1e-4, 100, 0.75   # base config yml / train.py:186

@@ -144,6 +144,58 @@ def gen_train():
               % out['ref_fp32_grad_relerr'])
 
 
+def gen_intention():
+    """train.train_intention (train.py:143-158) run twice on the reference vs the oracle restatement, bit-exact."""
+    for name, cin_full, B, wseed, dseed in cases.INTENTION_CASES:
+        cin = cin_full - 1
+        batch = cases.make_batch(cin_full, 1, B, dseed)
+        spec = fcn.state_spec(cin, 1)
+        net = ref_net(cin, 1, wseed)
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)   # train.py:190
+        info_ref = [ref_train.train_intention(net, opt, batch, learner.apply_transform) for _ in range(2)]
+        st = cases.oracle_state(cin, 1, wseed)
+        mom = [None] * len(learner.grad_keys(spec))
+        extras = [{}, {}]
+        info_or = [learner.train_intention_step(st, spec, mom, batch, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                                extras=extras[i]) for i in range(2)]
+        assert info_or == info_ref, (name, info_or, info_ref)
+        for k, v in net.state_dict().items():
+            assert_same(st[k], v, name + ' post-step ' + k)
+        st64 = cases.oracle_state(cin, 1, wseed, torch.float64)
+        ex64 = {}
+        info64 = learner.train_intention_step(st64, spec, [None] * len(mom), batch, cases.LR, cases.MOMENTUM,
+                                              cases.WEIGHT_DECAY, dtype=torch.float64, extras=ex64)
+        g32, g64 = cases.grad_summary(extras[0]['grads']), cases.grad_summary(ex64['grads'])
+        num = sum(float((extras[0]['grads'][k].double() - ex64['grads'][k]).pow(2).sum()) for k in g32)
+        den = sum(float(ex64['grads'][k].pow(2).sum()) for k in g32)
+        np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'),
+                 loss_intention=np.array([i['loss_intention'] for i in info_ref]), loss64=np.array(info64['loss_intention']),
+                 output_step1=extras[0]['output'].numpy(), grad_keys=np.array(list(g32.keys())),
+                 grad32=np.stack(list(g32.values())), grad64=np.stack(list(g64.values())),
+                 ref_fp32_grad_relerr=np.array((num / den) ** 0.5),
+                 param_summary_after2=cases.param_summary(st, spec),
+                 bn_buffers_after2=cases.bn_buffer_vector(st).astype(np.float32))
+        print('intention case', name, 'oracle == reference (bit-exact, 2 steps); ref fp32 grad rel err vs fp64 = %.3g'
+              % ((num / den) ** 0.5))
+
+
+def gen_intention_step():
+    """DQNIntentionPolicy.step fixture from the oracle restatement (policies.py is not importable here, see gen_step)."""
+    cin = 5
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 1}, {'pushing_robot': 1}], num_input_channels=cin,
+                                final_exploration=0.01)
+    seeds = iter([71, 72, 73, 74])
+    pol = opolicy.DQNIntentionPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=9)
+    s = synth.make_states(2, cin - 1, 81)
+    a, info = pol.step([[s[0]], [s[1]]], exploration_eps=0.0, debug=True)
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'intention_step.npz'), actions=np.array([a[0][0], a[1][0]], dtype=np.int64),
+             output_intention=np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]),
+             state_intention=np.stack([info['state_intention'][0][0], info['state_intention'][1][0]]),
+             q0=info['output'][0][0], q1=info['output'][1][0])
+    print('intention policy.step case saved (oracle restatement)')
+
+
 def gen_sampler():
     out = {}
     for n, B, seed in cases.SAMPLER_CASES:
@@ -191,7 +243,7 @@ def gen_step():
 if __name__ == '__main__':
     torch.manual_seed(0)
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
-    gen_sampler()
-    gen_forward()
-    gen_step()
-    gen_train()
+    gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
+            'intention': gen_intention, 'intention_step': gen_intention_step}
+    for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
+        gens[which]()

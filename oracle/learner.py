@@ -151,6 +151,36 @@ def train_step(cfg, state, target_state, spec, momentum_bufs, batch, discount_fa
     return {'td_error': td_error.mean().item(), 'loss': loss.item()}              # train.py:137-139
 
 
+def train_intention_step(state, spec, momentum_bufs, batch, lr, momentum, weight_decay, dtype=torch.float32,
+                         extras=None):
+    """One reference ``train_intention()`` call (train.py:143-158) on functional state.
+
+    ``state``: intention-net dict, FCN(num_input_channels - 1, 1) (policies.py:91-95); the LAST channel of every
+    replay state is the ground-truth intention map (train.py:144).  No gradient clipping on this path.
+    Returns {'loss_intention': float}.
+    """
+    state_batch = torch.cat([apply_transform(s[:, :, :-1]) for s in batch.state]).to(dtype)      # train.py:145
+    target_batch = torch.cat([apply_transform(s[:, :, -1:]) for s in batch.state]).to(dtype)     # train.py:146
+    gkeys = grad_keys(spec)
+    params = [state[k] for k in gkeys]
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = None
+    try:
+        output = fcn.fcn_forward(state, state_batch, True)                                        # train.py:148
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(output, target_batch)         # train.py:149-150
+        grads = list(torch.autograd.grad(loss, params))                                           # train.py:151-152
+    finally:
+        for p in params:
+            p.requires_grad_(False)
+    if extras is not None:
+        extras['grads'] = OrderedDict((k, g.clone()) for k, g in zip(gkeys, grads))
+        extras['output'] = output.detach()
+    with torch.no_grad():
+        sgd_step(params, grads, momentum_bufs, lr, momentum, weight_decay)                        # train.py:153
+    return {'loss_intention': loss.item()}                                                        # train.py:155-156
+
+
 def forward_backward(state, spec, state_batch, action_batch, y, dtype=torch.float32):
     """M1 of SURVEY 8d: policy forward (train-mode BN) + gather + Huber + backward,
     no target computation / optimiser.  Used for the cpu_baseline timing and M1 parity."""

@@ -73,3 +73,47 @@ class DQNPolicy:
         if debug:
             return action, {'output': output}
         return action
+
+
+class DQNIntentionPolicy(DQNPolicy):
+    """policies.py:76-146 over functional oracle states (intention nets: FCN(num_input_channels - 1, 1))."""
+
+    def __init__(self, cfg, make_state, train=False, random_seed=None):
+        super().__init__(cfg, make_state, train=train, random_seed=random_seed)
+        self.intention_nets = self.build_intention_nets()                                 # policies.py:79
+
+    def build_intention_nets(self):                                                       # policies.py:89-95
+        return [self._make_state(self.cfg.num_input_channels - 1, 1) for _ in range(self.num_robot_groups)]
+
+    def step_intention(self, state, debug=False):                                         # policies.py:97-117
+        import numpy as np
+        state_intention = [[None for _ in g] for g in state]
+        output_intention = [[None for _ in g] for g in state]
+        with torch.no_grad():
+            for i, g in enumerate(state):
+                for j, s in enumerate(g):
+                    if s is not None:
+                        s_copy = s.copy()
+                        s = self.apply_transform(s)
+                        o = torch.sigmoid(fcn.fcn_forward(self.intention_nets[i], s, False)).squeeze(0).squeeze(0).numpy()
+                        state_intention[i][j] = np.concatenate((s_copy, np.expand_dims(o, 2)), axis=2)
+                        output_intention[i][j] = o
+        if debug:
+            return state_intention, {'output_intention': output_intention}
+        return state_intention
+
+    def step(self, state, exploration_eps=None, debug=False, use_ground_truth_intention=False):   # policies.py:119-146
+        if self.train and use_ground_truth_intention:
+            return super().step(state, exploration_eps=exploration_eps, debug=debug)
+        if self.train:
+            state = [[None if s is None else s[:, :, :-1] for s in g] for g in state]     # drop the ground-truth map
+        state = self.step_intention(state, debug=debug)
+        if debug:
+            state, info_intention = state
+        action = super().step(state, exploration_eps=exploration_eps, debug=debug)
+        if debug:
+            action, info = action
+            info['state_intention'] = state
+            info['output_intention'] = info_intention['output_intention']
+            return action, info
+        return action

@@ -137,6 +137,9 @@ int launch_td_huber(const float* q, int batch, int n, const int64_t* action, con
                     float* out4, float* dq, hipStream_t stream);
 int launch_clip_sgd(float* p, float* g, float* m, int64_t count, float max_norm, float lr, float momentum,
                     float wd, int first_step, void* scratch, float* total_norm, hipStream_t stream);
+int launch_bce_logits(const float* x, const float* t, int64_t n, float* dx, double* loss_sum, hipStream_t stream);
+int launch_split_last_channel(const float* x, float* head, float* last, int64_t pixels, int C, hipStream_t stream);
+int launch_sigmoid_concat(const float* state, const float* logit, float* out, float* prob, int64_t pixels, int Cs, hipStream_t stream);
 int launch_replay_gather(const float* ring, int64_t item_floats, const int64_t* index, int count, float* out,
                          hipStream_t stream);
 

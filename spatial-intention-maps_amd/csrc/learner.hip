@@ -157,7 +157,76 @@ __global__ void replay_gather_kernel(const float* __restrict__ ring, size_t item
         dst[i] = src[i];
 }
 
+// ---- intention-prediction head (train.py:143-158, policies.py:97-117) ---------------------------------------------
+// BCEWithLogitsLoss (mean) and its gradient:  l = max(x,0) - x*t + log(1 + exp(-|x|)) ;  dl/dx = (sigmoid(x) - t) / N
+__global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ t, size_t n,
+                                                         float inv_n, float* __restrict__ dx, double* loss_sum) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float xv = x[i], tv = t[i];
+        const float e = __expf(-fabsf(xv));
+        acc += (double)(fmaxf(xv, 0.f) - xv * tv + log1pf(e));
+        const float sig = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        if (dx) dx[i] = (sig - tv) * inv_n;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, sm[0]);
+}
+
+// x [pixels][C] -> head [pixels][C-1], last [pixels]   (s[:, :, :-1] and s[:, :, -1:], train.py:145-146)
+__global__ void split_last_channel_kernel(const float* __restrict__ x, float* __restrict__ head, float* __restrict__ last,
+                                          size_t pixels, int C) {
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        for (int c = 0; c < C - 1; ++c) head[p * (C - 1) + c] = x[p * C + c];
+        last[p] = x[p * C + C - 1];
+    }
+}
+
+// out [pixels][Cs+1] = concat(state [pixels][Cs], sigmoid(logit [pixels]))   (policies.py:107-108)
+__global__ void sigmoid_concat_kernel(const float* __restrict__ state, const float* __restrict__ logit, float* __restrict__ out,
+                                      float* __restrict__ prob, size_t pixels, int Cs) {
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        for (int c = 0; c < Cs; ++c) out[p * (Cs + 1) + c] = state[p * Cs + c];
+        const float xv = logit[p];
+        const float e = __expf(-fabsf(xv));
+        const float sig = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        out[p * (Cs + 1) + Cs] = sig;
+        if (prob) prob[p] = sig;
+    }
+}
+
 }  // namespace
+
+int launch_bce_logits(const float* x, const float* t, int64_t n, float* dx, double* loss_sum, hipStream_t stream) {
+    SIMQ_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), stream));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(blocks), dim3(256), 0, stream, x, t, (size_t)n, (float)(1.0 / (double)n), dx, loss_sum);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_split_last_channel(const float* x, float* head, float* last, int64_t pixels, int C, hipStream_t stream) {
+    int blocks = (int)((pixels + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_last_channel_kernel, dim3(blocks), dim3(256), 0, stream, x, head, last, (size_t)pixels, C);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_sigmoid_concat(const float* state, const float* logit, float* out, float* prob, int64_t pixels, int Cs, hipStream_t stream) {
+    int blocks = (int)((pixels + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sigmoid_concat_kernel, dim3(blocks), dim3(256), 0, stream, state, logit, out, prob, (size_t)pixels, Cs);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_q_argmax(const float* q, int rows, int n, int64_t* index, float* maxv, hipStream_t stream) {
     if (rows == 0) return 0;

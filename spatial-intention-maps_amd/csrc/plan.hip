@@ -632,6 +632,21 @@ int simq_clip_sgd_step(float* d_params, float* d_grads, float* d_momentum, int64
                            d_total_norm, static_cast<hipStream_t>(stream));
 }
 
+int simq_bce_with_logits(const float* d_logits, const float* d_target, int64_t n, float* d_dlogits, double* d_loss_sum, void* stream) {
+    SIMQ_REQUIRE(d_logits && d_target && d_loss_sum && n > 0, "bce_with_logits: bad argument");
+    return launch_bce_logits(d_logits, d_target, n, d_dlogits, d_loss_sum, static_cast<hipStream_t>(stream));
+}
+
+int simq_split_last_channel(const float* d_x, float* d_head, float* d_last, int64_t pixels, int channels, void* stream) {
+    SIMQ_REQUIRE(d_x && d_head && d_last && pixels > 0 && channels >= 2, "split_last_channel: bad argument");
+    return launch_split_last_channel(d_x, d_head, d_last, pixels, channels, static_cast<hipStream_t>(stream));
+}
+
+int simq_sigmoid_concat(const float* d_state, const float* d_logit, float* d_out, float* d_prob, int64_t pixels, int channels, void* stream) {
+    SIMQ_REQUIRE(d_state && d_logit && d_out && pixels > 0 && channels >= 1, "sigmoid_concat: bad argument");
+    return launch_sigmoid_concat(d_state, d_logit, d_out, d_prob, pixels, channels, static_cast<hipStream_t>(stream));
+}
+
 int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* d_index, int count, float* d_out, void* stream) {
     return launch_replay_gather(d_ring, item_floats, d_index, count, d_out, static_cast<hipStream_t>(stream));
 }

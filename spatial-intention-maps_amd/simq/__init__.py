@@ -11,12 +11,14 @@ import importlib
 _LAZY = {
     'FCN': ('.fcn', 'FCN'),
     'DQNPolicy': ('.policy', 'DQNPolicy'),
+    'DQNIntentionPolicy': ('.policy', 'DQNIntentionPolicy'),
     'ReplayBuffer': ('.learner', 'ReplayBuffer'),
     'DeviceReplayBuffer': ('.learner', 'DeviceReplayBuffer'),
     'Transition': ('.learner', 'Transition'),
     'train': ('.learner', 'train'),
     'train_step': ('.learner', 'train_step'),
-    'Learner': ('.learner', 'Learner'),
+    'train_intention': ('.learner', 'train_intention'),
+    'train_intention_step': ('.learner', 'train_intention_step'),
     'lib': ('._lib', 'lib'),
 }
 

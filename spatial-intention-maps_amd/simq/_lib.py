@@ -58,6 +58,9 @@ _SIGS = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_clip_sgd_step': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
                                    c_void_p, c_void_p, c_void_p]),
+    'simq_bce_with_logits': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'simq_split_last_channel': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'simq_sigmoid_concat': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'simq_replay_gather': (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     'simq_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'simq_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

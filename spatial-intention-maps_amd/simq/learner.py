@@ -5,6 +5,8 @@ Reference symbols mirrored (same names, argument meaning, return values):
   ReplayBuffer             train.py:28-45   (host python-list ring, global `random` stream)
   train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_factor)
                            train.py:108-141 -> {'td_error': float, 'loss': float}
+  train_intention(intention_net, optimizer, batch, transform_fn)
+                           train.py:143-158 -> {'loss_intention': float}
 Additions for the MI355X path:
   DeviceReplayBuffer       same push/sample/len contract, states live in an HBM ring
                            ([capacity][96][96][C] fp32, the reference's own HWC layout) and
@@ -300,6 +302,72 @@ def train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_
                       cfg.grad_norm_clipping, use_double_dqn=cfg.use_double_dqn, opt_state=st)
     if momentum != 0:   # expose the (aliased) momentum buffers exactly where torch.optim.SGD keeps them
         params = [getattr(policy_net, pname) for _, pname, _ in policy_net._param_names]
+        for p, v in zip(params, st.views):
+            optimizer.state[p]['momentum_buffer'] = v
+    return info
+
+
+def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state=None, process_group=None,
+                         global_batch=None, sync=True):
+    """One intention-map supervision step (train.py:143-158) on the device: split the ground-truth map (last state
+    channel) off the replay states, train-mode forward of FCN(C-1, 1), BCE-with-logits + its gradient in one kernel,
+    backward, momentum SGD (no clipping on this path).  Returns {'loss_intention': float} or, with sync=False, the
+    device double holding the summed loss."""
+    if not isinstance(intention_net, FCN):
+        raise SimqError('simq.train_intention needs a simq.FCN network (got %s); there is no torch fallback'
+                        % type(intention_net).__name__)
+    if intention_net.num_output_channels != 1:
+        raise SimqError('train_intention: the intention net has one output channel (policies.py:93)')
+    dev = intention_net.device_
+    if isinstance(batch, DeviceBatch):
+        full = batch.state
+    else:
+        full = torch.from_numpy(np.stack(batch.state)).to(dev, non_blocking=True)
+    B, C = full.shape[0], full.shape[3]
+    if C != intention_net.num_input_channels + 1:
+        raise SimqError('train_intention: states have %d channels, expected %d (+1 ground-truth intention map)'
+                        % (C, intention_net.num_input_channels))
+    gB = B if global_batch is None else int(global_batch)
+    st = stream_ptr(dev)
+    st_opt = opt_state if opt_state is not None else _opt_state(intention_net, None)
+    x = torch.empty((B, W, W, C - 1), dtype=torch.float32, device=dev)
+    target = torch.empty((B, W, W), dtype=torch.float32, device=dev)
+    lib.call('simq_split_last_channel', ptr(full), ptr(x), ptr(target), B * W * W, C, st)          # train.py:145-146
+    logits = intention_net._forward_raw(x, MODE_TRAIN)                                                # train.py:148
+    dlogits = torch.empty_like(logits)
+    loss_sum = torch.empty(1, dtype=torch.float64, device=dev)
+    lib.call('simq_bce_with_logits', ptr(logits), ptr(target), B * W * W, ptr(dlogits), ptr(loss_sum), st)   # :149-150
+    if gB != B:
+        dlogits.mul_(B / gB)
+    if process_group is None:
+        grads = intention_net._backward_raw(dlogits, B)                                               # train.py:151-152
+    else:
+        split = intention_net.grad_bucket_split
+        grads = intention_net._backward_raw(dlogits, B, phase=1)
+        work = sdist.allreduce_async(grads[split:], process_group)
+        intention_net._backward_raw(dlogits, B, phase=2)
+        work2 = sdist.allreduce_async(grads[:split], process_group)
+        work3 = sdist.allreduce_async(loss_sum, process_group)
+        for wk in (work, work2, work3):
+            wk.wait()
+    lib.call('simq_clip_sgd_step', ptr(intention_net.flat_params), ptr(grads), ptr(st_opt.momentum),
+             intention_net.plan.param_count, 0.0, lr, momentum, weight_decay, 0 if st_opt.initialised else 1,
+             ptr(st_opt.scratch), ptr(st_opt.total_norm), st)                                         # train.py:153
+    st_opt.initialised = True
+    intention_net.weights_dirty = True
+    intention_net._last = {'logits': logits, 'target': target}
+    if not sync:
+        return loss_sum
+    return {'loss_intention': float(loss_sum.item()) / (gB * W * W)}                                  # train.py:155-156
+
+
+def train_intention(intention_net, optimizer, batch, transform_fn):
+    """Drop-in for train.train_intention (train.py:143-158); `transform_fn` kept for signature compatibility."""
+    lr, momentum, weight_decay = _hyper(optimizer)
+    st = _opt_state(intention_net, optimizer)
+    info = train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state=st)
+    if momentum != 0:
+        params = [getattr(intention_net, pname) for _, pname, _ in intention_net._param_names]
         for p, v in zip(params, st.views):
             optimizer.state[p]['momentum_buffer'] = v
     return info

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import arch
-from ._lib import SimqError
+from ._lib import SimqError, lib, ptr, stream_ptr
 from .fcn import FCN
 
 
@@ -70,7 +70,8 @@ class DQNPolicy:
                     if s is not None:
                         # the reference goes HWC -> CHW -> device -> net -> argmax -> .cpu(); here one captured hipGraph
                         # does forward + argmax on the HWC state, and the Q-map only travels back when asked for
-                        greedy, q = net.infer_argmax(np.ascontiguousarray(s, dtype=np.float32), need_q=debug)
+                        greedy, q = net.infer_argmax(s if torch.is_tensor(s) else np.ascontiguousarray(s, dtype=np.float32),
+                                                     need_q=debug)
                         if random.random() < exploration_eps:
                             a = random.randrange(arch.get_action_space(robot_type))
                         else:
@@ -81,5 +82,73 @@ class DQNPolicy:
                     net.train()
         if debug:
             info = {'output': output}
+            return action, info
+        return action
+
+
+class DQNIntentionPolicy(DQNPolicy):
+    """Drop-in for policies.DQNIntentionPolicy (policies.py:76-146): one intention net FCN(C-1, 1) per robot group
+    predicts the other robots' intention map, which is appended to the state before the Q-network runs.  The predicted
+    map never leaves HBM between the two nets unless `debug` asks for it."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.intention_nets = self.build_intention_nets()
+        if getattr(self.cfg, 'checkpoint_path', None) is not None:                          # policies.py:80-87
+            for i in range(self.num_robot_groups):
+                self.intention_nets[i].load_state_dict(self.policy_checkpoint['state_dicts_intention'][i])
+                if self.train:
+                    self.intention_nets[i].train()
+                else:
+                    self.intention_nets[i].eval()
+            print("=> loaded intention network '{}'".format(self.cfg.policy_path))
+
+    def build_intention_nets(self):                                                         # policies.py:89-95
+        return [FCN(num_input_channels=self.cfg.num_input_channels - 1, num_output_channels=1, device=self.device,
+                    precision=getattr(self.cfg, 'simq_precision', 'fp32')) for _ in range(self.num_robot_groups)]
+
+    def _predict(self, i, s):
+        """One HWC state [96,96,C-1] -> device tensors (state_with_intention [1,96,96,C], sigmoid map [96,96])."""
+        net = self.intention_nets[i]
+        x = torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).unsqueeze(0).to(self.device)
+        logit = net.forward_nhwc(x)
+        C = x.shape[3]
+        out = torch.empty((1, arch.STATE_WIDTH, arch.STATE_WIDTH, C + 1), dtype=torch.float32, device=self.device)
+        prob = torch.empty((arch.STATE_WIDTH, arch.STATE_WIDTH), dtype=torch.float32, device=self.device)
+        lib.call('simq_sigmoid_concat', ptr(x), ptr(logit), ptr(out), ptr(prob), arch.STATE_WIDTH * arch.STATE_WIDTH, C,
+                 stream_ptr(self.device))
+        return out, prob
+
+    def step_intention(self, state, debug=False, _device=False):                            # policies.py:97-117
+        state_intention = [[None for _ in g] for g in state]
+        output_intention = [[None for _ in g] for g in state]
+        with torch.no_grad():
+            for i, g in enumerate(state):
+                self.intention_nets[i].eval()
+                for j, s in enumerate(g):
+                    if s is not None:
+                        out, prob = self._predict(i, s)
+                        state_intention[i][j] = out if _device else out[0].cpu().numpy()
+                        if debug:
+                            output_intention[i][j] = prob.cpu().numpy()
+                if self.train:
+                    self.intention_nets[i].train()
+        if debug:
+            return state_intention, {'output_intention': output_intention}
+        return state_intention
+
+    def step(self, state, exploration_eps=None, debug=False, use_ground_truth_intention=False):   # policies.py:119-146
+        if self.train and use_ground_truth_intention:
+            return super().step(state, exploration_eps=exploration_eps, debug=debug)
+        if self.train:                                                                      # drop the ground-truth map
+            state = [[None if s is None else s[:, :, :-1] for s in g] for g in state]
+        state = self.step_intention(state, debug=debug, _device=not debug)
+        if debug:
+            state, info_intention = state
+        action = super().step(state, exploration_eps=exploration_eps, debug=debug)
+        if debug:
+            action, info = action
+            info['state_intention'] = state
+            info['output_intention'] = info_intention['output_intention']
             return action, info
         return action

@@ -119,3 +119,46 @@ def test_argmax_first_index_tiebreak():
     q[0, 5] = q[0, 9000] = 1.0
     q[1, 18431] = 2.0
     assert q.max(1)[1].tolist() == [5, 18431, 0]
+
+
+@pytest.mark.parametrize('case', cases.INTENTION_CASES, ids=[c[0] for c in cases.INTENTION_CASES])
+def test_train_intention_golden(case, golden_dir):
+    """train.train_intention (train.py:143-158): fixture written after a bit-exact match with the reference."""
+    name, cin_full, B, wseed, dseed = case
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    batch, spec = cases.make_batch(cin_full, 1, B, dseed), fcn.state_spec(cin_full - 1, 1)
+    st = cases.oracle_state(cin_full - 1, 1, wseed)
+    mom = [None] * len(learner.grad_keys(spec))
+    ex = [{}, {}]
+    info = [learner.train_intention_step(st, spec, mom, batch, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, extras=ex[i])
+            for i in range(2)]
+    assert all(set(i) == {'loss_intention'} for i in info)
+    assert rel([i['loss_intention'] for i in info], g['loss_intention']) < 2e-5
+    assert rel(ex[0]['output'].numpy(), g['output_step1']) < 2e-5
+    assert all(int(st[k]) == 2 for k in st if k.endswith('num_batches_tracked'))      # one train-mode forward per call
+    g32 = cases.grad_summary(ex[0]['grads'])
+    num = sum(((g32[k][1:] - g['grad64'][i][1:]) ** 2).sum() for i, k in enumerate(g32))
+    den = sum((g['grad64'][i][1:] ** 2).sum() for i, k in enumerate(g32))
+    assert (num / den) ** 0.5 < max(3 * float(g['ref_fp32_grad_relerr']), 1e-3)
+
+
+def test_intention_policy_step_golden(golden_dir):
+    import types
+    g = np.load('%s/intention_step.npz' % golden_dir)
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 1}, {'pushing_robot': 1}], num_input_channels=5,
+                                final_exploration=0.01)
+    seeds = iter([71, 72, 73, 74])
+    pol = opolicy.DQNIntentionPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=9)
+    s = synth.make_states(2, 4, 81)
+    a, info = pol.step([[s[0]], [s[1]]], exploration_eps=0.0, debug=True)
+    assert [a[0][0], a[1][0]] == g['actions'].tolist()
+    assert rel(np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]), g['output_intention']) < 1e-5
+    si = info['state_intention'][0][0]
+    assert si.shape == (96, 96, 5) and np.array_equal(si[:, :, :4], s[0]) and 0.0 <= si[:, :, 4].min() <= si[:, :, 4].max() <= 1.0
+    # train-mode policy: the ground-truth map (last channel) is dropped before predicting, or used as is
+    pol.train = True
+    full = np.concatenate([s[0], np.zeros((96, 96, 1), np.float32)], axis=2)
+    a_pred = pol.step([[full], [None]], exploration_eps=0.0)
+    assert a_pred[0][0] == a[0][0]
+    a_gt = pol.step([[full], [None]], exploration_eps=0.0, use_ground_truth_intention=True)
+    assert 0 <= a_gt[0][0] < 2 * 96 * 96
