@@ -16,26 +16,18 @@
 // (slot ^ f(row>>2), f = {0,2,3,1}) that makes every 16-lane group of the ds_read_b128 fragment loads hit 16
 // distinct 16-B slots without padding; 2 stages, one barrier per K-step, global loads two K-steps ahead.
 // Output is fp32 (it feeds BatchNorm statistics / elementwise consumers); epilogue as in conv_igemm.hip.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
 #include "igemm_epilogue.h"
+#include "igemm_bf16_args.h"
 
 namespace simq {
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct IgemmBfArgs {
-    const uint16_t* x[2];          // activation planes [pixels][Cin] (hi, lo)
-    const uint16_t* w[2];          // weight planes [Cout][R*S*Cin]   (hi, lo)
-    EpiArgs epi;
-    int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
-    int M, K;
-    int tilesN;
-    unsigned x_bytes, w_bytes;     // plane sizes for the bounds-checked buffer loads
-};
 
 // XOR swizzle of the 16-B slots of an LDS row so that every 16-lane group of a ds_read_b128 fragment load
 // (rows r..r+15 at one k-slot, two consecutive k-slots per group) hits 16 distinct slots of the 256-B bank row:
@@ -318,6 +310,10 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     }
     // plain bf16: 64-deep K stages (two MFMA k-steps per barrier) whenever the channel count allows; split-bf16 keeps 32
     if (nplanes == 2) return dispatch<2, 32>(bm, bn, a, stream);
+    {
+        const int took = try_conv_igemm_bf16_dma(a, stream);      // large-tile LDS-DMA kernel where the shape allows
+        if (took != 0) return took < 0 ? took : 0;
+    }
     return (g.Cin % 64 == 0) ? dispatch<1, 64>(bm, bn, a, stream) : dispatch<1, 32>(bm, bn, a, stream);
 }
 

@@ -39,12 +39,14 @@ inline EpiArgs make_epi(float* y, const ConvEpilogue& e) {
     return a;
 }
 
-// smem: >= 2*BN*4 doubles, idle at this point (all waves are past the last MFMA barrier)
-template <int BM, int BN, int TM, int TN>
+// smem: >= WM*BN*4 doubles, idle at this point (all waves are past the last MFMA barrier)
+template <int BM, int BN, int TM, int TN, int WM = 2, int NW = 4>
 __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[TM][TN], int m0, int n0, int M, int Cout,
                                                void* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int WN = NW / WM;                      // WM x WN waves, wave tile (BM/WM) x (BN/WN) = (16 TM) x (16 TN)
+    static_assert(TM * 16 * WM == BM && TN * 16 * WN == BN, "wave layout does not cover the block tile");
+    const int wm = wave / WN, wn = wave % WN;
     const int fi = lane & 15, fq = lane >> 4;
     const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
     float s0[TN], s1[TN], s2[TN], s3[TN];
@@ -52,7 +54,7 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
     for (int j = 0; j < TN; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fi;
+        const int n = n0 + wn * (BN / WN) + j * 16 + fi;
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float sc = p.scale ? p.scale[n] : 1.f;
         const float sh = p.scale ? p.shift[n] : 0.f;
@@ -63,7 +65,7 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + 4 * fq + r;
+                const int m = m0 + wm * (BM / WM) + i * 16 + 4 * fq + r;
                 if (m < M) {
                     float v = acc[i][j][r] + bias;
                     if (p.stats) { s0[j] += v; s1[j] += v * v; }
@@ -83,27 +85,136 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
         }
     }
     if (!p.stats && !bnr) return;   // block-uniform
-    double* red = reinterpret_cast<double*>(smem);   // [2 wave rows][BN][4]
+    double* red = reinterpret_cast<double*>(smem);   // [WM wave rows][BN][4]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         float a = s0[j], b = s1[j], c = s2[j], d = s3[j];
         a += __shfl_xor(a, 16); b += __shfl_xor(b, 16); c += __shfl_xor(c, 16); d += __shfl_xor(d, 16);
         a += __shfl_xor(a, 32); b += __shfl_xor(b, 32); c += __shfl_xor(c, 32); d += __shfl_xor(d, 32);
         if (fq == 0) {
-            double* q = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fi) * 4;
+            double* q = red + ((wm * BN) + wn * (BN / WN) + j * 16 + fi) * 4;
             q[0] = (double)a; q[1] = (double)b; q[2] = (double)c; q[3] = (double)d;
         }
     }
     __syncthreads();
     if (tid < BN) {
-        const double a = red[tid * 4 + 0] + red[(BN + tid) * 4 + 0];
-        const double b = red[tid * 4 + 1] + red[(BN + tid) * 4 + 1];
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+            a += red[(w * BN + tid) * 4 + 0]; b += red[(w * BN + tid) * 4 + 1];
+            c += red[(w * BN + tid) * 4 + 2]; d += red[(w * BN + tid) * 4 + 3];
+        }
         double* dst = p.stats ? p.stats : p.bnr_red1;
         unsafeAtomicAdd(dst + n0 + tid, a);
         unsafeAtomicAdd(dst + Cout + n0 + tid, b);
         if (bnr2) {
-            const double c = red[tid * 4 + 2] + red[(BN + tid) * 4 + 2];
-            const double d = red[tid * 4 + 3] + red[(BN + tid) * 4 + 3];
+            unsafeAtomicAdd(p.bnr_red2 + n0 + tid, c);
+            unsafeAtomicAdd(p.bnr_red2 + Cout + n0 + tid, d);
+        }
+    }
+}
+
+// ---- LDS-staged variant (conv_igemm_bf16_dma.hip) -------------------------------------------------------------------
+// Same arithmetic as igemm_epilogue, but every global access is a 16-byte vector over full output rows: each wave
+// transposes 48 rows of its accumulator tile at a time through a private LDS strip (ds_write_b32 by fragment layout,
+// ds_read_b128 by rows), so y / addend / mask / y1 / y2 move as float4 -- 128 B (WTN = 32) or 256 B (WTN = 64) per
+// output row and wave instruction -- instead of 4-byte accesses in 64-B pieces.  No block barrier until the final
+// per-channel reduction: DS operations of one wave execute in order.
+// smem: >= 64 KB + WM*BN*32 B, idle (all waves past the last MFMA barrier).
+template <int BM, int BN, int TM, int TN, int WM, int NW>
+__device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 (&acc)[TM][TN], int m0, int n0, int M, int Cout,
+                                                      void* smem) {
+    constexpr int WN = NW / WM, WTN = TN * 16;
+    static_assert(TM * 16 * WM == BM && TN * 16 * WN == BN, "wave layout does not cover the block tile");
+    static_assert(TM % 3 == 0, "row tiles are staged three at a time");
+    constexpr int LDW = WTN + 4;                    // strip row stride (floats): 4*LDW mod 32 == 16 -> conflict-free writes
+    constexpr int LPR = WTN / 4;                    // lanes per output row (float4 each)
+    constexpr int RPI = 64 / LPR;                   // rows per wave instruction
+    constexpr int STRIP = 48 * LDW;                 // floats per wave
+    static_assert(NW * STRIP * 4 <= 64 * 1024, "staging strips exceed their 64 KB");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fi = lane & 15, fq = lane >> 4;
+    const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
+    float* strip = reinterpret_cast<float*>(smem) + wave * STRIP;
+    const int cl = (lane % LPR) * 4;                // this lane's 4 columns inside the wave tile
+    const int rl = lane / LPR;
+    const int n = n0 + wn * WTN + cl;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    floatx4 mu1 = sh, is1 = sh, mu2 = sh, is2 = sh;
+    // per-channel vectors: scalar loads (parameter tensors are only 4-byte aligned inside the flat buffer)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (p.bias) bias[c] = p.bias[n + c];
+        if (p.scale) { sc[c] = p.scale[n + c]; sh[c] = p.shift[n + c]; }
+        if (bnr) { mu1[c] = p.bnr_mean1[n + c]; is1[c] = p.bnr_invstd1[n + c]; }
+        if (bnr2) { mu2[c] = p.bnr_mean2[n + c]; is2[c] = p.bnr_invstd2[n + c]; }
+    }
+    floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+#pragma unroll
+    for (int ig = 0; ig < TM / 3; ++ig) {
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) strip[(ii * 16 + 4 * fq + r) * LDW + j * 16 + fi] = acc[ig * 3 + ii][j][r];
+#pragma unroll
+        for (int k = 0; k < 48 / RPI; ++k) {
+            const int row = k * RPI + rl;
+            const int m = m0 + wm * (TM * 16) + ig * 48 + row;
+            floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * LDW + cl);
+            if (m < M) {
+                v += bias;
+                if (p.stats) { s0 += v; s1 += v * v; }
+                v = v * sc + sh;
+                const size_t o = (size_t)m * Cout + n;
+                if (p.addend) v += *reinterpret_cast<const floatx4*>(p.addend + o);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<floatx4*>(p.y + o) = v;
+                if (bnr) {
+                    const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
+                    floatx4 dz;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
+                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
+                    s0 += dz;
+                    s1 += dz * ((y1 - mu1) * is1);
+                    if (bnr2) {
+                        const floatx4 y2 = *reinterpret_cast<const floatx4*>(p.bnr_y2 + o);
+                        s2 += dz;
+                        s3 += dz * ((y2 - mu2) * is2);
+                    }
+                }
+            }
+        }
+    }
+    if (!p.stats && !bnr) return;   // block-uniform
+    double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + 64 * 1024);   // [WM][BN][4]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float a = s0[c], b = s1[c], cc = s2[c], d = s3[c];
+#pragma unroll
+        for (int x = LPR; x < 64; x <<= 1) {
+            a += __shfl_xor(a, x); b += __shfl_xor(b, x); cc += __shfl_xor(cc, x); d += __shfl_xor(d, x);
+        }
+        if (rl == 0) {
+            double* q = red + ((wm * BN) + wn * WTN + cl + c) * 4;
+            q[0] = (double)a; q[1] = (double)b; q[2] = (double)cc; q[3] = (double)d;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+            a += red[(w * BN + tid) * 4 + 0]; b += red[(w * BN + tid) * 4 + 1];
+            c += red[(w * BN + tid) * 4 + 2]; d += red[(w * BN + tid) * 4 + 3];
+        }
+        double* dst = p.stats ? p.stats : p.bnr_red1;
+        unsafeAtomicAdd(dst + n0 + tid, a);
+        unsafeAtomicAdd(dst + Cout + n0 + tid, b);
+        if (bnr2) {
             unsafeAtomicAdd(p.bnr_red2 + n0 + tid, c);
             unsafeAtomicAdd(p.bnr_red2 + Cout + n0 + tid, d);
         }
