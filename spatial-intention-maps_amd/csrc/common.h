@@ -95,6 +95,10 @@ struct BnRef {
     double rows = 0.0, inv_rows = 0.0;
     int C = 0;
 };
+// eval-mode coefficient table: one entry per BatchNorm layer (offsets in floats)
+struct BnEvalDesc { int64_t g_off, b_off, buf_off, aux_off; int C, pad_; };
+struct BnEvalTable { BnEvalDesc d[24]; int n; };
+int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream);
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,

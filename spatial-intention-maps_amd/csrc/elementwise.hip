@@ -59,6 +59,23 @@ __device__ __forceinline__ void bn_commit(const BnRef& b) {
     }
 }
 
+// eval mode: scale / shift of every BatchNorm layer from the running statistics in ONE launch (one block per layer); the
+// convolution epilogues then apply them (+ residual + ReLU) and no bn_apply launch is needed.
+__global__ void bn_eval_coeff_kernel(BnEvalTable t, const float* __restrict__ params, const float* __restrict__ bnbuf,
+                                     float* __restrict__ aux) {
+    const BnEvalDesc d = t.d[blockIdx.x];
+    BnRef b;
+    b.gamma = params + d.g_off; b.beta = params + d.b_off;
+    b.rmean = const_cast<float*>(bnbuf) + d.buf_off; b.rvar = const_cast<float*>(bnbuf) + d.buf_off + d.C;
+    b.C = d.C;
+    for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+        float sc, sh, m, i; double md, vd;
+        bn_coeff(b, c, sc, sh, m, i, md, vd);
+        aux[d.aux_off + c] = sc;
+        aux[d.aux_off + d.C + c] = sh;
+    }
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 fma4(float4 a, float4 s, float4 t) {
@@ -373,6 +390,12 @@ inline int grid_for(size_t work_items, int block = 256, int cap = 256 * 8) {
 }
 
 }  // namespace
+
+int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(t.n), dim3(256), 0, stream, t, params, bnbuf, aux);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
                     int C, hipStream_t stream, Planes pl) {

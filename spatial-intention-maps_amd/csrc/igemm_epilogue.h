@@ -120,18 +120,24 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
 // ds_read_b128 by rows), so y / addend / mask / y1 / y2 move as float4 -- 128 B (WTN = 32) or 256 B (WTN = 64) per
 // output row and wave instruction -- instead of 4-byte accesses in 64-B pieces.  No block barrier until the final
 // per-channel reduction: DS operations of one wave execute in order.
-// smem: >= 64 KB + WM*BN*32 B, idle (all waves past the last MFMA barrier).
-template <int BM, int BN, int TM, int TN, int WM, int NW>
+// RT = 16-row tiles staged per pass (divides TM).  smem: >= staged_epilogue_smem<...>() bytes, idle (all waves past the last
+// MFMA barrier).
+template <int BN, int TN, int WM, int NW, int RT>
+constexpr int staged_epilogue_smem() { return ((NW * RT * 16 * (TN * 16 + 4) * 4 + 255) / 256) * 256 + WM * BN * 32; }
+
+template <int BM, int BN, int TM, int TN, int WM, int NW, int RT = 3>
 __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 (&acc)[TM][TN], int m0, int n0, int M, int Cout,
                                                       void* smem) {
     constexpr int WN = NW / WM, WTN = TN * 16;
     static_assert(TM * 16 * WM == BM && TN * 16 * WN == BN, "wave layout does not cover the block tile");
-    static_assert(TM % 3 == 0, "row tiles are staged three at a time");
+    static_assert(TM % RT == 0, "row tiles are staged RT at a time");
+    constexpr int ROWS = RT * 16;
     constexpr int LDW = WTN + 4;                    // strip row stride (floats): 4*LDW mod 32 == 16 -> conflict-free writes
     constexpr int LPR = WTN / 4;                    // lanes per output row (float4 each)
     constexpr int RPI = 64 / LPR;                   // rows per wave instruction
-    constexpr int STRIP = 48 * LDW;                 // floats per wave
-    static_assert(NW * STRIP * 4 <= 64 * 1024, "staging strips exceed their 64 KB");
+    constexpr int STRIP = ROWS * LDW;               // floats per wave
+    constexpr int RED_OFF = ((NW * STRIP * 4 + 255) / 256) * 256;
+    static_assert(ROWS % RPI == 0, "rows per pass must be a multiple of the rows one wave instruction covers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fi = lane & 15, fq = lane >> 4;
@@ -152,17 +158,17 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
     }
     floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
 #pragma unroll
-    for (int ig = 0; ig < TM / 3; ++ig) {
+    for (int ig = 0; ig < TM / RT; ++ig) {
 #pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
+        for (int ii = 0; ii < RT; ++ii)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) strip[(ii * 16 + 4 * fq + r) * LDW + j * 16 + fi] = acc[ig * 3 + ii][j][r];
+                for (int r = 0; r < 4; ++r) strip[(ii * 16 + 4 * fq + r) * LDW + j * 16 + fi] = acc[ig * RT + ii][j][r];
 #pragma unroll
-        for (int k = 0; k < 48 / RPI; ++k) {
+        for (int k = 0; k < ROWS / RPI; ++k) {
             const int row = k * RPI + rl;
-            const int m = m0 + wm * (TM * 16) + ig * 48 + row;
+            const int m = m0 + wm * (TM * 16) + ig * ROWS + row;
             floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * LDW + cl);
             if (m < M) {
                 v += bias;
@@ -190,7 +196,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
         }
     }
     if (!p.stats && !bnr) return;   // block-uniform
-    double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + 64 * 1024);   // [WM][BN][4]
+    double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + RED_OFF);   // [WM][BN][4]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float a = s0[c], b = s1[c], cc = s2[c], d = s3[c];

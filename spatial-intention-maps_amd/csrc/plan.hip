@@ -271,6 +271,32 @@ WeightPrepTable weight_table(const simq_plan* p) {
     return t;
 }
 
+// eval-mode convolution with the following BatchNorm (running statistics), residual and ReLU folded into its epilogue:
+// out = [relu]( (conv(x) + bias) * scale + shift [+ addend] )  -- the same fma / add / max sequence bn_apply performs
+int conv_bn_folded(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, float* out, int hin, const float* addend, int relu) {
+    ConvGeom g = geom(cv, c.B, hin);
+    ConvEpilogue e;
+    if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
+    e.scale = c.aux(bn, 0); e.shift = c.aux(bn, 1);
+    e.addend = addend; e.relu = relu;
+    return conv_fwd(c, cv, x, out, g, e);
+}
+
+BnEvalTable bn_eval_table(const simq_plan* p) {
+    BnEvalTable t;
+    t.n = 0;
+    auto add = [&](const BnL& b) {
+        BnEvalDesc& d = t.d[t.n++];
+        d.g_off = b.g_off; d.b_off = b.b_off; d.buf_off = b.buf_off; d.aux_off = b.aux_off; d.C = b.C; d.pad_ = 0;
+    };
+    for (int i = 0; i < 8; ++i) {
+        add(p->blocks[i].b1); add(p->blocks[i].b2);
+        if (p->blocks[i].has_ds) add(p->blocks[i].bds);
+    }
+    add(p->hb1); add(p->hb2);
+    return t;
+}
+
 int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
@@ -285,11 +311,26 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     Act cur = c.act(L.pooled, L.p_pooled, rows * 64);
     RC(launch_stem_pool_fwd(c.f(L.y0), bnref(c, p->stem_bn, mode, (int64_t)B * 2304), cur.f,
                             reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl));
+    // eval mode, fp32 arithmetic: BatchNorm folded into the convolution epilogues (no bn_apply launches, no pre-BN
+    // round trip through HBM); the matrix-core precisions keep bn_apply, which also writes their bf16 planes
+    const bool folded = mode == SIMQ_MODE_EVAL && !c.mc();
+    if (folded) RC(launch_bn_eval_coeff(bn_eval_table(p), c.params, c.bnbuf, c.f(L.aux), c.stream));
     for (int i = 0; i < 8; ++i) {   // BasicBlock.forward, resnet.py:31-47
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
         const int64_t n = rows * b.planes;
         Act a1 = c.act(o.a1, o.p_a1, n), out = c.act(o.out, o.p_out, n);
+        if (folded) {
+            RC(conv_bn_folded(c, b.c1, b.b1, cur, a1.f, 24, nullptr, 1));
+            const float* identity = cur.f;
+            if (b.has_ds) {
+                RC(conv_bn_folded(c, b.ds, b.bds, cur, c.f(o.yd), 24, nullptr, 0));
+                identity = c.f(o.yd);
+            }
+            RC(conv_bn_folded(c, b.c2, b.b2, a1, out.f, 24, identity, 1));
+            cur = out;
+            continue;
+        }
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
         RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.f, rows, b.planes, c.stream, a1.pl));
         RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
@@ -303,12 +344,20 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         cur = out;
     }
     // head, networks.py:18-26
-    RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-    RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
+    if (folded) {
+        RC(conv_bn_folded(c, p->h1, p->hb1, cur, c.f(L.ah1), 24, nullptr, 1));
+    } else {
+        RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
+        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
+    }
     Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
     RC(launch_upsample2x_fwd(c.f(L.ah1), up1.f, B, 24, 24, 128, c.stream, up1.pl));
-    RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
-    RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
+    if (folded) {
+        RC(conv_bn_folded(c, p->h2, p->hb2, up1, c.f(L.ah2), 48, nullptr, 1));
+    } else {
+        RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
+        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
+    }
     RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
     RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
     return 0;
