@@ -17,6 +17,7 @@ all parameters with one kernel and all-reduce one message.
 import math
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from . import arch
@@ -295,6 +296,27 @@ class FCN(torch.nn.Module):
         ws = self._ws[slot]
         hw = int(round((n.value // (batch * ch.value)) ** 0.5))
         return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(batch, hw, hw, ch.value)
+
+    def infer_argmax_batch(self, states, need_q=False):
+        """Eval-mode forward of several HWC states (numpy [96,96,C] or device tensors [1,96,96,C]) in ONE batch + one
+        argmax launch: the multi-robot form of infer_argmax (batched multi-env inference)."""
+        if self.training:
+            raise SimqError('infer_argmax_batch: the net must be in eval mode (policies.py:56)')
+        if len(states) == 1:
+            a, q = self.infer_argmax(states[0], need_q)
+            return [a], [q]
+        if all(not torch.is_tensor(s) for s in states):
+            x = torch.from_numpy(np.stack([np.ascontiguousarray(s, dtype=np.float32) for s in states])).to(self.device_)
+        else:
+            x = torch.cat([s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).unsqueeze(0).to(self.device_)
+                           for s in states]).contiguous()
+        q = self.forward_nhwc(x)
+        n = q[0].numel()
+        idx = torch.empty(len(states), dtype=torch.int64, device=self.device_)
+        lib.call('simq_q_argmax', ptr(q), len(states), n, ptr(idx), None, stream_ptr(self.device_))
+        acts = idx.tolist()
+        qs = list(q.cpu().numpy()) if need_q else [None] * len(states)
+        return acts, qs
 
     # ------------------------------------------------------------------ batch-1 inference (DQNPolicy.step hot loop)
     def infer_argmax(self, state_hwc, need_q=False):

@@ -66,18 +66,19 @@ class DQNPolicy:
                 robot_type = self.robot_group_types[i]
                 net = self.policy_nets[i]
                 net.eval()
-                for j, s in enumerate(g):
-                    if s is not None:
-                        # the reference goes HWC -> CHW -> device -> net -> argmax -> .cpu(); here one captured hipGraph
-                        # does forward + argmax on the HWC state, and the Q-map only travels back when asked for
-                        greedy, q = net.infer_argmax(s if torch.is_tensor(s) else np.ascontiguousarray(s, dtype=np.float32),
-                                                     need_q=debug)
-                        if random.random() < exploration_eps:
-                            a = random.randrange(arch.get_action_space(robot_type))
-                        else:
-                            a = greedy
-                        action[i][j] = a
-                        output[i][j] = q
+                # the reference runs one batch-1 forward per robot (HWC -> CHW -> device -> net -> argmax -> .cpu()); here
+                # all robots of the group share ONE eval forward (eval-mode BatchNorm: samples are independent) and one
+                # argmax launch; only the indices come back, the Q-maps only when `debug` asks for them.  The RNG draws
+                # stay in the reference's (i, j) order.
+                live = [j for j, s in enumerate(g) if s is not None]
+                greedy, qmaps = net.infer_argmax_batch([g[j] for j in live], need_q=debug) if live else ([], [])
+                for k, j in enumerate(live):
+                    if random.random() < exploration_eps:
+                        a = random.randrange(arch.get_action_space(robot_type))
+                    else:
+                        a = greedy[k]
+                    action[i][j] = a
+                    output[i][j] = qmaps[k] if debug else None
                 if self.train:
                     net.train()
         if debug:

@@ -366,3 +366,36 @@ def test_precision_fused_train(simq_mod, case, precision, golden_dir):
     assert np.isfinite(info2['loss'])
     sd = policy.state_dict()
     assert all(int(sd[k]) == 4 for k in sd if k.endswith('num_batches_tracked'))
+
+
+def test_policy_step_batches_the_robots_of_a_group(simq_mod):
+    """SURVEY 8f (batched multi-env inference): the robots of one group share a single eval forward; actions, debug
+    Q-maps and the RNG draw order are those of the reference's per-robot loop (policies.py:57-66)."""
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 4}, {'pushing_robot': 2}], num_input_channels=4,
+                                final_exploration=0.01, checkpoint_path=None)
+    pol = simq_mod.DQNPolicy(cfg, train=False, random_seed=3)
+    s = synth.make_states(6, 4, 77)
+    state = [[s[0], s[1], None, s[2]], [s[3], s[4]]]
+    random.seed(11)
+    a_batched, info = pol.step(state, exploration_eps=0.3, debug=True)
+    # the same thing one robot at a time (every group call sees exactly one live state -> batch-1 path)
+    random.seed(11)
+    a_single = [[None] * 4, [None] * 2]
+    q_single = [[None] * 4, [None] * 2]
+    for i, g in enumerate(state):
+        for j, st in enumerate(g):
+            if st is None:
+                continue
+            one = [[None] * len(gg) for gg in state]
+            one[i][j] = st
+            a, inf = pol.step(one, exploration_eps=0.3, debug=True)
+            a_single[i][j], q_single[i][j] = a[i][j], inf['output'][i][j]
+    assert a_batched == a_single
+    for i, g in enumerate(state):
+        for j, st in enumerate(g):
+            if st is None:
+                assert info['output'][i][j] is None
+            else:
+                assert rel(info['output'][i][j], q_single[i][j]) < 1e-6
+    assert pol.step(state, exploration_eps=0.0) == [[int(np.argmax(info['output'][0][j].reshape(-1))) if state[0][j] is not None else None for j in range(4)],
+                                                    [int(np.argmax(info['output'][1][j].reshape(-1))) for j in range(2)]]

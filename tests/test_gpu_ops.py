@@ -285,3 +285,36 @@ def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
     L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(xd), L.ptr(dyd), L.ptr(dwd), B, H, H, Cin, Cout, k, k, 1, pad, nplanes,
                L.ptr(scratch), st)
     assert rel(dwd, wd64.grad.permute(0, 2, 3, 1)) < tol_fwd
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout,k', [(16, 24, 128, 256, 3), (15, 24, 64, 128, 3), (16, 24, 256, 128, 1)],
+                         ids=['256tiles', 'ragged_rows', '1x1'])
+def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k):
+    """The large-tile LDS-DMA kernel (conv_igemm_bf16_dma.hip, 288x128 tile, 8 waves, staged vector epilogue) against
+    the register-staged kernel on the same bf16 operands: identical K order (64-channel chunk outer, tap inner) and
+    fp32 MFMA accumulation, so outputs agree to fp32 round-off; bias + batch statistics go through both epilogues.
+    'ragged_rows': M = 15*576 is not a multiple of 288 (zero-filled DMA rows, masked stores)."""
+    g = torch.Generator().manual_seed(7 + Cin + Cout)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
+    st = L.stream_ptr()
+    outs = []
+    try:
+        for tile in ((288, 128), (96, 128)):
+            L.lib.call('simq_tune_force_tile', *tile)
+            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1,
+                       L.ptr(scratch), L.ptr(stats), st)
+            outs.append((y, stats))
+    finally:
+        L.lib.call('simq_tune_force_tile', 0, 0)
+    (y_dma, s_dma), (y_reg, s_reg) = outs
+    assert torch.isfinite(y_dma).all()
+    assert rel(y_dma, y_reg) < 2e-6
+    assert rel(s_dma, s_reg) < 1e-6
+    # and both are bf16-class against an fp64 convolution of the same inputs
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+    assert rel(y_dma, ref) < 2e-2
