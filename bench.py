@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the opt-in bf16 configs[2] leg of the default N=1 run')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                     help="arithmetic of the 3x3/1x1 convolutions; the default 'fp32' (exact) is the BASELINE configs[1] workload")
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='transitions per GPU per step (default: configs[1])')
@@ -136,80 +137,86 @@ def main():
     from simq._lib import lib
     from simq.learner import _opt_state, train_step
 
+    def run_workload(CIN, BATCH_PER_GPU, precision, steps, warmup, replay_items):
+        # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
+        # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
+        # stay O(1) so that many steps of synthetic training remain finite
+        torch.manual_seed(20260928)
+        policy = simq.FCN(CIN, COUT, device=dev, precision=precision)
+        target = simq.FCN(CIN, COUT, device=dev, precision=precision)
+        target.copy_state_from(policy)
+        policy.train()
+        target.eval()
+        st_opt = _opt_state(policy, None)
+
+        # synthetic replay, resident in HBM before the timed region (same content on every rank)
+        trs = synth.make_transitions(replay_items, CIN, COUT, 5, terminal_frac=0.1)
+        ring = simq.DeviceReplayBuffer(replay_items, CIN, device=dev)
+        ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
+                       np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
+                       [t[3] is None for t in trs])
+        B, gB = BATCH_PER_GPU, BATCH_PER_GPU * world
+        random.seed(1234)                   # every rank draws the same global minibatch, then takes its slice
+
+        def step():
+            idx = ring.sample_indices(gB)
+            batch = ring.gather(sdist.shard_indices(idx, world, rank))
+            return train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
+                              opt_state=st_opt, process_group=pg, global_batch=gB, sync=True)
+
+        def barrier():
+            if pg is not None:
+                torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(warmup):
+            info = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            info = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if pg is not None:
+            dt = sdist.max_over_ranks(dt, dev, pg)
+        if not np.isfinite(info['loss']):
+            sys.exit('bench: non-finite loss %r' % (info,))
+        value = gB * steps / dt
+
+        # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
+        # backward only -- no next-state forwards, clip or SGD.  Reported beside the full-step `value`, never instead of it.
+        from simq._lib import MODE_TRAIN, ptr, stream_ptr
+        idx = ring.sample_indices(gB)
+        fb = ring.gather(sdist.shard_indices(idx, world, rank))
+        nq = COUT * 96 * 96
+        fb_out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
+        fb_o4 = torch.empty(4, dtype=torch.float32, device=dev)
+        fb_nsv = torch.zeros(B, dtype=torch.float32, device=dev)
+
+        def fwd_bwd():
+            q = policy._forward_raw(fb.state, MODE_TRAIN)
+            dq = torch.empty_like(q)
+            lib.call('simq_td_huber', ptr(q), B, nq, ptr(fb.action), ptr(fb.reward), ptr(fb_nsv), GAMMA, 1.0 / gB, ptr(fb_out[0]),
+                     ptr(fb_out[1]), ptr(fb_out[2]), ptr(fb_o4), ptr(dq), stream_ptr(dev))
+            policy._backward_raw(dq, B)
+
+        for _ in range(2):
+            fwd_bwd()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            fwd_bwd()
+        barrier()
+        dt_m1 = time.perf_counter() - t2
+        if pg is not None:
+            dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
+
+        return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'barrier': barrier, 'B': B, 'gB': gB}
+
     global CIN, BATCH_PER_GPU
     CIN, BATCH_PER_GPU = args.cin, args.batch
-    # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
-    # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
-    # stay O(1) so that many steps of synthetic training remain finite
-    torch.manual_seed(20260928)
-    policy = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
-    target = simq.FCN(CIN, COUT, device=dev, precision=args.precision)
-    target.copy_state_from(policy)
-    policy.train()
-    target.eval()
-    st_opt = _opt_state(policy, None)
-
-    # synthetic replay, resident in HBM before the timed region (same content on every rank)
-    trs = synth.make_transitions(REPLAY_ITEMS, CIN, COUT, 5, terminal_frac=0.1)
-    ring = simq.DeviceReplayBuffer(REPLAY_ITEMS, CIN, device=dev)
-    ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
-                   np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
-                   [t[3] is None for t in trs])
-    B, gB = BATCH_PER_GPU, BATCH_PER_GPU * world
-    random.seed(1234)                   # every rank draws the same global minibatch, then takes its slice
-
-    def step():
-        idx = ring.sample_indices(gB)
-        batch = ring.gather(sdist.shard_indices(idx, world, rank))
-        return train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
-                          opt_state=st_opt, process_group=pg, global_batch=gB, sync=True)
-
-    def barrier():
-        if pg is not None:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        info = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        info = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if pg is not None:
-        dt = sdist.max_over_ranks(dt, dev, pg)
-    if not np.isfinite(info['loss']):
-        sys.exit('bench: non-finite loss %r' % (info,))
-    value = gB * args.steps / dt
-
-    # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
-    # backward only -- no next-state forwards, clip or SGD.  Reported beside the full-step `value`, never instead of it.
-    from simq._lib import MODE_TRAIN, ptr, stream_ptr
-    idx = ring.sample_indices(gB)
-    fb = ring.gather(sdist.shard_indices(idx, world, rank))
-    nq = COUT * 96 * 96
-    fb_out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
-    fb_o4 = torch.empty(4, dtype=torch.float32, device=dev)
-    fb_nsv = torch.zeros(B, dtype=torch.float32, device=dev)
-
-    def fwd_bwd():
-        q = policy._forward_raw(fb.state, MODE_TRAIN)
-        dq = torch.empty_like(q)
-        lib.call('simq_td_huber', ptr(q), B, nq, ptr(fb.action), ptr(fb.reward), ptr(fb_nsv), GAMMA, 1.0 / gB, ptr(fb_out[0]),
-                 ptr(fb_out[1]), ptr(fb_out[2]), ptr(fb_o4), ptr(dq), stream_ptr(dev))
-        policy._backward_raw(dq, B)
-
-    for _ in range(2):
-        fwd_bwd()
-    barrier()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
-        fwd_bwd()
-    barrier()
-    dt_m1 = time.perf_counter() - t2
-    if pg is not None:
-        dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
+    w = run_workload(CIN, BATCH_PER_GPU, args.precision, args.steps, args.warmup, REPLAY_ITEMS)
+    value, dt, dt_m1, info, step, barrier, B, gB = (w[k] for k in ('value', 'dt', 'dt_m1', 'info', 'step', 'barrier', 'B', 'gB'))
 
     roof = None
     if not args.no_roofline:
@@ -252,6 +259,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(min(BATCH_PER_GPU, 32))
 
+    # BASELINE configs[2] (lifting_4-small_divider: Cin=5, batch 128, bf16 operands) on the opt-in bf16 matrix-core path,
+    # reported beside the fp32 headline, never instead of it (N=1 default run only; a few seconds)
+    extras = None
+    if world == 1 and args.precision == 'fp32' and not args.no_extras and args.cin == 4 and args.batch == 32:
+        try:
+            e = run_workload(5, 128, 'bf16', 10, 3, 256)
+            extras = {'configs[2] lifting_4-small_divider, batch 128, bf16 operands (f32 accumulate / BN / optimiser)': {
+                'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / 10 * 1e3, 3),
+                'fwd_bwd_only_transitions_per_s': round(e['gB'] * 10 / e['dt_m1'], 1),
+                'fwd_bwd_only_ms_per_step': round(e['dt_m1'] / 10 * 1e3, 3), 'last_loss': e['info']['loss']}}
+            del e
+            torch.cuda.empty_cache()
+        except Exception as ex:       # the headline line must not depend on the opt-in leg
+            extras = {'error': repr(ex)}
+
     if rank == 0:
         line = {
             'metric': 'Q-map transitions/sec (full train() step: 3 fwd + bwd + clip + SGD, 96x96)',
@@ -265,7 +287,8 @@ def main():
                        'fwd_bwd_only': {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
                                         'ms_per_step': round(dt_m1 / args.steps * 1e3, 3), 'flop_per_transition': FLOP_M1,
                                         'note': 'policy forward + gather + Huber + backward only (M1 of SURVEY 8d); no '
-                                                'gradient all-reduce, clip or SGD'}, 'last_loss': info['loss'], 'last_td_error': info['td_error']},
+                                                'gradient all-reduce, clip or SGD'}, 'last_loss': info['loss'], 'last_td_error': info['td_error'],
+                       'opt_in_precisions': extras},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
