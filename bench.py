@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-m1', action='store_true', help='skip the forward+backward-only (M1) leg (profiling runs: every launch then belongs to a full step)')
     ap.add_argument('--no-extras', action='store_true', help='skip the opt-in bf16 configs[2] leg of the default N=1 run')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                     help="arithmetic of the 3x3/1x1 convolutions; the default 'fp32' (exact) is the BASELINE configs[1] workload")
@@ -200,15 +201,17 @@ def main():
                      ptr(fb_out[1]), ptr(fb_out[2]), ptr(fb_o4), ptr(dq), stream_ptr(dev))
             policy._backward_raw(dq, B)
 
-        for _ in range(2):
-            fwd_bwd()
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(steps):
-            fwd_bwd()
-        barrier()
-        dt_m1 = time.perf_counter() - t2
-        if pg is not None:
+        dt_m1 = float('nan')
+        if not args.no_m1:
+            for _ in range(2):
+                fwd_bwd()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(steps):
+                fwd_bwd()
+            barrier()
+            dt_m1 = time.perf_counter() - t2
+        if pg is not None and not args.no_m1:
             dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
 
         return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'barrier': barrier, 'B': B, 'gB': gB}
@@ -284,7 +287,7 @@ def main():
                                    'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
                        'global_batch': gB, 'parallelism': 'dp%d' % world,
                        'flop_per_transition': FLOP_M2,
-                       'fwd_bwd_only': {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
+                       'fwd_bwd_only': None if args.no_m1 else {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
                                         'ms_per_step': round(dt_m1 / args.steps * 1e3, 3), 'flop_per_transition': FLOP_M1,
                                         'note': 'policy forward + gather + Huber + backward only (M1 of SURVEY 8d); no '
                                                 'gradient all-reduce, clip or SGD'}, 'last_loss': info['loss'], 'last_td_error': info['td_error'],
