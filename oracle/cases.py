@@ -25,6 +25,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(_HERE), 'tests', 'golden')
 # (name, cin, cout, batch, weight seed, data seed)
 FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), ('fwd_c5o1', 5, 1, 2, 13, 23)]
 TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
+# the bench workload's own size (BASELINE configs[1]); summaries only, checked on the GPU without re-running the oracle
+TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 

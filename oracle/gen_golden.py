@@ -90,8 +90,8 @@ def gen_forward():
         print('forward case', name, 'oracle == reference (bit-exact); saved')
 
 
-def gen_train():
-    for name, cin, cout, B, wseed, dseed in cases.TRAIN_CASES:
+def gen_train(case_list=None):
+    for name, cin, cout, B, wseed, dseed in (case_list or cases.TRAIN_CASES):
         cfg = cases.make_cfg(B)
         batch = cases.make_batch(cin, cout, B, dseed)
         spec = fcn.state_spec(cin, cout)
@@ -244,6 +244,7 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
-            'intention': gen_intention, 'intention_step': gen_intention_step}
+            'intention': gen_intention, 'intention_step': gen_intention_step,
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL)}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

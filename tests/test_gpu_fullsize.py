@@ -176,3 +176,54 @@ def test_ragged_and_degenerate_batches(simq_mod):
                    cases.WEIGHT_DECAY, cases.CLIP)
     with pytest.raises(Exception):
         policy.forward_nhwc(torch.zeros(1, 96, 96, cin + 1, device='cuda'))      # wrong channel count
+
+
+def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
+    """BASELINE configs[1] at its own size: two consecutive simq.train calls on the seeded B=32 batch against
+    tests/golden/train_c4o2_b32.npz (written by oracle/gen_golden.py after a bit-exact match of the oracle with the
+    imported reference train.train; fp64 gradient summary = per-tensor L2 norm + 16 sampled elements)."""
+    from oracle import learner as olearner
+    from simq import arch
+    name, cin, cout, B, wseed, dseed = cases.TRAIN_CASES_FULL[0]
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    cfg, batch = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed)
+    policy = simq_mod.FCN(cin, cout)
+    target = simq_mod.FCN(cin, cout)
+    policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed)))
+    target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed + 1000)))
+    policy.train()
+    target.eval()
+    opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    rel1 = lambda a, b: abs(a - b) / abs(b)
+    assert rel1(info1['loss'], float(g['loss'][0])) < 1e-4 and rel1(info1['td_error'], float(g['td_error'][0])) < 1e-4
+    q_sa, y = policy._last['q_sa'].cpu().double().numpy(), policy._last['y'].cpu().double().numpy()
+    assert np.abs(q_sa - g['q_sa']).max() <= 1e-4 * np.abs(g['q_sa']).max()
+    assert np.abs(y - g['y']).max() <= 1e-4 * np.abs(g['y']).max()
+    # gradient (clipped in place) against the fp64 summary: total norm, per-tensor norms, sampled elements
+    tn = float(policy._simq_opt_state.total_norm.item())
+    assert rel1(tn, float(g['total_norm64'])) < 5e-2
+    coef = min(1.0, cases.CLIP / (tn + 1e-6))
+    gflat = policy.flat_grads.detach().cpu().double() / coef
+    keys = [str(k) for k in g['grad_keys']]
+    got = {}
+    for (pname, _, kind), (off, n, shape) in zip(policy._param_names, policy._grad_views):
+        t = gflat[off:off + n].view(shape)
+        got[arch.PREFIX + pname] = (t.permute(0, 3, 1, 2).contiguous() if len(shape) == 4 else t).reshape(-1)
+    num = den = 0.0
+    for i, k in enumerate(keys):
+        flat = got[k]
+        idx = torch.tensor(cases.sample_indices(flat.numel()))
+        mine = np.concatenate([[float(flat.norm())], flat[idx].numpy()])
+        num += ((mine[1:] - g['grad64'][i][1:]) ** 2).sum()
+        den += (g['grad64'][i][1:] ** 2).sum()
+        if g['grad64'][i][0] > 1e-3 * float(g['total_norm64']):          # tensors that carry gradient mass
+            assert abs(mine[0] - g['grad64'][i][0]) <= 5e-2 * g['grad64'][i][0], k
+    assert (num / den) ** 0.5 <= 5e-2, 'sampled-gradient rel-L2 error %.3g (reference fp32 itself: %.3g)' % ((num / den) ** 0.5, float(g['ref_fp32_grad_relerr']))
+    info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    assert rel1(info2['loss'], float(g['loss'][1])) < 0.1 and rel1(info2['td_error'], float(g['td_error'][1])) < 0.1
+    sd = policy.state_dict()
+    assert all(int(sd[k]) == 4 for k in sd if k.endswith('num_batches_tracked'))
+    spec = ofcn.state_spec(cin, cout)
+    rows = np.asarray([[float(sd[k].double().sum()), float(sd[k].double().norm())] for k, _, kind in spec if ofcn.is_parameter(kind)])
+    assert np.abs(rows[:, 1] - g['param_summary_after2'][:, 1]).max() <= 1e-4 * g['param_summary_after2'][:, 1].max()

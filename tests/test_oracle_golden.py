@@ -162,3 +162,20 @@ def test_intention_policy_step_golden(golden_dir):
     assert a_pred[0][0] == a[0][0]
     a_gt = pol.step([[full], [None]], exploration_eps=0.0, use_ground_truth_intention=True)
     assert 0 <= a_gt[0][0] < 2 * 96 * 96
+
+
+def test_full_size_golden_is_present_and_consistent(golden_dir):
+    """tests/golden/train_c4o2_b32.npz (BASELINE configs[1] size; the oracle needs ~40 s there, so it is not re-run on
+    the CPU tier): internal consistency of the stored summaries."""
+    name, cin, cout, B, wseed, dseed = cases.TRAIN_CASES_FULL[0]
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    assert g['q_sa'].shape == (B,) and g['y'].shape == (B,) and g['loss'].shape == (2,)
+    d = g['q_sa'].astype(np.float64) - g['y'].astype(np.float64)
+    huber = np.where(np.abs(d) < 1, 0.5 * d * d, np.abs(d) - 0.5).mean()
+    assert abs(huber - g['loss'][0]) <= 1e-5 * abs(g['loss'][0])                    # train.py:129 on the stored q, y
+    assert abs(np.abs(d).mean() - g['td_error'][0]) <= 1e-5 * abs(g['td_error'][0])  # train.py:127,138
+    assert abs(g['loss64'] - g['loss'][0]) <= 1e-4 * abs(g['loss64'])
+    tot = np.sqrt((g['grad64'][:, 0] ** 2).sum())
+    assert abs(tot - g['total_norm64']) <= 1e-9 * g['total_norm64']                  # global norm = norm of tensor norms
+    assert float(g['ref_fp32_grad_relerr']) < 5e-3
+    assert (g['num_batches_tracked'] == 4).all()
