@@ -252,7 +252,7 @@ int run(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
     int tilesM = (p.M + BM - 1) / BM;
-    prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
+    prof_launch_begin(2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
     hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, NP, BKB>), dim3((unsigned)(tilesM * p.tilesN)), dim3(256), 0, stream, p);
