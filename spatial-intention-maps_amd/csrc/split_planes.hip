@@ -56,28 +56,52 @@ __global__ void weight_prep_all_kernel(const float* __restrict__ params, WeightP
     const WeightPrepDesc d = t.d[blockIdx.y];
     const float* w = params + d.w_off;
     const size_t total = (size_t)d.cout * d.taps * d.cin;
-    if (blockIdx.z == 0) {          // OHWI order: coalesced reads and plane writes
+    if (blockIdx.z == 0) {          // OHWI order: 16-B reads, 8-B plane writes (weights are 16-B aligned in the flat buffer)
         if (!wpl) return;
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-            const float v = w[i];
-            const uint16_t h = to_bf16(v);
-            wpl[d.wp_off + i] = h;
-            if (np == 2) wpl[wp_total + d.wp_off + i] = to_bf16(v - from_bf16(h));
+        const size_t total4 = total / 4;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+            const float4 v = *reinterpret_cast<const float4*>(w + i * 4);
+            const ushort4 h = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+            *reinterpret_cast<ushort4*>(wpl + d.wp_off + i * 4) = h;
+            if (np == 2)
+                *reinterpret_cast<ushort4*>(wpl + wp_total + d.wp_off + i * 4) =
+                    make_ushort4(to_bf16(v.x - from_bf16(h.x)), to_bf16(v.y - from_bf16(h.y)), to_bf16(v.z - from_bf16(h.z)),
+                                 to_bf16(v.w - from_bf16(h.w)));
         }
         return;
     }
-    if (!wt_f32 && !wtpl) return;   // flipped / transposed order: strided (L2-resident) reads, coalesced writes
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % d.cout);
-        const size_t r = i / d.cout;
-        const int tf = (int)(r % d.taps);
-        const int ci = (int)(r / d.taps);
-        const float v = w[((size_t)co * d.taps + (d.taps - 1 - tf)) * d.cin + ci];
-        if (wt_f32) wt_f32[d.wt_off + i] = v;
-        if (wtpl) {
-            const uint16_t h = to_bf16(v);
-            wtpl[d.wp_off + i] = h;
-            if (np == 2) wtpl[wp_total + d.wp_off + i] = to_bf16(v - from_bf16(h));
+    if (!wt_f32 && !wtpl) return;
+    // flipped / transposed order wt[ci][taps-1-t][co] = w[co][t][ci]: one 64(co) x 64(ci) tile of one tap per block pass,
+    // transposed through LDS so that both the reads (along ci) and the writes (along co) are coalesced
+    __shared__ float tile[64][65];
+    const int tiles_co = (d.cout + 63) / 64, tiles_ci = (d.cin + 63) / 64;
+    const int ntiles = tiles_co * tiles_ci * d.taps;
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+        const int tap = bid % d.taps;
+        const int rest = bid / d.taps;
+        const int ci0 = (rest % tiles_ci) * 64, co0 = (rest / tiles_ci) * 64;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int co = co0 + y + 4 * k, ci = ci0 + x;
+            tile[y + 4 * k][x] = (co < d.cout && ci < d.cin) ? w[((size_t)co * d.taps + tap) * d.cin + ci] : 0.f;
+        }
+        __syncthreads();
+        const int tf = d.taps - 1 - tap;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int ci = ci0 + y + 4 * k, co = co0 + x;
+            if (ci < d.cin && co < d.cout) {
+                const float v = tile[x][y + 4 * k];
+                const size_t i = ((size_t)ci * d.taps + tf) * d.cout + co;
+                if (wt_f32) wt_f32[d.wt_off + i] = v;
+                if (wtpl) {
+                    const uint16_t h = to_bf16(v);
+                    wtpl[d.wp_off + i] = h;
+                    if (np == 2) wtpl[wp_total + d.wp_off + i] = to_bf16(v - from_bf16(h));
+                }
+            }
         }
     }
 }
@@ -87,7 +111,7 @@ __global__ void weight_prep_all_kernel(const float* __restrict__ params, WeightP
 int launch_weight_prep_all(const float* params, const WeightPrepTable& t, float* wt_f32, uint16_t* wpl, uint16_t* wtpl, int np,
                            int64_t wp_total, hipStream_t stream) {
     if (t.n == 0) return 0;
-    hipLaunchKernelGGL(weight_prep_all_kernel, dim3(128, t.n, 2), dim3(256), 0, stream, params, t, wt_f32, wpl, wtpl, np, wp_total);
+    hipLaunchKernelGGL(weight_prep_all_kernel, dim3(192, t.n, 2), dim3(256), 0, stream, params, t, wt_f32, wpl, wtpl, np, wp_total);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
