@@ -75,3 +75,38 @@ def param_summary(state, spec):
             t = state[k].detach().double()
             rows.append([float(t.sum()), float(t.norm())])
     return np.asarray(rows)
+
+
+def tracker_script(seed=5, steps=40, groups=(2, 1)):
+    """Scripted collector episode for the TransitionTracker fixture: per step, which robots get an action, which ones
+    receive a new observation, rewards, and episode ends.  Observations are small arrays tagged with a serial number."""
+    rng = np.random.RandomState(seed)
+    serial = [0]
+
+    def obs():
+        serial[0] += 1
+        return np.full((2, 2, 1), float(serial[0]), dtype=np.float32)
+
+    initial = [[obs() for _ in range(n)] for n in groups]
+    script = []
+    for t in range(steps):
+        action = [[int(rng.randint(100)) if rng.rand() < 0.7 else None for _ in range(n)] for n in groups]
+        done = bool(rng.rand() < 0.1)
+        state = [[obs() if rng.rand() < 0.6 else None for _ in range(n)] for n in groups]
+        reward = [[float(rng.randn()) for _ in range(n)] for n in groups]
+        script.append((action, reward, state, done))
+    return initial, script
+
+
+def run_tracker(tracker_cls, seed=5):
+    """Drive a TransitionTracker implementation through the script; returns per-buffer rows
+    [state tag, action (-1 = None), reward, next_state tag (0 = None)]."""
+    initial, script = tracker_script(seed)
+    tr = tracker_cls(initial)
+    rows = [[] for _ in initial]
+    for action, reward, state, done in script:
+        tr.update_action(action)
+        for i, lst in enumerate(tr.update_step_completed(reward, state, done)):
+            for (s, a, r, ns) in lst:
+                rows[i].append([float(s[0, 0, 0]), -1.0 if a is None else float(a), float(r), 0.0 if ns is None else float(ns[0, 0, 0])])
+    return [np.asarray(r, dtype=np.float64).reshape(-1, 4) for r in rows]

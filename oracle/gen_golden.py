@@ -196,6 +196,14 @@ def gen_intention_step():
     print('intention policy.step case saved (oracle restatement)')
 
 
+def gen_tracker():
+    """train.TransitionTracker (train.py:47-68) on a scripted episode; the fixture pins simq.TransitionTracker."""
+    rows = cases.run_tracker(ref_train.TransitionTracker)
+    assert sum(len(r) for r in rows) > 20
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'tracker.npz'), **{'buffer%d' % i: r for i, r in enumerate(rows)})
+    print('tracker case saved: %s transitions per buffer' % [len(r) for r in rows])
+
+
 def gen_sampler():
     out = {}
     for n, B, seed in cases.SAMPLER_CASES:
@@ -245,6 +253,6 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL)}
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

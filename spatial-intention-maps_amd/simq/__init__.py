@@ -14,6 +14,8 @@ _LAZY = {
     'DQNIntentionPolicy': ('.policy', 'DQNIntentionPolicy'),
     'ReplayBuffer': ('.learner', 'ReplayBuffer'),
     'DeviceReplayBuffer': ('.learner', 'DeviceReplayBuffer'),
+    'AliasedDeviceReplayBuffer': ('.learner', 'AliasedDeviceReplayBuffer'),
+    'TransitionTracker': ('.learner', 'TransitionTracker'),
     'Transition': ('.learner', 'Transition'),
     'train': ('.learner', 'train'),
     'train_step': ('.learner', 'train_step'),

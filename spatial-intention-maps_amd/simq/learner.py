@@ -7,10 +7,12 @@ Reference symbols mirrored (same names, argument meaning, return values):
                            train.py:108-141 -> {'td_error': float, 'loss': float}
   train_intention(intention_net, optimizer, batch, transform_fn)
                            train.py:143-158 -> {'loss_intention': float}
+  TransitionTracker        train.py:47-68
 Additions for the MI355X path:
   DeviceReplayBuffer       same push/sample/len contract, states live in an HBM ring
                            ([capacity][96][96][C] fp32, the reference's own HWC layout) and
                            sample() is an index gather driven by the same random.sample picks
+  AliasedDeviceReplayBuffer   the same with every observation stored once (next_state of t == state of t+1)
   train_step(...)          the fused step over flat buffers (no torch autograd), used by train()
 All arithmetic goes through libsimq (HIP); there is no torch/CPU fallback.
 """
@@ -152,6 +154,107 @@ class DeviceReplayBuffer:
 
     def sample(self, batch_size):
         return self.gather(self.sample_indices(batch_size))
+
+
+class TransitionTracker:
+    """Drop-in for train.TransitionTracker (train.py:47-68): remembers, per robot, the observation and action the robot is
+    waiting on and turns (reward, new observation, done) into replay transitions.  The SAME ndarray object is handed out
+    as `next_state` of one transition and `state` of the next one -- AliasedDeviceReplayBuffer uploads it once."""
+
+    def __init__(self, initial_state):
+        self.num_buffers = len(initial_state)
+        self.prev_state = initial_state
+        self.prev_action = [[None] * len(group) for group in initial_state]
+
+    def update_action(self, action):
+        for i, group in enumerate(action):
+            for j, a in enumerate(group):
+                if a is not None:
+                    self.prev_action[i][j] = a
+
+    def update_step_completed(self, reward, state, done):
+        out = [[] for _ in range(self.num_buffers)]
+        for i, group in enumerate(state):
+            for j, s in enumerate(group):
+                if s is None and not done:
+                    continue                                    # this robot has not finished its action yet
+                before = self.prev_state[i][j]
+                if before is not None:
+                    out[i].append((before, self.prev_action[i][j], reward[i][j], s))
+                self.prev_state[i][j] = s
+        return out
+
+
+class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
+    """DeviceReplayBuffer whose observations live ONCE in HBM: the collector hands the same ndarray over
+    as `next_state` of transition t and `state` of transition t+1 (train.py:61-66, 241-244), so each 96x96xC observation is
+    uploaded once into an observation pool and transitions hold two pool slots.  Half the HBM and half the H2D traffic
+    of the two-ring layout; same push / sample / len contract and the same `random.sample` picks.
+
+    pool_slots: observations the pool can hold (default capacity + 25 %, enough when pushes alias as the collector's do;
+    independent state / next_state arrays need up to 2 * capacity)."""
+
+    def __init__(self, capacity, num_input_channels, device=None, pool_slots=None):
+        self.capacity = int(capacity)
+        self.C = int(num_input_channels)
+        self.device = torch.device('cuda' if device is None else device)
+        self.item = W * W * self.C
+        n = int(pool_slots) if pool_slots is not None else self.capacity + max(256, self.capacity // 4)
+        self.pool = torch.empty((n, W, W, self.C), dtype=torch.float32, device=self.device)
+        self.states = self.next_states = self.pool          # both gathers of the base class read the one pool
+        self._free = list(range(n - 1, -1, -1))
+        self._ref = [0] * n
+        self._recent = {}                                   # id(ndarray) -> (slot, ndarray): observations uploaded lately
+        self._recent_order = []
+        self.buffer = []
+        self.position = 0
+
+    def _upload(self, arr):
+        hit = self._recent.get(id(arr))
+        if hit is not None and hit[1] is arr:
+            return hit[0]
+        if not self._free:
+            raise SimqError('AliasedDeviceReplayBuffer: observation pool exhausted (%d slots); the pushes do not alias '
+                            'next_state/state -- construct with pool_slots=2*capacity' % len(self._ref))
+        slot = self._free.pop()
+        self.pool[slot].copy_(torch.as_tensor(arr), non_blocking=True)
+        self._recent[id(arr)] = (slot, arr)
+        self._recent_order.append(id(arr))
+        if len(self._recent_order) > 256:
+            self._recent.pop(self._recent_order.pop(0), None)
+        return slot
+
+    def _release(self, slot):
+        self._ref[slot] -= 1
+        if self._ref[slot] == 0:
+            for key in [k for k, v in self._recent.items() if v[0] == slot]:
+                del self._recent[key]
+            self._free.append(slot)
+
+    def push(self, state, action, reward, next_state):
+        if len(self.buffer) < self.capacity:
+            self.buffer.append(None)
+        old = self.buffer[self.position]
+        s_slot = self._upload(state)
+        self._ref[s_slot] += 1
+        n_slot = None
+        if next_state is not None:
+            n_slot = self._upload(next_state)
+            self._ref[n_slot] += 1
+        if old is not None:                                  # the ring wrapped: the overwritten transition lets go
+            self._release(old.state)
+            if old.next_state is not None:
+                self._release(old.next_state)
+        self.buffer[self.position] = Transition(s_slot, int(action), float(reward), n_slot)
+        self.position = (self.position + 1) % self.capacity
+
+    def push_many(self, states, actions, rewards, next_states, terminal):
+        for i in range(len(actions)):
+            self.push(states[i], actions[i], rewards[i], None if terminal[i] else next_states[i])
+
+    @property
+    def observations_resident(self):
+        return len(self._ref) - len(self._free)
 
 
 _SIDE_STREAMS = {}

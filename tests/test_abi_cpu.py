@@ -74,3 +74,29 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(d, f)
+
+
+def test_transition_tracker_matches_reference_fixture(golden_dir):
+    """simq.TransitionTracker (host logic) against tests/golden/tracker.npz, written by running the reference's
+    train.TransitionTracker (train.py:47-68) on the same scripted episode (oracle/gen_golden.py gen_tracker)."""
+    import numpy as np
+    from oracle import cases
+    from simq.learner import TransitionTracker
+    g = np.load('%s/tracker.npz' % golden_dir)
+    rows = cases.run_tracker(TransitionTracker)
+    assert len(rows) == 2
+    for i, r in enumerate(rows):
+        assert r.shape == g['buffer%d' % i].shape and np.array_equal(r, g['buffer%d' % i])
+    # the array handed out as next_state is the very object handed out as the next state (what the aliased ring keys on)
+    initial, script = cases.tracker_script()
+    tr = TransitionTracker(initial)
+    last_next = {}
+    for action, reward, state, done in script:
+        tr.update_action(action)
+        for i, lst in enumerate(tr.update_step_completed(reward, state, done)):
+            for (s, a, r, ns) in lst:
+                key = (i, float(s[0, 0, 0]))
+                if key in last_next:
+                    assert last_next.pop(key) is s
+                if ns is not None:
+                    last_next[(i, float(ns[0, 0, 0]))] = ns

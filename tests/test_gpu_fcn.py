@@ -399,3 +399,43 @@ def test_policy_step_batches_the_robots_of_a_group(simq_mod):
                 assert rel(info['output'][i][j], q_single[i][j]) < 1e-6
     assert pol.step(state, exploration_eps=0.0) == [[int(np.argmax(info['output'][0][j].reshape(-1))) if state[0][j] is not None else None for j in range(4)],
                                                     [int(np.argmax(info['output'][1][j].reshape(-1))) for j in range(2)]]
+
+
+def test_aliased_device_replay_buffer(simq_mod):
+    """observations stored once in HBM.  A collector-style stream (TransitionTracker output, next_state of t
+    is the state object of t+1) through AliasedDeviceReplayBuffer vs the reference-style host ReplayBuffer: same picks,
+    same minibatch contents, one pool slot per observation, slots recycled when the ring wraps."""
+    from simq.learner import AliasedDeviceReplayBuffer, ReplayBuffer, TransitionTracker, assemble_batch
+    rng = np.random.RandomState(3)
+    C, cap = 4, 24
+    obs = lambda: rng.rand(96, 96, C).astype(np.float32)
+    tracker = TransitionTracker([[obs(), obs()]])
+    dev_buf, host_buf = AliasedDeviceReplayBuffer(cap, C, pool_slots=cap + 8), ReplayBuffer(cap)
+    pushed = 0
+    for t in range(60):
+        tracker.update_action([[int(rng.randint(2 * 96 * 96)), int(rng.randint(2 * 96 * 96))]])
+        done = t % 17 == 16
+        state = [[obs() if (rng.rand() < 0.8 and not done) else None for _ in range(2)]]
+        for tr in tracker.update_step_completed([[float(rng.randn()), float(rng.randn())]], state, done)[0]:
+            dev_buf.push(*tr)
+            host_buf.push(*tr)
+            pushed += 1
+        if done:
+            tracker = TransitionTracker([[obs(), obs()]])
+    assert pushed > cap and len(dev_buf) == len(host_buf) == cap and dev_buf.position == host_buf.position
+    # aliasing: at most one slot per live observation (<= cap + robots), far below the 2 * cap of the two-ring layout
+    assert dev_buf.observations_resident <= cap + 4
+    for seed in (1, 2):
+        random.seed(seed)
+        hb = host_buf.sample(8)
+        random.seed(seed)
+        db = dev_buf.sample(8)
+        ref = assemble_batch(hb, torch.device('cuda'))
+        assert torch.equal(db.state, ref.state) and torch.equal(db.next_state, ref.next_state)
+        assert torch.equal(db.action, ref.action) and torch.equal(db.reward, ref.reward)
+        assert db.non_final_mask == ref.non_final_mask and torch.equal(db.nonfinal_pos, ref.nonfinal_pos)
+    # independent arrays (no aliasing) exhaust a pool sized for aliasing -> loud error, not silent corruption
+    small = AliasedDeviceReplayBuffer(8, C, pool_slots=9)
+    with pytest.raises(Exception, match="pool exhausted"):
+        for _ in range(8):
+            small.push(obs(), 0, 0.0, obs())
