@@ -254,8 +254,9 @@ int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
     if (bm == 288 && bn == 128) {
         if (const char* e = getenv("SIMQ_BF16_DBG")) {
             const int v = atoi(e);
-#define SIMQ_DBG(N) if (v == N) return run<288, 128, 2, 8, N>(a, stream); if (v == 100 + N) return run<288, 128, 2, 4, N>(a, stream)
-            SIMQ_DBG(0); SIMQ_DBG(1); SIMQ_DBG(2); SIMQ_DBG(3); SIMQ_DBG(5); SIMQ_DBG(7); SIMQ_DBG(8); SIMQ_DBG(16); SIMQ_DBG(23); SIMQ_DBG(32);
+#define SIMQ_DBG(N) if (v == N) return run<288, 128, 2, 8, N>(a, stream)
+            SIMQ_DBG(1); SIMQ_DBG(2); SIMQ_DBG(8); SIMQ_DBG(16); SIMQ_DBG(23); SIMQ_DBG(32);
+            if (v == 100) return run<288, 128, 2, 4, 0>(a, stream);      // four-wave variant (wave tile 144 x 64)
 #undef SIMQ_DBG
         }
         return run<288, 128, 2, 8>(a, stream);

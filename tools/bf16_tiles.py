@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """GPU tuning aid: run the bf16 implicit-GEMM forward of one layer shape under every tile of the menus (kernel names
 carry the tile, so `rocprofv3 --kernel-trace` + tools/rocprof_summary.py gives the per-tile kernel time; tools/bt.sh wraps
-that).  BF16_DBGS="0 16 23 32 ..." additionally runs the timing ablations of the LDS-DMA kernel (SIMQ_BF16_DBG bit mask:
-1 no DMA, 2 no barrier, 4 no vmcnt wait, 8 no fragment reads, 16 no MFMA, 32 epilogue only; +100 = four-wave variant)."""
+that).  BF16_DBGS="1 2 8 16 23 32 100" additionally runs the timing ablations of the LDS-DMA kernel (SIMQ_BF16_DBG bit mask:
+1 no DMA, 2 no barrier, 8 no fragment reads, 16 no MFMA, 23 fragment reads only, 32 epilogue only; 100 = four-wave variant)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
