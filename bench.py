@@ -28,6 +28,10 @@ for _p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# multi-process GPU work on this ROCm stack needs dmabuf IPC (RCCL / cross-process tensor sharing); keep whatever the
+# launcher exported, default to the supported mode otherwise -- must be in the environment before the HIP runtime starts
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
