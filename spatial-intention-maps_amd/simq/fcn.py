@@ -328,7 +328,8 @@ class FCN(torch.nn.Module):
         if self.training:
             raise SimqError('infer_argmax: the net must be in eval mode (policies.py:56)')
         # a device tensor [1,96,96,C] is taken as is (DQNIntentionPolicy hands over state + predicted map in HBM)
-        x = state_hwc if torch.is_tensor(state_hwc) else torch.from_numpy(state_hwc).unsqueeze(0).to(self.device_)
+        x = state_hwc if torch.is_tensor(state_hwc) else \
+            torch.from_numpy(np.ascontiguousarray(state_hwc, dtype=np.float32)).unsqueeze(0).to(self.device_)
         q = self.forward_nhwc(x)
         a = self.argmax(q[0])
         return (a, q[0].cpu().numpy()) if need_q else (a, None)

@@ -83,12 +83,44 @@ def assemble_batch(batch, device):
     return DeviceBatch(state, action, reward, next_state, pos, mask)
 
 
+class _DeviceObs:
+    """One observation resident in an HBM ring slot, standing where the reference keeps the ndarray itself
+    (`random.choice(replay_buffers[i].buffer).state`, train.py:294): converts to the [96,96,C] float32 array on demand
+    (np.asarray / slicing), and to its slot number for the index gathers."""
+    __slots__ = ('store', 'slot')
+
+    def __init__(self, store, slot):
+        self.store, self.slot = store, int(slot)
+
+    def __index__(self):
+        return self.slot
+
+    __int__ = __index__
+
+    @property
+    def shape(self):
+        return tuple(self.store.shape[1:])
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.store[self.slot].cpu().numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, key):
+        return self.__array__()[key]
+
+    def copy(self):
+        return self.__array__()
+
+    def __repr__(self):
+        return '_DeviceObs(slot=%d, shape=%s)' % (self.slot, self.shape)
+
+
 class DeviceReplayBuffer:
     """ReplayBuffer (train.py:28-45) with the states in an HBM ring.
 
     push(state, action, reward, next_state) / sample(B) / len() / .position as in the reference;
-    `.buffer` is a list of lightweight Transition records whose state fields are ring slot
-    numbers.  Sampling draws `random.sample(range(len), B)` -- the same picks the reference's
+    `.buffer` is a list of Transition records whose state fields are _DeviceObs handles (ring slot +
+    on-demand ndarray view, so `random.choice(buf.buffer).state` of train.py:294 still yields the observation).  Sampling draws `random.sample(range(len), B)` -- the same picks the reference's
     `random.sample(self.buffer, B)` makes under the same seed (golden: tests/golden/sampler.npz).
     """
 
@@ -109,7 +141,8 @@ class DeviceReplayBuffer:
         self.states[slot].copy_(torch.as_tensor(state), non_blocking=True)
         if next_state is not None:
             self.next_states[slot].copy_(torch.as_tensor(next_state), non_blocking=True)
-        self.buffer[slot] = Transition(slot, int(action), float(reward), slot if next_state is not None else None)
+        self.buffer[slot] = Transition(_DeviceObs(self.states, slot), int(action), float(reward),
+                                       _DeviceObs(self.next_states, slot) if next_state is not None else None)
         self.position = (self.position + 1) % self.capacity
 
     def push_many(self, states, actions, rewards, next_states, terminal):
@@ -123,7 +156,8 @@ class DeviceReplayBuffer:
         self.states[s0:s0 + n].copy_(torch.as_tensor(states))
         self.next_states[s0:s0 + n].copy_(torch.as_tensor(next_states))
         for i in range(n):
-            self.buffer.append(Transition(s0 + i, int(actions[i]), float(rewards[i]), None if terminal[i] else s0 + i))
+            self.buffer.append(Transition(_DeviceObs(self.states, s0 + i), int(actions[i]), float(rewards[i]),
+                                          None if terminal[i] else _DeviceObs(self.next_states, s0 + i)))
         self.position = (s0 + n) % self.capacity
 
     def __len__(self):
@@ -137,11 +171,11 @@ class DeviceReplayBuffer:
         B = len(recs)
         dev = self.device
         st = stream_ptr(dev)
-        index = torch.tensor([r.state for r in recs], dtype=torch.int64).to(dev, non_blocking=True)
+        index = torch.tensor([int(r.state) for r in recs], dtype=torch.int64).to(dev, non_blocking=True)
         state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
         lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
         mask = [r.next_state is not None for r in recs]
-        nf = [r.next_state for r in recs if r.next_state is not None]
+        nf = [int(r.next_state) for r in recs if r.next_state is not None]
         if not nf:
             raise SimqError('sample: no non-final next state in the batch (train.py:112 would raise)')
         nindex = torch.tensor(nf, dtype=torch.int64).to(dev, non_blocking=True)
@@ -242,10 +276,11 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
             n_slot = self._upload(next_state)
             self._ref[n_slot] += 1
         if old is not None:                                  # the ring wrapped: the overwritten transition lets go
-            self._release(old.state)
+            self._release(int(old.state))
             if old.next_state is not None:
-                self._release(old.next_state)
-        self.buffer[self.position] = Transition(s_slot, int(action), float(reward), n_slot)
+                self._release(int(old.next_state))
+        self.buffer[self.position] = Transition(_DeviceObs(self.pool, s_slot), int(action), float(reward),
+                                                None if n_slot is None else _DeviceObs(self.pool, n_slot))
         self.position = (self.position + 1) % self.capacity
 
     def push_many(self, states, actions, rewards, next_states, terminal):

@@ -227,3 +227,36 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
     spec = ofcn.state_spec(cin, cout)
     rows = np.asarray([[float(sd[k].double().sum()), float(sd[k].double().norm())] for k, _, kind in spec if ofcn.is_parameter(kind)])
     assert np.abs(rows[:, 1] - g['param_summary_after2'][:, 1]).max() <= 1e-4 * g['param_summary_after2'][:, 1].max()
+
+
+@pytest.mark.parametrize('intention', [False, True], ids=['dqn', 'intention'])
+def test_reference_style_main_loop_on_synthetic_env(simq_mod, tmp_path, intention):
+    """train.py:main (:181-346) on the drop-ins with a synthetic environment (tools/train_synthetic.py): step, tracker,
+    aliased device replay, train / train_intention, target sync, the train.py:294 debug path, checkpoints and resume."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('train_synthetic', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tools', 'train_synthetic.py'))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    cfg = ts.default_cfg(use_predicted_intention=intention, num_input_channels=5 if intention else 4,
+                         robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}] if intention else [{'lifting_robot': 2}],
+                         total_timesteps=36)
+    policy, log, policy_path, checkpoint_path = ts.run(cfg, str(tmp_path), verbose=False)
+    assert len(log) >= 8
+    keys = {'td_error', 'loss'} | ({'loss_intention'} if intention else set())
+    assert all(set(info) == keys and all(np.isfinite(v) for v in info.values()) for _, _, info in log)
+    # resume: the policy checkpoint loads into fresh nets (policies.py:25-33), the optimizer state into fresh optimizers
+    cfg2 = ts.default_cfg(**{**vars(cfg), 'checkpoint_path': checkpoint_path, 'policy_path': policy_path, 'total_timesteps': 36})
+    Policy = simq_mod.DQNIntentionPolicy if intention else simq_mod.DQNPolicy
+    resumed = Policy(cfg2, train=True)
+    for a, b in zip(policy.policy_nets, resumed.policy_nets):
+        assert torch.equal(a.flat_params, b.flat_params) and torch.equal(a.bn_buffers, b.bn_buffers)
+        assert a.num_batches_tracked == b.num_batches_tracked and b.training
+    if intention:
+        for a, b in zip(policy.intention_nets, resumed.intention_nets):
+            assert torch.equal(a.flat_params, b.flat_params)
+    ck = torch.load(checkpoint_path, weights_only=False)
+    opt = torch.optim.SGD(resumed.policy_nets[0].parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt.load_state_dict(ck['optimizers'][0])
+    assert len(opt.state) > 0

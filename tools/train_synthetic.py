@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""The reference's training loop (train.py:main, :181-346) on the simq drop-ins, with a synthetic stand-in for the
+pybullet environment (random 96x96xC observations, random rewards, robots that finish their actions at random times).
+
+It exists to exercise the drop-in surface end to end on an MI355X: DQNPolicy / DQNIntentionPolicy.step, TransitionTracker,
+(Aliased)DeviceReplayBuffer.push / sample, train, train_intention, target sync through state_dict, the Q-map debug path
+of train.py:294-296, policy + optimizer checkpoints and resume.  Not a benchmark (bench.py is)."""
+import argparse
+import os
+import random
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import simq  # noqa: E402
+from simq import arch  # noqa: E402
+
+
+class SyntheticEnv:
+    """reset() -> state ; step(action) -> (state, reward, done, info) with the nested [group][robot] lists of envs.py."""
+
+    def __init__(self, robot_config, channels, seed, episode_len=25):
+        self.groups = [next(iter(g.values())) for g in robot_config]
+        self.C, self.rng, self.episode_len, self.t = channels, np.random.RandomState(seed), episode_len, 0
+
+    def _obs(self):
+        return self.rng.rand(arch.STATE_WIDTH, arch.STATE_WIDTH, self.C).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        return [[self._obs() for _ in range(n)] for n in self.groups]
+
+    def step(self, action):
+        self.t += 1
+        done = self.t >= self.episode_len
+        state = [[self._obs() if (self.rng.rand() < 0.7 and not done) else None for _ in range(n)] for n in self.groups]
+        if not done and all(s is None for g in state for s in g):
+            state[0][0] = self._obs()
+        reward = [[float(np.clip(self.rng.randn(), -1.5, 2.0)) for _ in range(n)] for n in self.groups]
+        return state, reward, done, {'steps': self.t}
+
+
+def run(cfg, checkpoint_dir, verbose=True):
+    env = SyntheticEnv(cfg.robot_config, cfg.num_input_channels, seed=cfg.seed)
+    num_robot_groups = len(cfg.robot_config)
+    Policy = simq.DQNIntentionPolicy if cfg.use_predicted_intention else simq.DQNPolicy
+    policy = Policy(cfg, train=True, random_seed=cfg.seed)                                            # train.py:181
+    sgd = lambda net: torch.optim.SGD(net.parameters(), lr=cfg.learning_rate, momentum=0.9, weight_decay=cfg.weight_decay)
+    optimizers = [sgd(n) for n in policy.policy_nets]                                                # train.py:184-186
+    optimizers_intention = [sgd(n) for n in policy.intention_nets] if cfg.use_predicted_intention else None
+    replay_buffers = [simq.AliasedDeviceReplayBuffer(cfg.replay_buffer_size, cfg.num_input_channels)
+                      for _ in range(num_robot_groups)]                                               # train.py:193-195
+    start_timestep = 0
+    if cfg.checkpoint_path is not None:                                                               # train.py:200-211
+        checkpoint = torch.load(cfg.checkpoint_path, weights_only=False)
+        start_timestep = checkpoint['timestep']
+        for i in range(num_robot_groups):
+            optimizers[i].load_state_dict(checkpoint['optimizers'][i])
+    target_nets = policy.build_policy_nets()                                                          # train.py:213-216
+    for i in range(num_robot_groups):
+        target_nets[i].load_state_dict(policy.policy_nets[i].state_dict())
+        target_nets[i].eval()
+    state = env.reset()
+    tracker = simq.TransitionTracker(state)
+    learning_starts = int(round(cfg.learning_starts_frac * cfg.total_timesteps))
+    total = learning_starts + cfg.total_timesteps
+    log = []
+    for timestep in range(start_timestep, total):
+        eps = 1 - (1 - cfg.final_exploration) * min(1, max(0, timestep - learning_starts) / (cfg.exploration_frac * cfg.total_timesteps))
+        if cfg.use_predicted_intention:                                                               # train.py:229-233
+            gt = max(0, timestep - learning_starts) / cfg.total_timesteps <= cfg.use_predicted_intention_frac
+            action = policy.step(state, exploration_eps=eps, use_ground_truth_intention=gt)
+        else:
+            action = policy.step(state, exploration_eps=eps)
+        tracker.update_action(action)
+        state, reward, done, info = env.step(action)
+        for i, transitions in enumerate(tracker.update_step_completed(reward, state, done)):         # train.py:241-244
+            for transition in transitions:
+                replay_buffers[i].push(*transition)
+        if done:
+            state = env.reset()
+            tracker = simq.TransitionTracker(state)
+        if timestep >= learning_starts and (timestep + 1) % cfg.train_freq == 0:                      # train.py:252-264
+            for i in range(num_robot_groups):
+                if len(replay_buffers[i]) < cfg.batch_size:
+                    continue
+                batch = replay_buffers[i].sample(cfg.batch_size)
+                info_i = simq.train(cfg, policy.policy_nets[i], target_nets[i], optimizers[i], batch, policy.apply_transform,
+                                    cfg.discount_factors[i])
+                if cfg.use_predicted_intention:
+                    info_i.update(simq.train_intention(policy.intention_nets[i], optimizers_intention[i], batch, policy.apply_transform))
+                log.append((timestep + 1, i, info_i))
+                if verbose:
+                    print('t=%d group %d %s' % (timestep + 1, i, {k: round(v, 4) for k, v in info_i.items()}))
+        if (timestep + 1) % cfg.target_update_freq == 0:                                              # train.py:267-269
+            for i in range(num_robot_groups):
+                target_nets[i].load_state_dict(policy.policy_nets[i].state_dict())
+        if done and timestep >= learning_starts and all(len(b) for b in replay_buffers):             # train.py:292-296
+            random_state = [[random.choice(replay_buffers[i].buffer).state] for i in range(num_robot_groups)]
+            _, dbg = policy.step(random_state, debug=True)       # _DeviceObs handles convert on demand
+            assert all(dbg['output'][i][0].shape[-2:] == (arch.STATE_WIDTH, arch.STATE_WIDTH) for i in range(num_robot_groups))
+    os.makedirs(checkpoint_dir, exist_ok=True)                                                        # train.py:312-336
+    policy_path = os.path.join(checkpoint_dir, 'policy_%08d.pth.tar' % total)
+    policy_checkpoint = {'timestep': total, 'state_dicts': [n.state_dict() for n in policy.policy_nets]}
+    if cfg.use_predicted_intention:
+        policy_checkpoint['state_dicts_intention'] = [n.state_dict() for n in policy.intention_nets]
+    torch.save(policy_checkpoint, policy_path)
+    checkpoint_path = os.path.join(checkpoint_dir, 'checkpoint_%08d.pth.tar' % total)
+    torch.save({'timestep': total, 'episode': 0, 'optimizers': [o.state_dict() for o in optimizers]}, checkpoint_path)
+    return policy, log, policy_path, checkpoint_path
+
+
+def default_cfg(**over):
+    cfg = types.SimpleNamespace(
+        robot_config=[{'lifting_robot': 2}], num_input_channels=4, use_predicted_intention=False, use_predicted_intention_frac=0.5,
+        final_exploration=0.01, exploration_frac=0.5, learning_starts_frac=0.25, total_timesteps=40, train_freq=2,
+        target_update_freq=10, batch_size=8, replay_buffer_size=64, learning_rate=0.01, weight_decay=1e-4,
+        grad_norm_clipping=100, use_double_dqn=True, discount_factors=[0.75, 0.75], checkpoint_path=None, policy_path=None, seed=0)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--timesteps', type=int, default=40)
+    ap.add_argument('--intention', action='store_true')
+    ap.add_argument('--out', default='/tmp/simq_synthetic')
+    a = ap.parse_args()
+    c = default_cfg(total_timesteps=a.timesteps, use_predicted_intention=a.intention,
+                    num_input_channels=5 if a.intention else 4,
+                    robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}] if a.intention else [{'lifting_robot': 2}])
+    _, lg, pp, cp = run(c, a.out)
+    print('%d training calls; saved %s and %s' % (len(lg), pp, cp))
