@@ -85,7 +85,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
 
-    auto load_tile = [&](auto set_c, int r0) {   // rows >= rend read zeros (byte offset 0xFFFFFFFF is out of bounds)
+    // pixel decomposition of the rows this lane loads from x (VEC path), for the first tile; load_tile advances it
+    int xb[VEC ? X_PASSES_V : 1], xoy[VEC ? X_PASSES_V : 1], xox[VEC ? X_PASSES_V : 1];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int ps = 0; ps < X_PASSES_V; ++ps) {
+            const int r = rbeg + (tid + 256 * ps) / (TJ / 4);
+            xb[ps] = r / hw;
+            const int rem = r - xb[ps] * hw;
+            xoy[ps] = rem / p.Wout;
+            xox[ps] = rem - xoy[ps] * p.Wout;
+        }
+    }
+    auto load_tile = [&](auto set_c, int r0) {   // rows >= rend read zeros; calls must advance r0 by BR each time (byte offset 0xFFFFFFFF is out of bounds)
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int ps = 0; ps < Y_PASSES; ++ps) {
@@ -102,13 +114,16 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                 const int idx = tid + 256 * ps;
                 const int row = idx / (TJ / 4), c4 = idx - row * (TJ / 4);
                 const int r = r0 + row;
-                const int b = r / hw, rem = r - b * hw;
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                // (image, oy, ox) of this lane's row advance by BR pixels per call: carried in registers (xb/xoy/xox) instead
+                // of two integer divisions per load
+                const int iy = xoy[ps] * p.stride - p.pad + ky, ix = xox[ps] * p.stride - p.pad + kx;
                 const bool ok = (X_F4 % 256 == 0 || idx < X_F4) && r < rend && (unsigned)iy < (unsigned)p.Hin &&
                                 (unsigned)ix < (unsigned)p.Win;
-                const unsigned voff = ok ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c4 * 4) * 4u : 0xFFFFFFFFu;
+                const unsigned voff = ok ? (unsigned)(((xb[ps] * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c4 * 4) * 4u : 0xFFFFFFFFu;
                 vx[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
+                xox[ps] += BR;
+                while (xox[ps] >= p.Wout) { xox[ps] -= p.Wout; ++xoy[ps]; }
+                if (xoy[ps] >= p.Hout) { xoy[ps] -= p.Hout; ++xb[ps]; }
             }
         } else {
 #pragma unroll

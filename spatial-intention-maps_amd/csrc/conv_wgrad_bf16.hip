@@ -87,7 +87,16 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const WgradBfArgs p) {
         xr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x[pl]), 0, p.x_bytes, 0x00020000);
         yr[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.dy[pl]), 0, p.dy_bytes, 0x00020000);
     }
-    auto load_tile = [&](auto set_c, int r0) {   // r0 >= rend: everything reads zeros
+    int xb[X_PASSES], xoy[X_PASSES], xox[X_PASSES];   // pixel decomposition of the x rows this lane loads (first tile)
+#pragma unroll
+    for (int ps = 0; ps < X_PASSES; ++ps) {
+        const int r = rbeg + (tid + 256 * ps) / X_LANES;
+        xb[ps] = r / hw;
+        const int rem = r - xb[ps] * hw;
+        xoy[ps] = rem / p.Wout;
+        xox[ps] = rem - xoy[ps] * p.Wout;
+    }
+    auto load_tile = [&](auto set_c, int r0) {   // r0 >= rend: everything reads zeros; calls must advance r0 by BRB
         constexpr int SET = decltype(set_c)::value;
 #pragma unroll
         for (int ps = 0; ps < Y_PASSES; ++ps) {
@@ -105,14 +114,16 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const WgradBfArgs p) {
             const int idx = tid + 256 * ps;
             const int row = idx / X_LANES, c8 = idx - row * X_LANES;
             const int r = r0 + row;
-            const int b = r / hw, rem = r - b * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+            // (image, oy, ox) of this lane's row are carried in registers and advanced by BRB pixels per call
+            const int iy = xoy[ps] * p.stride - p.pad + ky, ix = xox[ps] * p.stride - p.pad + kx;
             const bool ok = (X_V % 256 == 0 || idx < X_V) && r < rend && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            const unsigned voff = ok ? (unsigned)(((b * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c8 * 8) * 2u : 0xFFFFFFFFu;
+            const unsigned voff = ok ? (unsigned)(((xb[ps] * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c8 * 8) * 2u : 0xFFFFFFFFu;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
                 vx[SET][pl][ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr[pl], voff, 0, 0));
+            xox[ps] += BRB;
+            while (xox[ps] >= p.Wout) { xox[ps] -= p.Wout; ++xoy[ps]; }
+            if (xoy[ps] >= p.Hout) { xoy[ps] -= p.Hout; ++xb[ps]; }
         }
     };
     auto store_tile = [&](auto set_c, int buf) {
