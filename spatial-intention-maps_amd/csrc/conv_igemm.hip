@@ -47,8 +47,9 @@ struct IgemmArgs {
     unsigned x_bytes, w_bytes;   // sizes of x / w for the bounds-checked buffer loads
 };
 
+// occupancy target: tiles up to 96x128 run 3 blocks per CU (LDS 44.5 KB each); the register budget is held to the 168 that allows
 template <int BM, int BN, bool VEC>
-__global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
+__global__ void __launch_bounds__(256, (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave (2x2 waves)
     constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK;
@@ -104,15 +105,28 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
     // pass the bounds test
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-    int rpix[VEC ? A_PASSES_V : 1], riy[VEC ? A_PASSES_V : 1], rix[VEC ? A_PASSES_V : 1];
+    // VEC: per row of this thread, the byte offset of tap (0,0) / channel 0 and the bit mask of the filter taps that fall
+    // inside the image (R*S <= 32; rows past M have an empty mask) -- a K-step then costs one add, one mask test and one
+    // select per load instead of re-deriving the input coordinates
+    unsigned abase[VEC ? A_PASSES_V : 1], amask[VEC ? A_PASSES_V : 1], bbase[VEC ? B_PASSES_V : 1];
     if constexpr (VEC) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES_V; ++ps) {
             const int r = lrow + 64 * ps;
             int4 ri = (BM % 64 == 0 || r < BM) ? rowinfo[r] : make_int4(0, 0, 0, 0);
-            rpix[ps] = ri.x;
-            riy[ps] = ri.w ? ri.y : -(1 << 20);
-            rix[ps] = ri.z;
+            abase[ps] = (unsigned)(((ri.x + ri.y * p.Win + ri.z) * p.Cin + kq * 4) * 4);
+            unsigned mk = 0u;
+            if (ri.w)
+                for (int t = 0; t < p.R * p.S; ++t) {
+                    const int ty = t / p.S, tx = t - ty * p.S;
+                    if ((unsigned)(ri.y + ty) < (unsigned)p.Hin && (unsigned)(ri.z + tx) < (unsigned)p.Win) mk |= 1u << t;
+                }
+            amask[ps] = mk;
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES_V; ++ps) {
+            const int n = lrow + 64 * ps;
+            bbase[ps] = (BN % 64 == 0 || n < BN) ? (unsigned)(((n0 + n) * p.K + kq * 4) * 4) : 0xFFFFFFFFu;
         }
     }
 
@@ -121,17 +135,16 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(const IgemmArgs p) {
         if constexpr (VEC) {
             // branch-free: out-of-image taps / ragged rows get byte offset 0xFFFFFFFF, which the buffer bounds
             // check turns into a zero fill
+            const unsigned soff_a = (unsigned)(((ky * p.Win + kx) * p.Cin + c0) * 4), soff_b = (unsigned)((tap * p.Cin + c0) * 4);
+            const unsigned bit = live ? (1u << tap) : 0u;
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
-                const int iy = riy[ps] + ky, ix = rix[ps] + kx;
-                const bool ok = live && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                const unsigned voff = ok ? (unsigned)((rpix[ps] + iy * p.Win + ix) * p.Cin + c0 + kq * 4) * 4u : 0xFFFFFFFFu;
+                const unsigned voff = (amask[ps] & bit) ? abase[ps] + soff_a : 0xFFFFFFFFu;
                 va[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
-                const int n = lrow + 64 * ps;
-                const unsigned voff = (live && (BN % 64 == 0 || n < BN)) ? (unsigned)((n0 + n) * p.K + tap * p.Cin + c0 + kq * 4) * 4u : 0xFFFFFFFFu;
+                const unsigned voff = (live && bbase[ps] != 0xFFFFFFFFu) ? bbase[ps] + soff_b : 0xFFFFFFFFu;
                 vb[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, 0, 0));
             }
         } else {
@@ -335,7 +348,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     SIMQ_REQUIRE(g.Cout % 32 == 0, "conv_igemm: Cout=%d must be a multiple of 32", g.Cout);
-    const bool vec = (g.Cin % BK) == 0;
+    const bool vec = (g.Cin % BK) == 0 && g.R * g.S <= 32;   // vector path: 16-channel chunks, tap validity kept as a 32-bit mask
     SIMQ_REQUIRE(vec || g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);
     int bm = 0, bn = 0;
     if (!forced_tile(&bm, &bn) || g.Cout % bn != 0 || (!vec && !(bn == 64 && (bm == 128 || bm == 64 || bm == 32)))) {
