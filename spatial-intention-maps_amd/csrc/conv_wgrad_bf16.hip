@@ -45,7 +45,7 @@ __device__ __forceinline__ int rsw(int r) {
 // occupancy target 3 waves per SIMD: without it the compiler spreads into AGPRs (118 + 92 registers, 2 waves); measured +2 % on
 // the bf16 step.  (4 or 5 waves spill; the fp32 wgrad kernel measured no gain from a 4-wave target.)
 template <int TI, int TJ, int NP>
-__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const WgradBfArgs p) {
+__global__ void __launch_bounds__(256, NP == 1 ? 3 : 2) wgrad_bf16_kernel(const WgradBfArgs p) {
     constexpr int NI = TI / 32, NJ = TJ / 32;
     static_assert(NI >= 1 && NJ >= 1, "tile must be a multiple of 32");
     constexpr int YROW = TI * 2, XROW = TJ * 2;                       // bytes per pixel row
