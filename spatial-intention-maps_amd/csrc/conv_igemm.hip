@@ -47,16 +47,20 @@ struct IgemmArgs {
     unsigned x_bytes, w_bytes;   // sizes of x / w for the bounds-checked buffer loads
 };
 
-// occupancy target: tiles up to 96x128 run 3 blocks per CU (LDS 44.5 KB each); the register budget is held to the 168 that allows
+// occupancy target: tiles up to 96x128 run 3 blocks per CU (LDS 43 KB each), up to 96x64 five (30.7 KB); the register budget is
+// held to what that allows (168 / 96)
 template <int BM, int BN, bool VEC>
-__global__ void __launch_bounds__(256, (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
+__global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave (2x2 waves)
     constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK;
     constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
-    // one LDS object: [2 stages of A|B] [row info int4 x BM]
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS + 4 * BM];
-    int4* rowinfo = reinterpret_cast<int4*>(smem + 2 * STAGE_FLOATS);
+    // one LDS object: [2 stages of A|B] [row info int4 x BM].  The vector path only needs the row info in its prologue
+    // (it ends up in registers as offsets + tap masks), so there it aliases stage 1, which is first written behind the
+    // second barrier -- 96x64 then fits 5 blocks per CU (30.7 KB) instead of 4.
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS + (VEC ? 0 : 4 * BM)];
+    static_assert(!VEC || STAGE_FLOATS >= 4 * BM, "row info must fit in one stage");
+    int4* rowinfo = reinterpret_cast<int4*>(smem + (VEC ? STAGE_FLOATS : 2 * STAGE_FLOATS));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
