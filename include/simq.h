@@ -146,6 +146,28 @@ int simq_clip_sgd_step(float* d_params, float* d_grads, float* d_momentum, int64
 int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* d_index, int count,
                        float* d_out, void* stream);
 
+/* ---- the whole TD step in one call (reference train.train, train.py:108-141, lines 114-135) -------------------------------
+ * Policy forward (train-mode BN) on `state`; double DQN: policy forward (train mode, no grad) on `next_state` + argmax, target
+ * forward (eval) + gather -- vanilla DQN: target forward + max; scatter into the bootstrap vector, TD target + Huber + dLoss/dQ
+ * (scaled by 1/global_batch), backward, global-norm clip + momentum SGD, refresh of the policy weight cache.  Exactly the
+ * launches simq.learner.train_step issues, sequenced by the library.  All pointers are device memory owned by the caller; both
+ * weight caches must be current on entry (simq_weights_prepare).  side_stream (may be NULL): the target forward runs there,
+ * fork/join by events.  Results: out4[0] = sum of Huber terms, out4[1] = sum of |td| over this rank's batch; q_sa, y, td per
+ * transition; *total_norm = pre-clip gradient norm.  Single-process form (no gradient all-reduce between backward and SGD). */
+typedef struct simq_train_args {
+    const simq_plan* plan;
+    int batch, num_nonfinal, global_batch, use_double_dqn, first_step, reserved_;
+    float gamma, lr, momentum, weight_decay, max_norm, reserved2_;
+    float* params; void* wcache; float* bnbuf; float* grads; float* momentum_buf; void* ws_train; void* ws_tmp;   /* policy */
+    const float* t_params; const void* t_wcache; float* t_bnbuf; void* t_ws;                                      /* target */
+    const float* state; const float* next_state; const int64_t* action; const float* reward; const int32_t* nonfinal_pos;
+    float* q; float* q_next; float* q_tgt; float* dq;               /* [batch|num_nonfinal][Cout*96*96] scratch / outputs */
+    float* nsv; float* vals; int64_t* best; float* q_sa; float* y; float* td; float* out4;
+    void* opt_scratch; float* total_norm;
+    void* stream; void* side_stream;
+} simq_train_args;
+int simq_train_step(const simq_train_args* a);
+
 /* ---- intention-prediction head (train_intention, train.py:143-158; step_intention, policies.py:97-117) ----------
  * simq_bce_with_logits: nn.BCEWithLogitsLoss() ('mean') over n logits vs targets; *d_loss_sum (double) receives the SUM
  *   (host divides by n), d_dlogits (may be NULL) the gradient (sigmoid(x) - t) / n.

@@ -651,6 +651,49 @@ int simq_backward(const simq_plan* plan, int batch, const float* d_params, const
     return simq_backward_phase(plan, batch, d_params, d_wcache, d_dq, d_grads, d_workspace, 0, stream);
 }
 
+int simq_train_step(const simq_train_args* a) {
+    SIMQ_REQUIRE(a && a->plan, "train_step: NULL argument");
+    SIMQ_REQUIRE(a->params && a->wcache && a->bnbuf && a->grads && a->momentum_buf && a->ws_train && a->ws_tmp && a->t_params &&
+                 a->t_wcache && a->t_bnbuf && a->t_ws && a->state && a->next_state && a->action && a->reward && a->nonfinal_pos &&
+                 a->q && a->q_tgt && a->dq && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
+                 "train_step: NULL buffer");
+    SIMQ_REQUIRE(!a->use_double_dqn || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
+    SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= 1 && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
+                 "train_step: batch=%d num_nonfinal=%d global_batch=%d", a->batch, a->num_nonfinal, a->global_batch);
+    const simq_plan* p = a->plan;
+    hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
+    const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (side && !ev_fork) {
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read
+    if (side) {
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side ? side : main));
+    if (side) SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
+    RC(simq_forward(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main));          // train.py:114
+    if (a->use_double_dqn) {                                                                                          // train.py:119-122
+        RC(simq_forward(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, main));
+        RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, main));
+        if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
+    } else {                                                                                                          // train.py:124
+        if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(launch_q_argmax(a->q_tgt, Nn, n, nullptr, a->vals, main));
+    }
+    RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
+    RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
+                       a->out4, a->dq, main));                                                                       // train.py:115,126-129
+    RC(simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, 0, main));                      // train.py:131-132
+    RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
+                       a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
+    return simq_weights_prepare(p, a->params, a->wcache, main);
+}
+
 int64_t simq_grad_bucket_split(const simq_plan* plan) { return plan ? plan->blocks[kPhaseSplitBlock].c1.w_off : -1; }
 
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream) {

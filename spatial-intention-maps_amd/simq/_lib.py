@@ -30,6 +30,20 @@ if not os.path.exists(LIB_PATH):
 
 _c = ctypes.CDLL(LIB_PATH)
 
+class TrainArgs(ctypes.Structure):
+    """simq_train_args of include/simq.h (the whole TD step in one library call)."""
+    _fields_ = [('plan', c_void_p),
+                ('batch', c_int), ('num_nonfinal', c_int), ('global_batch', c_int), ('use_double_dqn', c_int), ('first_step', c_int),
+                ('reserved_', c_int),
+                ('gamma', c_float), ('lr', c_float), ('momentum', c_float), ('weight_decay', c_float), ('max_norm', c_float),
+                ('reserved2_', c_float)] + [(n, c_void_p) for n in (
+                    'params', 'wcache', 'bnbuf', 'grads', 'momentum_buf', 'ws_train', 'ws_tmp',
+                    't_params', 't_wcache', 't_bnbuf', 't_ws',
+                    'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
+                    'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream')]
+
+
 _SIGS = {
     'simq_version': (c_int, []),
     'simq_last_error': (c_char_p, []),
@@ -51,6 +65,7 @@ _SIGS = {
     'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_backward_phase': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_grad_bucket_split': (c_int64, [c_void_p]),
+    'simq_train_step': (c_int, [c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_scatter_next_values': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

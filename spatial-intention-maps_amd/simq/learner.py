@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import arch, dist as sdist
-from ._lib import MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD, SimqError, lib, ptr, stream_ptr
+from ._lib import MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD, SimqError, TrainArgs, lib, ptr, stream_ptr
 from .fcn import FCN
 
 Transition = namedtuple('Transition', ('state', 'action', 'reward', 'next_state'))   # train.py:26
@@ -293,6 +293,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
 
 
 _SIDE_STREAMS = {}
+FUSED_LIBRARY_STEP = True       # single-process steps go through ONE library call (simq_train_step) instead of ~15 ctypes calls
 OVERLAP_TARGET_FORWARD = True    # run the (independent) target-net forward on a side stream; bench.py turns it off
                                  # for its per-kernel HIP-event pass, where concurrent kernels would share the GPU
 
@@ -371,6 +372,10 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     n = policy_net.num_output_channels * W * W
     st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
 
+    if process_group is None and FUSED_LIBRARY_STEP:
+        return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
+                                 use_double_dqn, st_opt, sync)
+
     # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes:
     # it runs on a side stream so its blocks fill the CUs that the tail of each policy-net kernel leaves idle.
     main = torch.cuda.current_stream(dev)
@@ -425,6 +430,59 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     st_opt.initialised = True
     policy_net.weights_dirty = True      # parameters moved: the next forward refreshes the derived weight cache
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q}
+    if not sync:
+        return out4
+    o = out4.tolist()                                                       # train.py:138-139 (.item() host sync)
+    return {'td_error': o[1] / gB, 'loss': o[0] / gB}
+
+
+def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
+                      use_double_dqn, st_opt, sync):
+    """train_step through simq_train_step: the same launches in the same order, sequenced inside the library."""
+    dev = policy_net.device_
+    B, Nn = b.state.shape[0], b.next_state.shape[0]
+    n = policy_net.num_output_channels * W * W
+    for t, c in ((b.state, policy_net.num_input_channels), (b.next_state, policy_net.num_input_channels)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[1:]) != (W, W, c):
+            raise SimqError('train: states must be contiguous fp32 [B,%d,%d,%d] (NHWC), got %s' % (W, W, c, tuple(t.shape)))
+    policy_net._ensure_weights()
+    target_net._ensure_weights()
+    f32 = dict(dtype=torch.float32, device=dev)
+    q, q_tgt, dq = torch.empty((B, n), **f32), torch.empty((Nn, n), **f32), torch.empty((B, n), **f32)
+    q_next = torch.empty((Nn, n), **f32) if use_double_dqn else None
+    best = torch.empty(Nn, dtype=torch.int64, device=dev) if use_double_dqn else None
+    vec = torch.empty(5 * B + 4, **f32)
+    nsv, vals, q_sa, y, td, out4 = vec[:B], vec[B:2 * B], vec[2 * B:3 * B], vec[3 * B:4 * B], vec[4 * B:5 * B], vec[5 * B:]
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else None
+    a = TrainArgs()
+    a.plan = policy_net.plan.handle
+    a.batch, a.num_nonfinal, a.global_batch = B, Nn, gB
+    a.use_double_dqn, a.first_step = int(bool(use_double_dqn)), 0 if st_opt.initialised else 1
+    a.gamma, a.lr, a.momentum, a.weight_decay = float(discount_factor), lr, momentum, weight_decay
+    a.max_norm = float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0
+    tensors = dict(params=policy_net.flat_params, wcache=policy_net.wcache, bnbuf=policy_net.bn_buffers, grads=policy_net.flat_grads,
+                   momentum_buf=st_opt.momentum, ws_train=policy_net._workspace('train', B), ws_tmp=policy_net._workspace('tmp', Nn),
+                   t_params=target_net.flat_params, t_wcache=target_net.wcache, t_bnbuf=target_net.bn_buffers,
+                   t_ws=target_net._workspace('tmp', Nn), state=b.state, next_state=b.next_state, action=b.action, reward=b.reward,
+                   nonfinal_pos=b.nonfinal_pos, q=q, q_next=q_next, q_tgt=q_tgt, dq=dq, nsv=nsv, vals=vals, best=best, q_sa=q_sa,
+                   y=y, td=td, out4=out4, opt_scratch=st_opt.scratch, total_norm=st_opt.total_norm)
+    for k, t in tensors.items():
+        setattr(a, k, None if t is None else t.data_ptr())
+    a.stream = main.cuda_stream
+    a.side_stream = side.cuda_stream if side is not None else None
+    import ctypes
+    lib.call('simq_train_step', ctypes.byref(a))
+    if side is not None:
+        q_tgt.record_stream(side)
+    # bookkeeping the separate calls do on the Python side
+    policy_net._train_generation += 1
+    for k in policy_net.num_batches_tracked:
+        policy_net.num_batches_tracked[k] += 2 if use_double_dqn else 1
+    policy_net.weights_dirty = False          # the library refreshed the weight cache behind the SGD update
+    policy_net._weights_stamp += 1
+    st_opt.initialised = True
+    policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q.view(B, policy_net.num_output_channels, W, W)}
     if not sync:
         return out4
     o = out4.tolist()                                                       # train.py:138-139 (.item() host sync)

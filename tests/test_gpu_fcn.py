@@ -439,3 +439,29 @@ def test_aliased_device_replay_buffer(simq_mod):
     with pytest.raises(Exception, match="pool exhausted"):
         for _ in range(8):
             small.push(obs(), 0, 0.0, obs())
+
+
+@pytest.mark.parametrize('double_dqn', [True, False], ids=['double', 'vanilla'])
+def test_library_fused_step_equals_composed_step(simq_mod, double_dqn):
+    """simq_train_step (one C call) against the same launches issued one by one from Python (the data-parallel form):
+    loss / td / q_sa / TD targets identical, parameters after two steps equal up to the atomics' summation order."""
+    import simq.learner as sl
+    cin, cout, B = 4, 2, 6
+    batch = cases.make_batch(cin, cout, B, 123)
+    res = []
+    for fused in (True, False):
+        policy, target = make_net(simq_mod, cin, cout, 61, True), make_net(simq_mod, cin, cout, 62, False)
+        old = sl.FUSED_LIBRARY_STEP
+        sl.FUSED_LIBRARY_STEP = fused
+        try:
+            infos = [sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                                   use_double_dqn=double_dqn) for _ in range(2)]
+        finally:
+            sl.FUSED_LIBRARY_STEP = old
+        res.append((infos, policy._last['q_sa'].clone(), policy._last['y'].clone(), policy.flat_params.clone(),
+                    policy.bn_buffers.clone(), dict(policy.num_batches_tracked)))
+    (ia, qa, ya, pa, ba, na), (ib, qb, yb, pb, bb, nb) = res
+    assert abs(ia[0]['loss'] - ib[0]['loss']) <= 1e-6 * abs(ib[0]['loss']) and abs(ia[0]['td_error'] - ib[0]['td_error']) <= 1e-6 * abs(ib[0]['td_error'])
+    assert abs(ia[1]['loss'] - ib[1]['loss']) <= 2e-2 * abs(ib[1]['loss'])        # second step sees the (atomics-ordered) first update
+    assert na == nb and all(v == (4 if double_dqn else 2) for v in na.values())
+    assert rel(pa, pb) < 1e-3 and rel(ba, bb) < 1e-3
