@@ -64,6 +64,20 @@ def test_argument_errors_are_reported_not_thrown(L):
     plan = L.Plan(4, 2)
     assert L.lib.c.simq_forward(plan.handle, 1, 2, None, None, None, None, None, None, None) != 0
     assert 'NULL' in L.last_error()
+    # every entry point validates before it launches anything (no GPU in this tier): status codes + messages, no exceptions
+    assert L.lib.c.simq_backward(plan.handle, 2, None, None, None, None, None, None) != 0 and 'NULL' in L.last_error()
+    assert L.lib.c.simq_train_step(None) != 0 and 'NULL' in L.last_error()
+    args = L.TrainArgs()
+    args.plan = plan.handle
+    args.batch, args.num_nonfinal, args.global_batch = 4, 4, 4
+    assert L.lib.c.simq_train_step(ctypes.byref(args)) != 0 and 'NULL buffer' in L.last_error()
+    assert L.lib.c.simq_bce_with_logits(None, None, 10, None, None, None) != 0 and 'bad argument' in L.last_error()
+    assert L.lib.c.simq_split_last_channel(None, None, None, 10, 1, None) != 0
+    assert L.lib.c.simq_clip_sgd_step(None, None, None, 0, 1.0, 0.1, 0.9, 0.0, 1, None, None, None) != 0
+    assert L.lib.c.simq_weights_prepare(plan.handle, None, None, None) != 0
+    h2 = ctypes.c_void_p()
+    assert L.lib.c.simq_plan_create_ex(4, 2, 7, ctypes.byref(h2)) != 0 and 'precision' in L.last_error()
+    assert L.lib.c.simq_workspace_bytes(plan.handle, 32) > L.lib.c.simq_workspace_bytes(plan.handle, 1) > 0
 
 
 def test_product_never_imports_oracle():
