@@ -371,6 +371,10 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     st = stream_ptr(dev)
     n = policy_net.num_output_channels * W * W
     st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
+    # the next-state forwards see a different number of non-final samples every step: size their workspaces for the whole
+    # batch once, so that no step re-allocates gigabytes when it draws fewer terminal transitions than any step before
+    policy_net._workspace('tmp', B)
+    target_net._workspace('tmp', B)
 
     if process_group is None and FUSED_LIBRARY_STEP:
         return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
