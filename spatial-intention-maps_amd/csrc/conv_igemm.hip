@@ -304,12 +304,15 @@ int run(const IgemmArgs& a, hipStream_t stream) {
 // The 256 CUs share nothing, so the launch time is (max blocks on one CU) x (time of one block).  Pick the
 // (BM, BN) of the menu that minimises  ceil(blocks / 256) * BM * BN / efficiency(BM, BN):  bigger tiles reuse
 // operands better, but a block count that is not a multiple of 256 leaves CUs idle in the last round.
-struct TileCfg { int bm, bn; float eff; };
-// relative per-tile efficiency, measured on the 512-channel 3x3 layer (tools/tune_conv.py; 96x128 = 1): the 128x128 tile
-// needs 182 registers (2 waves per SIMD) and trails, so large batches must not drift to it once quantisation stops mattering
+// relative per-tile efficiency, measured on the 512-channel 3x3 layer (tools/tune_conv.py).  `eff`: a few blocks per CU
+// (B = 32: M = 18432) -- the 96x128 tile (3 resident blocks) leads; `eff_many`: >= 8 blocks per CU (B >= 64), where the
+// narrower tiles with 4-6 resident blocks per CU take over (128x64 reaches 140.7 TF/s = 0.89 of the fp32 matrix peak).  The
+// 128x128 tile needs 182 registers (2 waves per SIMD) and trails in both regimes.
+struct TileCfg { int bm, bn; float eff, eff_many; };
 constexpr TileCfg kMenu[] = {
-    {96, 128, 1.00f}, {96, 64, 0.96f}, {64, 64, 0.95f}, {64, 128, 0.92f}, {128, 64, 0.88f}, {128, 32, 0.86f},
-    {64, 32, 0.86f},  {32, 64, 0.86f}, {96, 32, 0.84f}, {128, 128, 0.75f}, {32, 32, 0.72f},
+    {96, 128, 1.00f, 0.934f}, {96, 64, 0.96f, 0.984f}, {64, 64, 0.95f, 0.974f}, {64, 128, 0.92f, 0.959f}, {128, 64, 0.88f, 1.00f},
+    {128, 32, 0.86f, 0.915f}, {64, 32, 0.86f, 0.877f},  {32, 64, 0.86f, 0.854f}, {96, 32, 0.84f, 0.882f}, {128, 128, 0.75f, 0.70f},
+    {32, 32, 0.72f, 0.75f},
 };
 constexpr int kNumCU = 256;
 
@@ -364,7 +367,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
             if (!vec && !(t.bn == 64 && (t.bm == 128 || t.bm == 64 || t.bm == 32))) continue;
             const long blocks = (long)((a.M + t.bm - 1) / t.bm) * (g.Cout / t.bn);
             const long rounds = (blocks + kNumCU - 1) / kNumCU;
-            double cost = (double)rounds * t.bm * t.bn / t.eff;
+            double cost = (double)rounds * t.bm * t.bn / (rounds >= 8 ? t.eff_many : t.eff);
             if (rounds == 1) cost *= 1.25;      // a lone block per CU cannot hide its barriers behind another block
             if (cost < best) { best = cost; bm = t.bm; bn = t.bn; }
         }
