@@ -663,10 +663,18 @@ int simq_train_step(const simq_train_args* a) {
     const simq_plan* p = a->plan;
     hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
     const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (side && !ev_fork) {
-        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    // fork / join events, one pair per device and host thread (events belong to the device they were created on)
+    static thread_local hipEvent_t ev_pairs[64][2] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (side) {
+        int dev = 0;
+        SIMQ_CHECK_HIP(hipGetDevice(&dev));
+        SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+        if (!ev_pairs[dev][0]) {
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][0], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][1], hipEventDisableTiming));
+        }
+        ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1];
     }
     // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read
     if (side) {
