@@ -8,7 +8,7 @@ context / stream table.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
 import torch  # noqa: F401  (must precede the CDLL: shares the HIP runtime)
 

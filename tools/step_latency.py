@@ -3,7 +3,7 @@
 import os, sys, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
-import numpy as np, torch
+import torch
 import simq
 from simq import synth
 for prec in ('fp32', 'bf16'):
