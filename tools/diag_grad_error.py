@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import torch
 import simq
-from simq import synth, arch
+from simq import synth
 from oracle import cases, fcn as ofcn, learner as ol
 
 name, cin, cout, B, wseed, dseed = cases.TRAIN_CASES[int(sys.argv[1]) if len(sys.argv) > 1 else 0]
