@@ -11,6 +11,7 @@
 // compared with the reduction) and combined with hardware fp32 atomics into the
 // zero-initialised gradient buffer.  Loads are bounds-checked buffer loads (no branches, zero
 // fill for padding / ragged ends) issued two reduction steps ahead of the MFMAs.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -239,10 +240,14 @@ int run(const WgradArgs& a, hipStream_t stream) {
     int splits = 1;
     double best = 1e300;
     for (int s = 1; s <= max_splits; ++s) {
+        // blocks per CU share the matrix pipe, so time ~ (blocks per CU) x (steps per block + fixed cost); one or two blocks
+        // per CU cannot hide their own barriers / load latency (measured utilisation ~0.6 / ~0.85 of three resident blocks)
         const long rounds = ((long)tiles * s + 255) / 256;
-        const double cost = (double)rounds * ((rsteps + s - 1) / s + 6);
+        const double util = rounds == 1 ? 0.6 : rounds == 2 ? 0.85 : 1.0;
+        const double cost = (double)rounds * ((rsteps + s - 1) / s + 6) / util;
         if (cost < best * 0.999) { best = cost; splits = s; }
     }
+    if (const char* e = getenv("SIMQ_WGRAD_SPLITS")) splits = atoi(e);   // tuning aid (tools/wgrad_splits.py)
     int rps = (p.M + splits - 1) / splits;
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;
