@@ -105,7 +105,7 @@ def pmc_traffic(precision):
         return None
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        return round(t['igemm_conv_kernel<96, 128, true>']['bytes_per_launch'])
+        return round(t['igemm_conv_kernel<96, 64, true>']['bytes_per_launch'])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -239,16 +239,16 @@ def main():
         dt_inst = time.perf_counter() - t1
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
-        dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # igemm_conv_kernel<96,128> (fp32)
+        dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # igemm_conv_kernel<96,64> (fp32)
         wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}
         oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # every other implicit-GEMM tile
         allg = {k: dom[k] + oth[k] for k in dom}
-        # the dominant KERNEL of the fp32 workload is the 96x128 instantiation; the other precisions report all tiles
+        # the dominant KERNEL of the fp32 workload is the 96x64 instantiation; the other precisions report all tiles
         ig = dom if (args.precision == 'fp32' and dom['launches'] > 0) else allg
         ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
         ach_all = allg['flops'] / (allg['ms'] * 1e-3) / 1e12 if allg['ms'] > 0 else 0.0
         PEAK = PEAK_FP32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
-        kname = {'fp32': 'igemm_conv_kernel<96,128,true> (implicit-GEMM conv forward + dgrad of the 512-channel layers, v_mfma_f32_16x16x4_f32)',
+        kname = {'fp32': 'igemm_conv_kernel<96,64,true> (implicit-GEMM conv forward + dgrad of the 256- and 512-channel layers, v_mfma_f32_16x16x4_f32)',
                  'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
                            'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
                  'bf16': 'igemm_bf16_kernel<NP=1> (bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16)'}[args.precision]

@@ -202,7 +202,7 @@ int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w
 int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of the GEMM-class launches ----------------
- * Between start and stop every implicit-GEMM launch (forward + dgrad; kind 0: the fp32 96x128 tile that dominates the
+ * Between start and stop every implicit-GEMM launch (forward + dgrad; kind 0: the fp32 96x64 tile that dominates the
  * headline workload, kind 2: every other tile / precision) and every wgrad launch (kind 1) is
  * bracketed by hipEventRecord on its own stream.  stop() fills, per kind (max_kinds >= 3 to see all),
  * {launches, total ms, total algorithmic flops (2*M*N*K), total algorithmic bytes}.  Not thread-safe. */
