@@ -1,6 +1,6 @@
 """Diagnostic (GPU): per-layer forward error of a precision mode vs the fp64 oracle (and the fp32 oracle's own error)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import torch
 import simq

@@ -1,6 +1,6 @@
 """Diagnostic (GPU): per-tensor gradient error of the HIP path and of the fp32 oracle, both vs the fp64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import torch
 import simq

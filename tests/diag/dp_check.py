@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """GPU check of the data-parallel TD step: run under
-   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py [--backend gloo]
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tests/diag/dp_check.py [--backend gloo]
 Every rank runs simq.learner.train_step on its shard (per-rank BN statistics, 1/global_batch loss scaling, one flat
 all-reduce); rank 0 compares the all-reduced gradient, the loss and rank-0's running statistics with the single-process
 sharded emulation of the oracle (oracle.learner.dp_emulation)."""
 import argparse, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import numpy as np
 import torch

@@ -5,11 +5,11 @@ Parity bars (BASELINE.json north_star + SURVEY section 0):
     vs the fp32 oracle AND vs the golden vectors written from the imported reference;
   * gradients / post-step weights: train-mode BN backward of a one-hot upstream gradient cancels
     catastrophically and every ReLU whose pre-activation is within round-off of 0 flips its mask
-    (tools/diag_grad_error.py: one flipped element in the head is a 1e-4 error everywhere below it),
+    (tests/diag/diag_grad_error.py: one flipped element in the head is a 1e-4 error everywhere below it),
     so the reference's OWN fp32 gradient is only 3e-4..2e-2 accurate vs fp64
     (tests/golden/train_*.npz: ref_fp32_grad_relerr; which implementation is luckier varies per
     batch: on the three fixture batches the reference-fp32 / HIP-fp32 errors are 3.4e-4 / 8.0e-3,
-    1.8e-2 / 4.6e-4 and 2.1e-3 / 1.5e-4 -- tools/diag_grad_error.py).  The HIP gradient is therefore
+    1.8e-2 / 4.6e-4 and 2.1e-3 / 1.5e-4 -- tests/diag/diag_grad_error.py).  The HIP gradient is therefore
     judged against the fp64 oracle with ONE bar for the whole fp32 class: global relative L2 error
     <= 5e-2 (2.5 x the worst error of the reference's own fp32); the per-kernel backward ops are held
     to 1e-4 in test_gpu_ops.py, where no such conditioning is involved.
@@ -308,7 +308,7 @@ def test_target_sync_and_checkpoint_format(simq_mod, tmp_path):
 # ---- matrix-core precisions ---------------------------------------------------------------------------------------
 # Opt-in arithmetic modes of the 3x3 / 1x1 convolutions (the default 'fp32' is the exact one held to 1e-4 above):
 #   'bf16x3'  split-bf16 (v = hi + lo, 3 MFMA products, fp32 accumulate): ~10x the round-off of true fp32
-#             (tools/diag_fwd_error.py: eval Q-map 1.7e-5 vs 2.4e-6).  Bars: Q / loss / td <= 3e-4 (train-mode BN on
+#             (tests/diag/diag_fwd_error.py: eval Q-map 1.7e-5 vs 2.4e-6).  Bars: Q / loss / td <= 3e-4 (train-mode BN on
 #             2-4 samples amplifies it to ~1e-4), gradients <= max(100 x reference-fp32 error, 5e-2) vs fp64.
 #   'bf16'    plain bf16 operands (BASELINE configs 3 and 5), bf16-class bars: Q-map <= 5e-2
 #             (max-normalised), loss / td-error within 15 % on these 4-8 sample batches, gradients <= 0.5.
