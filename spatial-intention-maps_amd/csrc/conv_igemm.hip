@@ -35,7 +35,9 @@ namespace simq {
 namespace {
 
 constexpr int BK = 16;
-constexpr int LDK = 24;  // padded row stride (floats): 96 B -> conflict-free ds_read_b128 for the 16x16x4 fragment
+constexpr int LDK = 16;  // LDS rows are exactly one K-step (64 B); the 16-B slots of a row are XOR-swizzled by row bits so that
+                         // the 16 rows x 1 slot (and the mixed-slot lane groups) of a ds_read_b128 fragment load hit 16 distinct slots
+__device__ __forceinline__ int lds_sw(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }   // {0,2,3,1}[(row >> 2) & 3]
 
 struct IgemmArgs {
     const float* x;
@@ -47,8 +49,9 @@ struct IgemmArgs {
     unsigned x_bytes, w_bytes;   // sizes of x / w for the bounds-checked buffer loads
 };
 
-// occupancy target: tiles up to 96x128 run 3 blocks per CU (LDS 43 KB each), up to 96x64 five (30.7 KB); the register budget is
-// held to what that allows (168 / 96)
+// occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
+// (168 / 96).  (Six waves for 96x64 compile to 78 registers without spilling but lose the software pipeline: 1445 vs 1737 tr/s;
+// four for 96x128 spill.)  LDS is not the limit: 20.5 KB (96x64) / 28.7 KB (96x128) per block with unpadded swizzled rows.
 template <int BM, int BN, bool VEC>
 __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
@@ -178,18 +181,18 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
 #pragma unroll
             for (int ps = 0; ps < A_PASSES_V; ++ps) {
                 const int r = lrow + 64 * ps;
-                if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(As + r * LDK + kq * 4) = va[SET][ps];
+                if (BM % 64 == 0 || r < BM) *reinterpret_cast<float4*>(As + r * LDK + ((kq ^ lds_sw(r)) << 2)) = va[SET][ps];
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_V; ++ps) {
                 const int n = lrow + 64 * ps;
-                if (BN % 64 == 0 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + kq * 4) = vb[SET][ps];
+                if (BN % 64 == 0 || n < BN) *reinterpret_cast<float4*>(Bs + n * LDK + ((kq ^ lds_sw(n)) << 2)) = vb[SET][ps];
             }
         } else {
 #pragma unroll
-            for (int ps = 0; ps < A_PASSES_S; ++ps) As[(srow + 16 * ps) * LDK + kl] = sa[SET][ps];
+            for (int ps = 0; ps < A_PASSES_S; ++ps) As[(srow + 16 * ps) * LDK + ((((kl >> 2) ^ lds_sw(srow + 16 * ps)) << 2) | (kl & 3))] = sa[SET][ps];
 #pragma unroll
-            for (int ps = 0; ps < B_PASSES_S; ++ps) Bs[(srow + 16 * ps) * LDK + kl] = sb[SET][ps];
+            for (int ps = 0; ps < B_PASSES_S; ++ps) Bs[(srow + 16 * ps) * LDK + ((((kl >> 2) ^ lds_sw(srow + 16 * ps)) << 2) | (kl & 3))] = sb[SET][ps];
         }
     };
     auto advance = [&]() {   // VEC: next K-tile position (tap inner, channel chunk outer)
@@ -212,10 +215,10 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
         const float* Bs = As + A_FLOATS;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            af[SET][i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / 2) + i * 16 + fi) * LDK + fq * 4);
+            af[SET][i] = *reinterpret_cast<const floatx4*>(As + (wm * (BM / 2) + i * 16 + fi) * LDK + ((fq ^ lds_sw(wm * (BM / 2) + i * 16 + fi)) << 2));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            bf[SET][j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / 2) + j * 16 + fi) * LDK + fq * 4);
+            bf[SET][j] = *reinterpret_cast<const floatx4*>(Bs + (wn * (BN / 2) + j * 16 + fi) * LDK + ((fq ^ lds_sw(wn * (BN / 2) + j * 16 + fi)) << 2));
     };
     auto mfma_step = [&](auto set_c) {
         constexpr int SET = decltype(set_c)::value;
