@@ -48,6 +48,7 @@ struct ConvEpilogue {
     // dgrad only: fused reduction of the NEXT BatchNorm backward (sum dz, sum dz*xhat with dz = out * (mask > 0)),
     // optionally against a second (downsample-branch) BN that shares the mask.  See igemm_epilogue.h.
     const float* bnr_mask = nullptr;
+    const uint16_t* bnr_mask16 = nullptr;   // the same mask as a bf16 plane (used when bnr_mask is NULL)
     const float* bnr_y1 = nullptr; const float* bnr_mean1 = nullptr; const float* bnr_invstd1 = nullptr; double* bnr_red1 = nullptr;
     const float* bnr_y2 = nullptr; const float* bnr_mean2 = nullptr; const float* bnr_invstd2 = nullptr; double* bnr_red2 = nullptr;
 };
@@ -102,7 +103,7 @@ int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float*
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
-                    int C, hipStream_t stream, Planes pl = Planes());
+                    int C, hipStream_t stream, Planes pl = Planes(), Planes res_pl = Planes());
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
                          hipStream_t stream, Planes pl = Planes());
@@ -115,7 +116,8 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 // dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
-                        float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes());
+                        float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes(),
+                        const uint16_t* mask16 = nullptr);
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);

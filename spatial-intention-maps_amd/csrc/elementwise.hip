@@ -85,6 +85,16 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 // optional bf16 plane outputs (hi = bf16(v), lo = bf16(v - hi)) for the matrix-core convolution paths
 __device__ __forceinline__ uint16_t to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 __device__ __forceinline__ float from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+// read 4 values back from bf16 planes (hi [+ lo]); mask form: > 0 of a bf16 value == positive non-zero as int16
+__device__ __forceinline__ float4 ld_planes(const Planes& pl, size_t i4) {
+    const ushort4 h = *reinterpret_cast<const ushort4*>(pl.hi + i4 * 4);
+    float4 v = make_float4(from_bf16(h.x), from_bf16(h.y), from_bf16(h.z), from_bf16(h.w));
+    if (pl.lo) {
+        const ushort4 l = *reinterpret_cast<const ushort4*>(pl.lo + i4 * 4);
+        v.x += from_bf16(l.x); v.y += from_bf16(l.y); v.z += from_bf16(l.z); v.w += from_bf16(l.w);
+    }
+    return v;
+}
 __device__ __forceinline__ void st_planes(const Planes& pl, size_t i4, float4 v) {
     if (!pl.hi) return;
     ushort4 h = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
@@ -100,7 +110,9 @@ __device__ __forceinline__ float4 relu4(float4 a) {
 }
 
 // out = [relu]( y*scale+shift [+ res | + res*rscale+rshift] ), one float4 per thread-iteration
-__global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const float* __restrict__ res, BnRef rbn, int has_rbn,
+// res / res_pl: the residual as fp32 or (matrix-core precisions, where the fp32 copy of a block activation is not kept) as its
+// bf16 planes; out may be NULL when only the planes are consumed downstream
+__global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const float* __restrict__ res, Planes res_pl, BnRef rbn, int has_rbn,
                                 int relu, float* __restrict__ out, Planes pl, size_t total4, int C4) {
     // the grid stride (gridDim*blockDim) is a multiple of C4, so a thread keeps its 4 channels: coefficients once
     const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -110,13 +122,13 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const flo
     if (has_rbn) bn_coeff4(rbn, c, rsc, rsh);
     for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         float4 v = fma4(ld4(y + i * 4), sc, sh);
-        if (res) {
-            float4 r = ld4(res + i * 4);
+        if (res || res_pl.hi) {
+            float4 r = res ? ld4(res + i * 4) : ld_planes(res_pl, i);
             if (has_rbn) r = fma4(r, rsc, rsh);
             v = add4(v, r);
         }
         if (relu) v = relu4(v);
-        st4(out + i * 4, v);
+        if (out) st4(out + i * 4, v);
         st_planes(pl, i, v);
     }
     bn_commit(bn);
@@ -248,7 +260,8 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
     }
 }
 
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+// mask / mask_pl: the ReLU output whose sign gates g, as fp32 or as its bf16 (hi) plane; dy may be NULL (planes only)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ mask, const uint16_t* __restrict__ mask16,
                                     const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
@@ -269,6 +282,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
             float4 m = ld4(mask + i * 4);
             dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
             dz.z = m.z > 0.f ? dz.z : 0.f; dz.w = m.w > 0.f ? dz.w : 0.f;
+        } else if (mask16) {
+            const ushort4 m = *reinterpret_cast<const ushort4*>(mask16 + i * 4);
+            dz.x = (short)m.x > 0 ? dz.x : 0.f; dz.y = (short)m.y > 0 ? dz.y : 0.f;
+            dz.z = (short)m.z > 0 ? dz.z : 0.f; dz.w = (short)m.w > 0 ? dz.w : 0.f;
         }
         if (dz_out) st4(dz_out + i * 4, dz);
         float4 yv = ld4(y + i * 4), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
@@ -279,7 +296,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
         o.y = ga.y * is.y * (dz.y - db[1] * inv_rows - (yv.y - mu.y) * is.y * dg[1] * inv_rows);
         o.z = ga.z * is.z * (dz.z - db[2] * inv_rows - (yv.z - mu.z) * is.z * dg[2] * inv_rows);
         o.w = ga.w * is.w * (dz.w - db[3] * inv_rows - (yv.w - mu.w) * is.w * dg[3] * inv_rows);
-        st4(dy + i * 4, o);
+        if (dy) st4(dy + i * 4, o);
         st_planes(pl, i, o);
     }
 }
@@ -398,10 +415,11 @@ int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float*
 }
 
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
-                    int C, hipStream_t stream, Planes pl) {
+                    int C, hipStream_t stream, Planes pl, Planes res_pl) {
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_apply: C=%d unsupported", C);
+    SIMQ_REQUIRE(out || pl.hi, "bn_apply: no output requested");
     size_t total4 = (size_t)rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, rbn ? *rbn : bn,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, res_pl, rbn ? *rbn : bn,
                        rbn ? 1 : 0, relu, out, pl, total4, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -445,9 +463,10 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
-                        int64_t rows, int C, hipStream_t stream, Planes pl) {
+                        int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16) {
+    SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     size_t total4 = (size_t)rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, y, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
                        gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;

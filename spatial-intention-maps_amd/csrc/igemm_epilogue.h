@@ -26,6 +26,7 @@ struct EpiArgs {
     int relu;
     // fused BN-backward reduction (dgrad launches only)
     const float* bnr_mask;
+    const uint16_t* bnr_mask16;
     const float* bnr_y1; const float* bnr_mean1; const float* bnr_invstd1; double* bnr_red1;
     const float* bnr_y2; const float* bnr_mean2; const float* bnr_invstd2; double* bnr_red2;
 };
@@ -33,7 +34,7 @@ struct EpiArgs {
 inline EpiArgs make_epi(float* y, const ConvEpilogue& e) {
     EpiArgs a;
     a.y = y; a.bias = e.bias; a.stats = e.stats; a.scale = e.scale; a.shift = e.shift; a.addend = e.addend; a.relu = e.relu;
-    a.bnr_mask = e.bnr_mask;
+    a.bnr_mask = e.bnr_mask; a.bnr_mask16 = e.bnr_mask16;
     a.bnr_y1 = e.bnr_y1; a.bnr_mean1 = e.bnr_mean1; a.bnr_invstd1 = e.bnr_invstd1; a.bnr_red1 = e.bnr_red1;
     a.bnr_y2 = e.bnr_y2; a.bnr_mean2 = e.bnr_mean2; a.bnr_invstd2 = e.bnr_invstd2; a.bnr_red2 = e.bnr_red2;
     return a;
@@ -75,7 +76,8 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.y[o] = v;
                     if (bnr) {
-                        const float dz = p.bnr_mask[o] > 0.f ? v : 0.f;
+                        const bool pos = p.bnr_mask ? p.bnr_mask[o] > 0.f : (short)p.bnr_mask16[o] > 0;
+                        const float dz = pos ? v : 0.f;
                         s0[j] += dz;
                         s1[j] += dz * ((p.bnr_y1[o] - mu1) * is1);
                         if (bnr2) { s2[j] += dz; s3[j] += dz * ((p.bnr_y2[o] - mu2) * is2); }
@@ -179,10 +181,16 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 *reinterpret_cast<floatx4*>(p.y + o) = v;
                 if (bnr) {
-                    const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
                     floatx4 dz;
+                    if (p.bnr_mask) {
+                        const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
+                        for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
+                    } else {
+                        const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
+                        dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
+                        dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
+                    }
                     const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
                     s0 += dz;
                     s1 += dz * ((y1 - mu1) * is1);

@@ -177,6 +177,7 @@ WLayout make_wlayout(const simq_plan* p) {
 struct Act {          // a tensor some convolution reads: fp32 view + (matrix-core precisions) its bf16 planes
     float* f = nullptr;
     Planes pl;
+    bool fv = true;   // the fp32 view is materialised (false: block activations of the matrix-core precisions live as planes only)
 };
 
 struct Ctx {
@@ -203,6 +204,14 @@ struct Ctx {
         return pl;
     }
     Act act(int64_t off, int64_t poff, int64_t elems) const { Act a; a.f = f(off); a.pl = planes(poff, elems); return a; }
+    // matrix-core precisions: the post-BN activations inside the residual blocks are consumed as bf16 planes only (convolution
+    // operands, residuals, ReLU masks), so their fp32 copies are neither written nor read (SIMQ_KEEP_FP32_ACT=1 keeps them,
+    // for FCN.saved_activation / tests/diag)
+    bool planes_only() const {
+        static const bool keep = getenv("SIMQ_KEEP_FP32_ACT") != nullptr || getenv("SIMQ_NO_BNR_FUSE") != nullptr;
+        return mc() && !keep;
+    }
+    Act block_act(int64_t off, int64_t poff, int64_t elems) const { Act a = act(off, poff, elems); a.fv = !planes_only(); return a; }
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
         uint16_t* base = reinterpret_cast<uint16_t*>(wc + (transposed ? W.wtpl : W.wpl));
@@ -319,7 +328,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
         const int64_t n = rows * b.planes;
-        Act a1 = c.act(o.a1, o.p_a1, n), out = c.act(o.out, o.p_out, n);
+        Act a1 = c.block_act(o.a1, o.p_a1, n), out = c.block_act(o.out, o.p_out, n);
         if (folded) {
             RC(conv_bn_folded(c, b.c1, b.b1, cur, a1.f, 24, nullptr, 1));
             const float* identity = cur.f;
@@ -332,14 +341,15 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
             continue;
         }
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
-        RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.f, rows, b.planes, c.stream, a1.pl));
+        RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.fv ? a1.f : nullptr, rows, b.planes, c.stream, a1.pl));
         RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
         if (b.has_ds) {
             RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
             const BnRef rd = bnref(c, b.bds, mode, rows);
-            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), c.f(o.yd), &rd, 1, out.f, rows, b.planes, c.stream, out.pl));
+            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), c.f(o.yd), &rd, 1, out.fv ? out.f : nullptr, rows, b.planes, c.stream, out.pl));
         } else {
-            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), cur.f, nullptr, 1, out.f, rows, b.planes, c.stream, out.pl));
+            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), cur.fv ? cur.f : nullptr, nullptr, 1, out.fv ? out.f : nullptr, rows, b.planes,
+                               c.stream, out.pl, cur.fv ? Planes() : cur.pl));
         }
         cur = out;
     }
@@ -365,11 +375,13 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 
 // BatchNorm backward (train mode) fused with the ReLU mask of the activation that followed it; dy also as planes.
 // `reduced`: the sums (red slot) were already accumulated by the epilogue of the dgrad launch that produced g.
+// `mask16`: the mask as a bf16 plane when its fp32 copy is not kept (then `mask` is NULL and the reduction was fused);
+// `dy.fv == false`: only the planes of dy are written
 int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
-           bool reduced = false) {
+           bool reduced = false, const uint16_t* mask16 = nullptr) {
     if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
-    return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.f, dz_out,
-                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl);
+    return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
+                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16);
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
@@ -439,7 +451,8 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase) {
         ConvEpilogue e;
         if (no_fuse) return e;
         const BlockL& bb = p->blocks[bi];
-        e.bnr_mask = c.f(L.blk[bi].out);
+        if (c.planes_only()) e.bnr_mask16 = c.planes(L.blk[bi].p_out, rows * bb.planes).hi;
+        else e.bnr_mask = c.f(L.blk[bi].out);
         e.bnr_y1 = c.f(L.blk[bi].y2); e.bnr_mean1 = c.aux(bb.b2, 2); e.bnr_invstd1 = c.aux(bb.b2, 3); e.bnr_red1 = c.red(bb.b2);
         if (bb.has_ds) {
             e.bnr_y2 = c.f(L.blk[bi].yd); e.bnr_mean2 = c.aux(bb.bds, 2); e.bnr_invstd2 = c.aux(bb.bds, 3); e.bnr_red2 = c.red(bb.bds);
@@ -459,16 +472,24 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase) {
         Act T0 = dyact(S[(gi + 1) & 3], 0);
         Act T1 = dyact(S[(gi + 2) & 3], 1);
         float* T2 = S[(gi + 3) & 3];
+        // planes-only mode: the BN input gradients are consumed as planes (wgrad / dgrad operands), the ReLU masks come from
+        // the activations' planes
+        const bool po = c.planes_only();
+        T0.fv = T1.fv = !po;
+        const float* m_out = po ? nullptr : c.f(o.out);
+        const float* m_a1 = po ? nullptr : c.f(o.a1);
+        const uint16_t* m16_out = po ? c.planes(o.p_out, rows * b.planes).hi : nullptr;
+        const uint16_t* m16_a1 = po ? c.planes(o.p_a1, rows * b.planes).hi : nullptr;
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
-        RC(bn_bwd(c, b.b2, G, c.f(o.out), c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse));
-        if (b.has_ds) RC(bn_bwd(c, b.bds, G, c.f(o.out), c.f(o.yd), T1, nullptr, rows, !no_fuse));
+        RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out));
+        if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out));
         RC(conv_wgrad(c, b.c2, a1, T0, 24));
         ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
         if (!no_fuse) {
-        f1.bnr_mask = c.f(o.a1); f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
+        f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1));
-        RC(bn_bwd(c, b.b1, T2, c.f(o.a1), c.f(o.y1), T0, nullptr, rows, !no_fuse));
+        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1));
         RC(conv_wgrad(c, b.c1, xin, T0, 24));
         const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {

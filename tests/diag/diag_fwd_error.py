@@ -1,5 +1,6 @@
 """Diagnostic (GPU): per-layer forward error of a precision mode vs the fp64 oracle (and the fp32 oracle's own error)."""
 import os, sys
+os.environ.setdefault("SIMQ_KEEP_FP32_ACT", "1")   # this tool reads the fp32 copies of the block activations (FCN.saved_activation)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import torch
