@@ -140,14 +140,16 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, floa
                                      uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * Ho * Wo * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int c4 = (int)(i % C4);
-        size_t r = i / C4;
+    // the grid stride (gridDim * 256) is a multiple of C4, so a thread keeps its 4 channels: BN coefficients once
+    float4 sc, sh;
+    bn_coeff4(bn, (int)((blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)C4) * 4, sc, sh);
+    // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (unsigned)C4);
+        unsigned r = i / (unsigned)C4;
         int px = (int)(r % Wo); r /= Wo;
         int py = (int)(r % Ho);
         int b = (int)(r / Ho);
-        float4 sc, sh;
-        bn_coeff4(bn, c4 * 4, sc, sh);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         uchar4 bi = make_uchar4(0, 0, 0, 0);
 #pragma unroll
@@ -179,9 +181,10 @@ __global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* _
                                      int C4) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * H * W * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int c4 = (int)(i % C4);
-        size_t r = i / C4;
+    // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (unsigned)C4);
+        unsigned r = i / (unsigned)C4;
         int x = (int)(r % W); r /= W;
         int yy = (int)(r % H);
         int b = (int)(r / H);
@@ -275,8 +278,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     }
     const float inv_rows = (float)(1.0 / (double)rows);
     size_t total4 = rows * C4;
+    // the grid stride is a multiple of C4 (256 % C4 == 0): a thread keeps its 4 channels
+    const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) % C4) * 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % C4) * 4;
         float4 dz = ld4(g + i * 4);
         if (mask) {
             float4 m = ld4(mask + i * 4);
@@ -324,9 +328,10 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
     size_t total = (size_t)B * Ho * Wo * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int c4 = (int)(i % C4);
-        size_t r = i / C4;
+    // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (unsigned)C4);
+        unsigned r = i / (unsigned)C4;
         int ox = (int)(r % Wo); r /= Wo;
         int oy = (int)(r % Ho);
         int b = (int)(r / Ho);
@@ -350,9 +355,10 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __r
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
     size_t total = (size_t)B * H * W * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int c4 = (int)(i % C4);
-        size_t r = i / C4;
+    // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        int c4 = (int)(i % (unsigned)C4);
+        unsigned r = i / (unsigned)C4;
         int ix = (int)(r % W); r /= W;
         int iy = (int)(r % H);
         int b = (int)(r / H);
@@ -427,8 +433,9 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
 
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
                          hipStream_t stream, Planes pl) {
-    SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "stem_pool: bad shape");
+    SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && 256 % (C / 4) == 0, "stem_pool: bad shape");
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    SIMQ_REQUIRE(total < 2147483648ull, "stem_pool: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, bn, pooled, idx, pl, B, H,
                        W, C / 4);
     SIMQ_CHECK_LAUNCH();
@@ -438,6 +445,7 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
                          int C, hipStream_t stream) {
     size_t total = (size_t)B * H * W * (C / 4);
+    SIMQ_REQUIRE(total < 2147483648ull, "stem_pool_bwd: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, pooled, idx, dz, B, H, W,
                        C / 4);
     SIMQ_CHECK_LAUNCH();
@@ -465,6 +473,7 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
                         int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
+    SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
                        gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4);
@@ -490,6 +499,7 @@ int launch_colsum_finish(const double* red, float* out, int C, hipStream_t strea
 int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
     size_t total = (size_t)B * 4 * H * W * (C / 4);
+    SIMQ_REQUIRE(total < 2147483648ull, "upsample2x_fwd: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out, pl, B, H, W, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -498,6 +508,7 @@ int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int 
 int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream) {
     SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
     size_t total = (size_t)B * H * W * (C / 4);
+    SIMQ_REQUIRE(total < 2147483648ull, "upsample2x_bwd: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dout, din, B, H, W, C / 4);
     SIMQ_CHECK_LAUNCH();
     return 0;

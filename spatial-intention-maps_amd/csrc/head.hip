@@ -24,12 +24,12 @@ __global__ void __launch_bounds__(256) head_conv3_fwd_kernel(const float* __rest
     const size_t ppb = blockDim.x / L;
     for (size_t pix = blockIdx.x * ppb + threadIdx.x / L; pix < total; pix += (size_t)gridDim.x * ppb) {
         float4 v = *reinterpret_cast<const float4*>(x + pix * CIN + sub * 4);
-        size_t b = pix / HW, p = pix - b * HW;
+        const unsigned b = (unsigned)pix / (unsigned)HW, p = (unsigned)pix - b * (unsigned)HW;   // 32-bit: B*HW < 2^31
         for (int co = 0; co < Cout; ++co) {
             float s = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
 #pragma unroll
             for (int o = L / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            if (sub == 0) q[(b * Cout + co) * HW + p] = s + bias[co];
+            if (sub == 0) q[((size_t)b * Cout + co) * HW + p] = s + bias[co];
         }
     }
 }
@@ -51,13 +51,13 @@ __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __rest
     const size_t total = (size_t)B * HW;
     const size_t ppb = blockDim.x / L;
     for (size_t pix = blockIdx.x * ppb + threadIdx.x / L; pix < total; pix += (size_t)gridDim.x * ppb) {
-        size_t b = pix / HW, p = pix - b * HW;
+        const unsigned b = (unsigned)pix / (unsigned)HW, p = (unsigned)pix - b * (unsigned)HW;   // 32-bit: B*HW < 2^31
         float4 v = *reinterpret_cast<const float4*>(x + pix * CIN + sub * 4);
         float4 o = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int co = 0; co < MAX_COUT; ++co) {
             if (co < Cout) {
-                float g = dq[(b * Cout + co) * HW + p];
+                float g = dq[((size_t)b * Cout + co) * HW + p];
                 o.x += g * wv[co].x; o.y += g * wv[co].y; o.z += g * wv[co].z; o.w += g * wv[co].w;
                 gw[co].x += g * v.x; gw[co].y += g * v.y; gw[co].z += g * v.z; gw[co].w += g * v.w;
                 gb[co] += g;
@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __rest
 int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, float* q, int B, int HW, int Cin, int Cout,
                           hipStream_t stream) {
     SIMQ_REQUIRE(Cin == 32 && Cout >= 1 && Cout <= MAX_COUT, "head_conv3: Cin=%d Cout=%d unsupported", Cin, Cout);
+    SIMQ_REQUIRE((size_t)B * HW < 2147483648ull, "head_conv3: too many pixels for 32-bit indexing");
     size_t blocks = ((size_t)B * HW + 31) / 32;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(head_conv3_fwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, bias, q, B, HW, Cout);
@@ -103,6 +104,7 @@ int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, flo
 int launch_head_conv3_bwd(const float* x, const float* w, const float* dq, float* dx, float* dw, float* dbias, int B,
                           int HW, int Cin, int Cout, hipStream_t stream) {
     SIMQ_REQUIRE(Cin == 32 && Cout >= 1 && Cout <= MAX_COUT, "head_conv3: Cin=%d Cout=%d unsupported", Cin, Cout);
+    SIMQ_REQUIRE((size_t)B * HW < 2147483648ull, "head_conv3: too many pixels for 32-bit indexing");
     size_t blocks = ((size_t)B * HW + 31) / 32;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(head_conv3_bwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, dq, dx, dw, dbias, B,
