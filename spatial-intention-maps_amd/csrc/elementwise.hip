@@ -454,7 +454,7 @@ int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx
 
 static int reduce_grid(int64_t rows, int C4) {
     int rowlanes = 256 / C4;
-    int64_t blocks = (rows + (int64_t)rowlanes * 8 - 1) / ((int64_t)rowlanes * 8);
+    int64_t blocks = (rows + (int64_t)rowlanes * 32 - 1) / ((int64_t)rowlanes * 32);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     return (int)blocks;

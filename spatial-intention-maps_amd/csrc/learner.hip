@@ -16,20 +16,20 @@ __device__ __forceinline__ bool better(float bv, int bi, float av, int ai) {
     return (bv > av) || (bv == av && bi < ai);
 }
 
-__global__ void __launch_bounds__(256) q_argmax_kernel(const float* __restrict__ q, int n, int64_t* index, float* maxv) {
-    __shared__ float sv[256];
-    __shared__ int si[256];
+__global__ void __launch_bounds__(1024) q_argmax_kernel(const float* __restrict__ q, int n, int64_t* index, float* maxv) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
     const float* row = q + (size_t)blockIdx.x * n;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
         float v = row[i];
         if (better(v, i, bv, bi)) { bv = v; bi = i; }
     }
     sv[threadIdx.x] = bv;
     si[threadIdx.x] = bi;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = 512; s >= 1; s >>= 1) {
         if (threadIdx.x < s) {
             float ov = sv[threadIdx.x + s];
             int oi = si[threadIdx.x + s];
@@ -230,7 +230,7 @@ int launch_sigmoid_concat(const float* state, const float* logit, float* out, fl
 
 int launch_q_argmax(const float* q, int rows, int n, int64_t* index, float* maxv, hipStream_t stream) {
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(q_argmax_kernel, dim3(rows), dim3(256), 0, stream, q, n, index, maxv);
+    hipLaunchKernelGGL(q_argmax_kernel, dim3(rows), dim3(1024), 0, stream, q, n, index, maxv);   // one 1024-thread block per Q-map
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
