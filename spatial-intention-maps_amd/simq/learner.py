@@ -380,15 +380,16 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
         return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
                                  use_double_dqn, st_opt, sync)
 
-    # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes:
-    # it runs on a side stream so its blocks fill the CUs that the tail of each policy-net kernel leaves idle.
+    # train.py:114 -- policy forward, train-mode BN, activations kept for backward
+    q = policy_net._forward_raw(b.state, MODE_TRAIN)
+    # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes: it runs
+    # on a side stream, forked behind the train-mode forward so that it overlaps the policy's next-state forward (both work
+    # on the ~29 non-final samples and fill each other's partially filled rounds of CUs).
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else main
     side.wait_stream(main)
     with torch.cuda.stream(side):
         q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
-    # train.py:114 -- policy forward, train-mode BN, activations kept for backward
-    q = policy_net._forward_raw(b.state, MODE_TRAIN)
     # train.py:116-124 -- bootstrap values of the non-final next states
     Nn = b.next_state.shape[0]
     nsv = torch.empty(B, dtype=torch.float32, device=dev)
