@@ -92,7 +92,9 @@ int64_t simq_wcache_bytes(const simq_plan* plan);
 int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_wcache, void* stream);
 
 /* Inspection aid (parity bisecting): where a saved NHWC fp32 activation lives inside the workspace after simq_forward.
- * name: "stem.conv" | "stem.pool" | "layer<1-4>.<0-1>" (BasicBlock outputs) | "head.a1" | "head.a2".              */
+ * name: "stem.conv" | "stem.pool" | "layer<1-4>.<0-1>" (BasicBlock outputs) | "head.a1" | "head.a2".
+ * In the matrix-core precisions the block outputs live as bf16 planes only; their fp32 copies are written when the
+ * environment has SIMQ_KEEP_FP32_ACT=1 (diagnostics).                                                              */
 int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems,
                           int* channels);
 
