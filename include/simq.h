@@ -118,6 +118,11 @@ int simq_backward(const simq_plan* plan, int batch, const float* d_params, const
 int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                         float* d_grads, void* d_workspace, int phase, void* stream);
 int64_t simq_grad_bucket_split(const simq_plan* plan);
+/* The same walk for the TD loss's upstream gradient in its natural one-hot form: dQ[b][d_action[b]] = clamp(d_q_sa[b] - d_y[b],
+ * -1, 1) * grad_scale and zero elsewhere (train.py:115,129) -- no dense dQ map, the head starts from B pixels.  phase as above. */
+int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const int64_t* d_action,
+                         const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads, void* d_workspace, int phase,
+                         void* stream);
 
 /* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */
 /* flat max / first-index argmax over each row of d_q [rows][n]  (train.py:121,124; policies.py:64) */
@@ -155,7 +160,8 @@ int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* 
  * launches simq.learner.train_step issues, sequenced by the library.  All pointers are device memory owned by the caller; both
  * weight caches must be current on entry (simq_weights_prepare).  side_stream (may be NULL): the target forward runs there,
  * fork/join by events.  Results: out4[0] = sum of Huber terms, out4[1] = sum of |td| over this rank's batch; q_sa, y, td per
- * transition; *total_norm = pre-clip gradient norm.  Single-process form (no gradient all-reduce between backward and SGD). */
+ * transition; *total_norm = pre-clip gradient norm.  Single-process form (no gradient all-reduce between backward and SGD).
+ * dq may be NULL: the backward then starts from the one-hot form (simq_backward_onehot) and no dense dQ map is written. */
 typedef struct simq_train_args {
     const simq_plan* plan;
     int batch, num_nonfinal, global_batch, use_double_dqn, first_step, reserved_;

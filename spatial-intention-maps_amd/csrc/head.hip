@@ -88,7 +88,56 @@ __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __rest
     }
 }
 
+// One-hot upstream gradient: the TD loss touches ONE Q-value per transition (train.py:115,129), so dLoss/dQ has exactly B
+// non-zeros.  This launch replaces the dense head_conv3_bwd + upsample2x_bwd pair (and the zero-filled dQ map) by B tiny
+// blocks: conv3 backward at the one pixel, then the bilinear x2 transpose scatters its 32 channels onto <= 4 pixels of the
+// 48x48 head activation gradient (ds1, zero on entry).  g = clamp(q_sa - y, -1, 1) * grad_scale is the Huber derivative.
+__device__ __forceinline__ void lerp2x(int o, int in_size, float scale, int& i0, int& i1, float& l0, float& l1) {
+    const float real = scale * (float)o;       // ATen upsample_bilinear2d, align_corners=True (as elementwise.hip lerp_coord)
+    i0 = (int)real;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    l0 = 1.f - l1;
+}
+
+__global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __restrict__ up2, const float* __restrict__ w3,
+                                                             const int64_t* __restrict__ action, const float* __restrict__ q_sa,
+                                                             const float* __restrict__ y, float grad_scale, float* ds1, float* dw3,
+                                                             float* db3, int Cout) {
+    constexpr int W2 = 96, W1 = 48, CIN = 32;
+    const int b = blockIdx.x, ci = threadIdx.x;
+    const int64_t a = action[b];
+    const int co = (int)(a / (W2 * W2)), p = (int)(a - (int64_t)co * W2 * W2);
+    if (co >= Cout) return;
+    const int oy = p / W2, ox = p - oy * W2;
+    const float d = q_sa[b] - y[b];
+    const float g = fminf(fmaxf(d, -1.f), 1.f) * grad_scale;
+    unsafeAtomicAdd(dw3 + co * CIN + ci, g * up2[((size_t)b * W2 * W2 + p) * CIN + ci]);
+    if (ci == 0) unsafeAtomicAdd(db3 + co, g);
+    const float dx = g * w3[co * CIN + ci];
+    const float s = (float)(W1 - 1) / (float)(W2 - 1);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    lerp2x(oy, W1, s, y0, y1, ly0, ly1);
+    lerp2x(ox, W1, s, x0, x1, lx0, lx1);
+    float* base = ds1 + (size_t)b * W1 * W1 * CIN + ci;      // this thread owns channel ci of sample b: plain read-modify-write
+    base[(y0 * W1 + x0) * CIN] += ly0 * lx0 * dx;
+    base[(y0 * W1 + x1) * CIN] += ly0 * lx1 * dx;
+    base[(y1 * W1 + x0) * CIN] += ly1 * lx0 * dx;
+    base[(y1 * W1 + x1) * CIN] += ly1 * lx1 * dx;
+}
+
 }  // namespace
+
+int launch_head_onehot_bwd(const float* up2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
+                           float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream) {
+    SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_onehot_bwd: Cout=%d unsupported", Cout);
+    SIMQ_CHECK_HIP(hipMemsetAsync(ds1, 0, sizeof(float) * (size_t)B * 48 * 48 * 32, stream));
+    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, up2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, float* q, int B, int HW, int Cin, int Cout,
                           hipStream_t stream) {

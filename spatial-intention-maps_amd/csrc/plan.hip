@@ -417,7 +417,10 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
 //   phase 1 = zero-fill, head, blocks 7..6 (layer4)      phase 2 = blocks 5..0, stem
 constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that belongs to phase 1
 
-int backward_impl(const Ctx& c, const float* d_dq, int phase) {
+// one-hot form of the upstream gradient (the TD loss): dQ[b][action[b]] = clamp(q_sa[b] - y[b], -1, 1) * grad_scale
+struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
+
+int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
     const int B = c.B;
@@ -432,8 +435,13 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase) {
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
     if (phase != 2) {
-    RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
-    RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
+    if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
+        RC(launch_head_onehot_bwd(c.f(L.up2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
+                                  c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream));
+    } else {
+        RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
+        RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
+    }
     Act dyh = dyact(S[0], 0);
     RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dyh, nullptr, (int64_t)B * 2304));
     RC(launch_colsum(S[0], cs, c.grads + p->h2.b_off, (int64_t)B * 2304, 32, c.stream));
@@ -667,6 +675,18 @@ int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params,
     return backward_impl(c, d_dq, phase);
 }
 
+int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const int64_t* d_action,
+                         const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads, void* d_workspace, int phase,
+                         void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_action && d_q_sa && d_y && d_grads && d_workspace, "backward_onehot: NULL argument");
+    SIMQ_REQUIRE(phase >= 0 && phase <= 2, "backward: bad phase %d", phase);
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
+    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
+    return backward_impl(c, nullptr, phase, &oh);
+}
+
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream) {
     return simq_backward_phase(plan, batch, d_params, d_wcache, d_dq, d_grads, d_workspace, 0, stream);
@@ -676,7 +696,7 @@ int simq_train_step(const simq_train_args* a) {
     SIMQ_REQUIRE(a && a->plan, "train_step: NULL argument");
     SIMQ_REQUIRE(a->params && a->wcache && a->bnbuf && a->grads && a->momentum_buf && a->ws_train && a->ws_tmp && a->t_params &&
                  a->t_wcache && a->t_bnbuf && a->t_ws && a->state && a->next_state && a->action && a->reward && a->nonfinal_pos &&
-                 a->q && a->q_tgt && a->dq && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
+                 a->q && a->q_tgt && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
                  "train_step: NULL buffer");
     SIMQ_REQUIRE(!a->use_double_dqn || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
     SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= 1 && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
@@ -720,7 +740,9 @@ int simq_train_step(const simq_train_args* a) {
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
-    RC(simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, 0, main));                      // train.py:131-132
+    if (a->dq) RC(simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, 0, main));           // train.py:131-132
+    else RC(simq_backward_onehot(p, B, a->params, a->wcache, a->action, a->q_sa, a->y, 1.0f / (float)a->global_batch, a->grads,
+                                 a->ws_train, 0, main));
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);

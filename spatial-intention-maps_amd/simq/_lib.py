@@ -66,6 +66,7 @@ _SIGS = {
     'simq_backward_phase': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_grad_bucket_split': (c_int64, [c_void_p]),
     'simq_train_step': (c_int, [c_void_p]),
+    'simq_backward_onehot': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_scatter_next_values': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

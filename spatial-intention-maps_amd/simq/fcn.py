@@ -249,6 +249,16 @@ class FCN(torch.nn.Module):
                  ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
         return self.flat_grads
 
+    def _backward_onehot(self, action, q_sa, y, grad_scale, batch, phase=0):
+        """Backward of the TD loss from its one-hot upstream gradient dQ[b][action[b]] = clamp(q_sa - y, -1, 1) * grad_scale
+        (no dense dQ map); same phases as _backward_raw."""
+        ws = self._ws.get('train')
+        if ws is None:
+            raise SimqError('simq.FCN: backward without a grad-mode forward')
+        lib.call('simq_backward_onehot', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(action), ptr(q_sa),
+                 ptr(y), float(grad_scale), ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
+        return self.flat_grads
+
     @property
     def grad_bucket_split(self):
         """flat_grads[split:] (head + layer4, 75 % of the bytes) is final after backward phase 1."""

@@ -411,19 +411,19 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     y = torch.empty(B, dtype=torch.float32, device=dev)
     td = torch.empty(B, dtype=torch.float32, device=dev)
     out4 = torch.empty(4, dtype=torch.float32, device=dev)
-    dq = torch.empty_like(q)
+    # (the upstream gradient stays in its one-hot form: B non-zeros, the backward walk starts from those pixels)
     lib.call('simq_td_huber', ptr(q), B, n, ptr(b.action), ptr(b.reward), ptr(nsv), float(discount_factor),
-             1.0 / gB, ptr(q_sa), ptr(y), ptr(td), ptr(out4), ptr(dq), st)
+             1.0 / gB, ptr(q_sa), ptr(y), ptr(td), ptr(out4), None, st)
     # train.py:131-132
     if process_group is None:
-        grads = policy_net._backward_raw(dq, B)
+        grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B)
     else:
         # data parallel: the all-reduce of the head + layer4 gradients (75 % of the 45 MB) is issued as soon as they are
         # final and runs on RCCL's stream while layers 3..1 + stem are still being differentiated
         split = policy_net.grad_bucket_split
-        grads = policy_net._backward_raw(dq, B, phase=1)
+        grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=1)
         work = sdist.allreduce_async(grads[split:], process_group)
-        policy_net._backward_raw(dq, B, phase=2)
+        policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=2)
         work2 = sdist.allreduce_async(grads[:split], process_group)
         work3 = sdist.allreduce_async(out4, process_group)
         for wk in (work, work2, work3):
@@ -453,7 +453,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     policy_net._ensure_weights()
     target_net._ensure_weights()
     f32 = dict(dtype=torch.float32, device=dev)
-    q, q_tgt, dq = torch.empty((B, n), **f32), torch.empty((Nn, n), **f32), torch.empty((B, n), **f32)
+    q, q_tgt, dq = torch.empty((B, n), **f32), torch.empty((Nn, n), **f32), None     # dq None: one-hot backward
     q_next = torch.empty((Nn, n), **f32) if use_double_dqn else None
     best = torch.empty(Nn, dtype=torch.int64, device=dev) if use_double_dqn else None
     vec = torch.empty(5 * B + 4, **f32)

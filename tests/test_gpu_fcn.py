@@ -465,3 +465,31 @@ def test_library_fused_step_equals_composed_step(simq_mod, double_dqn):
     assert abs(ia[1]['loss'] - ib[1]['loss']) <= 2e-2 * abs(ib[1]['loss'])        # second step sees the (atomics-ordered) first update
     assert na == nb and all(v == (4 if double_dqn else 2) for v in na.values())
     assert rel(pa, pb) < 1e-3 and rel(ba, bb) < 1e-3
+
+
+@pytest.mark.parametrize('cout', [2, 1], ids=['cout2', 'cout1'])
+def test_onehot_backward_equals_dense_backward(simq_mod, cout):
+    """simq_backward_onehot (the head starts from the B non-zero pixels of dLoss/dQ) against simq_backward on the dense
+    dQ map that simq_td_huber writes: same gradient up to fp32 summation order; border pixels (bilinear taps that coincide)
+    and both output channels are hit."""
+    from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
+    cin, B = 4, 6
+    net = make_net(simq_mod, cin, cout, 77, True)
+    x = torch.from_numpy(synth.make_states(B, cin, 5)).cuda()
+    q = net._forward_raw(x, MODE_TRAIN)
+    n = cout * 96 * 96
+    pix = [0, 95, 96 * 95, 96 * 96 - 1, 96 * 40 + 17, 96 * 3 + 94]                   # corners, edges, interior
+    action = torch.tensor([(i % cout) * 9216 + pix[i] for i in range(B)], dtype=torch.int64, device='cuda')
+    reward = torch.linspace(-1.5, 2.0, B, device='cuda')
+    nsv = torch.linspace(-0.5, 0.5, B, device='cuda')
+    outs = [torch.empty(B, device='cuda') for _ in range(3)]
+    out4 = torch.empty(4, device='cuda')
+    dq = torch.empty_like(q)
+    lib.call('simq_td_huber', ptr(q), B, n, ptr(action), ptr(reward), ptr(nsv), 0.75, 1.0 / B, ptr(outs[0]), ptr(outs[1]),
+             ptr(outs[2]), ptr(out4), ptr(dq), stream_ptr(torch.device('cuda')))
+    assert int((dq != 0).sum()) <= B
+    g_dense = net._backward_raw(dq, B).clone()
+    g_onehot = net._backward_onehot(action, outs[0], outs[1], 1.0 / B, B).clone()
+    assert rel(g_onehot, g_dense) < 1e-4
+    num = float((g_onehot.double() - g_dense.double()).norm() / g_dense.double().norm())
+    assert num < 1e-4, num
