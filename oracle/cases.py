@@ -110,3 +110,15 @@ def run_tracker(tracker_cls, seed=5):
             for (s, a, r, ns) in lst:
                 rows[i].append([float(s[0, 0, 0]), -1.0 if a is None else float(a), float(r), 0.0 if ns is None else float(ns[0, 0, 0])])
     return [np.asarray(r, dtype=np.float64).reshape(-1, 4) for r in rows]
+
+
+CKPT_CAPACITY, CKPT_CIN, CKPT_SEED = 3, 4, 77
+
+
+def checkpoint_transitions():
+    """Transitions for the checkpoint fixture (tests/golden/ref_checkpoint.pth.tar, pickled by the reference's own
+    train.ReplayBuffer): 4 pushes into a capacity-3 ring (wraps by one), next_state of one transition is the state
+    OBJECT of the following one as the collector produces them (train.py:61-66), one terminal transition."""
+    from simq import synth
+    o = list(synth.make_states(5, CKPT_CIN, CKPT_SEED))
+    return [(o[0], 11, 0.5, o[1]), (o[1], 9216 + 7, -0.25, o[2]), (o[2], 123, 1.0, None), (o[3], 18431, 0.0, o[4])]

@@ -204,6 +204,20 @@ def gen_tracker():
     print('tracker case saved: %s transitions per buffer' % [len(r) for r in rows])
 
 
+def gen_checkpoint():
+    """A checkpoint_*.pth.tar as train.py:324-334 writes it, produced with the reference's own ReplayBuffer / Transition
+    classes (pickled under the module name `train`) and a fresh torch SGD over the reference FCN (train.py:186)."""
+    buf = ref_train.ReplayBuffer(cases.CKPT_CAPACITY)
+    for t in cases.checkpoint_transitions():
+        buf.push(*t)
+    assert type(buf).__module__ == 'train' and type(buf.buffer[0]).__module__ == 'train'
+    net = ref_net(cases.CKPT_CIN, 2, cases.CKPT_SEED)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    path = os.path.join(cases.GOLDEN_DIR, 'ref_checkpoint.pth.tar')
+    torch.save({'timestep': 7, 'episode': 2, 'optimizers': [opt.state_dict()], 'replay_buffers': [buf]}, path)
+    print('checkpoint fixture saved: %d bytes' % os.path.getsize(path))
+
+
 def gen_sampler():
     out = {}
     for n, B, seed in cases.SAMPLER_CASES:
@@ -253,6 +267,6 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker}
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

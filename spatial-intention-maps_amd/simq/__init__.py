@@ -22,6 +22,10 @@ _LAZY = {
     'train_intention': ('.learner', 'train_intention'),
     'train_intention_step': ('.learner', 'train_intention_step'),
     'lib': ('._lib', 'lib'),
+    'save_policy': ('.checkpoint', 'save_policy'),
+    'save_checkpoint': ('.checkpoint', 'save_checkpoint'),
+    'load_checkpoint': ('.checkpoint', 'load_checkpoint'),
+    'resume': ('.checkpoint', 'resume'),
 }
 
 

@@ -114,3 +114,29 @@ def test_transition_tracker_matches_reference_fixture(golden_dir):
                     assert last_next.pop(key) is s
                 if ns is not None:
                     last_next[(i, float(ns[0, 0, 0]))] = ns
+
+
+def test_reference_written_checkpoint_loads_without_the_reference(golden_dir):
+    """tests/golden/ref_checkpoint.pth.tar was pickled by the reference's own train.ReplayBuffer / train.Transition
+    (oracle/gen_golden.py checkpoint; layout of train.py:324-334).  simq.load_checkpoint resolves those class names to
+    this package's: ring geometry, record order, values and the state/next_state object aliasing all survive."""
+    import sys
+    import simq
+    from simq import learner
+    from oracle import cases
+    assert 'train' not in sys.modules
+    ck = simq.load_checkpoint(os.path.join(golden_dir, 'ref_checkpoint.pth.tar'))
+    assert ck['timestep'] == 7 and ck['episode'] == 2
+    assert len(ck['optimizers'][0]['param_groups'][0]['params']) == 72 and ck['optimizers'][0]['state'] == {}
+    buf = ck['replay_buffers'][0]
+    assert type(buf) is learner.ReplayBuffer and all(type(t) is learner.Transition for t in buf.buffer)
+    tr = cases.checkpoint_transitions()
+    assert buf.capacity == cases.CKPT_CAPACITY == len(buf) and buf.position == 1
+    for got, want in zip(buf.buffer, [tr[3], tr[1], tr[2]]):                  # 4 pushes into 3 slots: slot 0 overwritten
+        assert np.array_equal(got.state, want[0]) and got.action == want[1] and got.reward == want[2]
+        assert (got.next_state is None) == (want[3] is None)
+        if want[3] is not None:
+            assert np.array_equal(got.next_state, want[3])
+    assert buf.buffer[1].next_state is buf.buffer[2].state                     # one ndarray, pickled once
+    buf.push(tr[0][0], 1, 0.0, None)                                           # and it is a working ring
+    assert buf.position == 2 and len(buf) == 3

@@ -493,3 +493,76 @@ def test_onehot_backward_equals_dense_backward(simq_mod, cout):
     assert rel(g_onehot, g_dense) < 1e-4
     num = float((g_onehot.double() - g_dense.double()).norm() / g_dense.double().norm())
     assert num < 1e-4, num
+
+
+def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_dir):
+    """SURVEY 8f row 4 (train.py:197-209, 309-346).  (1) a checkpoint pickled by the reference's own classes goes into the
+    HBM ring and samples what the host ring samples; (2) save_policy + save_checkpoint + resume() in fresh objects continue
+    the run: same picks, same losses, same weights as the uninterrupted trainer (up to the atomics' summation order)."""
+    import os
+    from simq import checkpoint as ck
+    from simq.learner import AliasedDeviceReplayBuffer, TransitionTracker, assemble_batch
+    dev = torch.device('cuda')
+    host = ck.load_checkpoint(os.path.join(golden_dir, 'ref_checkpoint.pth.tar'))['replay_buffers'][0]
+    for aliased in (True, False):
+        ring = ck.to_device_ring(host, aliased=aliased)
+        assert ring.position == host.position == 1 and len(ring) == len(host) == 3 and ring.capacity == 3
+        if aliased:
+            assert ring.observations_resident == 4            # o1, o2 (shared by two records), o3, o4
+        random.seed(4)
+        db = ring.sample(3)
+        random.seed(4)
+        ref = assemble_batch(host.sample(3), dev)
+        assert torch.equal(db.state, ref.state) and torch.equal(db.next_state, ref.next_state)
+        assert torch.equal(db.action, ref.action) and torch.equal(db.reward, ref.reward) and db.non_final_mask == ref.non_final_mask
+        back = ck.to_host_ring(ring)
+        assert back.position == 1 and all(np.array_equal(a.state, b.state) and a.action == b.action and a.reward == b.reward
+                                          for a, b in zip(back.buffer, host.buffer))
+        if aliased:
+            assert back.buffer[1].next_state is back.buffer[2].state
+
+    cin, cout, B = 4, 2, 6
+    cfg = types.SimpleNamespace(batch_size=B, use_double_dqn=True, grad_norm_clipping=100)
+    sgd = lambda net: torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    policy, target = make_net(simq_mod, cin, cout, 71, True), make_net(simq_mod, cin, cout, 71, False)
+    opt = sgd(policy)
+    rng = np.random.RandomState(8)
+    obs = lambda: rng.rand(96, 96, cin).astype(np.float32)
+    ring = AliasedDeviceReplayBuffer(16, cin)
+    tracker = TransitionTracker([[obs()]])
+    for t in range(22):                                         # wraps the 16-slot ring
+        tracker.update_action([[int(rng.randint(cout * 96 * 96))]])
+        done = t % 9 == 8
+        for tr in tracker.update_step_completed([[float(rng.randn())]], [[None if done else obs()]], done)[0]:
+            ring.push(*tr)
+        if done:
+            tracker = TransitionTracker([[obs()]])
+    random.seed(9)
+    for step in (1, 2):
+        simq_mod.train(cfg, policy, target, opt, ring.sample(B), None, 0.75)
+        ppath = ck.save_policy(tmp_path, step, [policy])
+        cpath = ck.save_checkpoint(tmp_path, step, 0, [opt], [ring])
+    assert sorted(os.path.basename(p) for p in tmp_path.iterdir()) == \
+        ['checkpoint_00000002.pth.tar', 'policy_00000001.pth.tar', 'policy_00000002.pth.tar']   # train.py:341-345
+    target.load_state_dict(policy.state_dict())                 # what a resumed run starts from (train.py:212-214)
+    rstate = random.getstate()
+    cont = [simq_mod.train(cfg, policy, target, opt, ring.sample(B), None, 0.75) for _ in range(2)]
+
+    policy2, target2 = simq_mod.FCN(cin, cout), simq_mod.FCN(cin, cout)
+    policy2.load_state_dict(torch.load(ppath, map_location=dev)['state_dicts'][0])
+    policy2.train()
+    target2.load_state_dict(policy2.state_dict())
+    target2.eval()
+    opt2 = sgd(policy2)
+    start, episode, rings = ck.resume(cpath, [opt2])
+    assert (start, episode) == (2, 0) and isinstance(rings[0], AliasedDeviceReplayBuffer)
+    assert rings[0].position == ring.position and len(rings[0]) == len(ring)
+    assert rings[0].observations_resident == ring.observations_resident
+    random.setstate(rstate)
+    again = [simq_mod.train(cfg, policy2, target2, opt2, rings[0].sample(B), None, 0.75) for _ in range(2)]
+    for a, b in zip(again, cont):
+        assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss']) and abs(a['td_error'] - b['td_error']) <= 1e-3 * abs(b['td_error'])
+    assert rel(policy2.flat_params, policy.flat_params) < 1e-3
+    # momentum = the last gradients: run-to-run noise of the atomically accumulated BN statistics, amplified by the
+    # conditioning described in this file's header (two identical runs differ by ~1e-3 here)
+    assert rel(policy2._simq_opt_state.momentum, policy._simq_opt_state.momentum) < 1e-2

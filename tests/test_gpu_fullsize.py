@@ -260,3 +260,9 @@ def test_reference_style_main_loop_on_synthetic_env(simq_mod, tmp_path, intentio
     opt = torch.optim.SGD(resumed.policy_nets[0].parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     opt.load_state_dict(ck['optimizers'][0])
     assert len(opt.state) > 0
+    # ... and the trainer itself continues from the files (train.py:197-209): rings back in HBM, timestep carried on
+    assert len(ck['replay_buffers']) == len(cfg.robot_config) and all(len(b) > 8 for b in ck['replay_buffers'])
+    cfg3 = ts.default_cfg(**{**vars(cfg2), 'total_timesteps': 44})
+    _, log3, _, checkpoint3 = ts.run(cfg3, str(tmp_path), verbose=False)
+    assert log3 and min(t for t, _, _ in log3) > 45 and all(np.isfinite(v) for _, _, info in log3 for v in info.values())
+    assert os.path.basename(checkpoint3) == 'checkpoint_00000055.pth.tar' and not os.path.exists(checkpoint_path)

@@ -56,10 +56,8 @@ def run(cfg, checkpoint_dir, verbose=True):
                       for _ in range(num_robot_groups)]                                               # train.py:193-195
     start_timestep = 0
     if cfg.checkpoint_path is not None:                                                               # train.py:200-211
-        checkpoint = torch.load(cfg.checkpoint_path, weights_only=False)
-        start_timestep = checkpoint['timestep']
-        for i in range(num_robot_groups):
-            optimizers[i].load_state_dict(checkpoint['optimizers'][i])
+        start_timestep, _, replay_buffers = simq.resume(cfg.checkpoint_path, optimizers, cfg.num_input_channels,
+                                                        optimizers_intention=optimizers_intention)
     target_nets = policy.build_policy_nets()                                                          # train.py:213-216
     for i in range(num_robot_groups):
         target_nets[i].load_state_dict(policy.policy_nets[i].state_dict())
@@ -103,14 +101,9 @@ def run(cfg, checkpoint_dir, verbose=True):
             random_state = [[random.choice(replay_buffers[i].buffer).state] for i in range(num_robot_groups)]
             _, dbg = policy.step(random_state, debug=True)       # _DeviceObs handles convert on demand
             assert all(dbg['output'][i][0].shape[-2:] == (arch.STATE_WIDTH, arch.STATE_WIDTH) for i in range(num_robot_groups))
-    os.makedirs(checkpoint_dir, exist_ok=True)                                                        # train.py:312-336
-    policy_path = os.path.join(checkpoint_dir, 'policy_%08d.pth.tar' % total)
-    policy_checkpoint = {'timestep': total, 'state_dicts': [n.state_dict() for n in policy.policy_nets]}
-    if cfg.use_predicted_intention:
-        policy_checkpoint['state_dicts_intention'] = [n.state_dict() for n in policy.intention_nets]
-    torch.save(policy_checkpoint, policy_path)
-    checkpoint_path = os.path.join(checkpoint_dir, 'checkpoint_%08d.pth.tar' % total)
-    torch.save({'timestep': total, 'episode': 0, 'optimizers': [o.state_dict() for o in optimizers]}, checkpoint_path)
+    policy_path = simq.save_policy(checkpoint_dir, total, policy.policy_nets,                         # train.py:312-345
+                                   policy.intention_nets if cfg.use_predicted_intention else None)
+    checkpoint_path = simq.save_checkpoint(checkpoint_dir, total, 0, optimizers, replay_buffers, optimizers_intention)
     return policy, log, policy_path, checkpoint_path
 
 
