@@ -218,6 +218,9 @@ int simq_profile_start(void);
 int simq_profile_stop(double* out, int max_kinds);
 /* tuning aid (tools/tune_conv.py): force the implicit-GEMM block tile BM x BN; bm = 0 restores the cost model */
 int simq_tune_force_tile(int bm, int bn);
+/* tuning aid: switch the fp32 implicit-GEMM kernel's balanced last round (K-sliced tail tiles + fix-up kernel) on (1) /
+ * off (0); default off (it pays only when the forwards run serialised), also SIMQ_TAIL_SPLIT=1 in the environment */
+int simq_tune_tail_split(int on);
 
 #ifdef __cplusplus
 }

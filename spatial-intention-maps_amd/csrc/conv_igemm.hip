@@ -25,7 +25,9 @@
 // BatchNorm (fp64 atomics of per-block partials), folded-BN affine, residual add, ReLU.
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "igemm_epilogue.h"
@@ -47,6 +49,10 @@ struct IgemmArgs {
     int M, K;
     int tilesN;
     unsigned x_bytes, w_bytes;   // sizes of x / w for the bounds-checked buffer loads
+    // balanced last round (see run()): blocks >= full_tiles each contract `kper` K-steps of tile full_tiles + (i / splits)
+    // and leave their accumulators in `partial`; igemm_tail_fixup_kernel adds the pieces and runs the epilogue
+    int full_tiles, splits, kper;
+    float* partial;
 };
 
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
@@ -69,7 +75,17 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / p.tilesN, tile_n = blockIdx.x % p.tilesN;
+    int tile = blockIdx.x, piece = -1, kbeg = 0;
+    int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
+    if constexpr (VEC) {
+        if (tile >= p.full_tiles) {                   // a K-slice of one of the last round's tiles
+            piece = tile - p.full_tiles;
+            tile = p.full_tiles + piece / p.splits;
+            kbeg = (piece % p.splits) * p.kper;
+            nk = min(nk - kbeg, p.kper);
+        }
+    }
+    const int tile_m = tile / p.tilesN, tile_n = tile % p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- row -> pixel decode, once per block (rows do not change along K) ----
@@ -95,8 +111,6 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
-
     // ---- staging registers: TWO sets, so global loads run two K-steps ahead of the MFMAs ----
     constexpr int A_PASSES_V = (BM + 63) / 64, B_PASSES_V = (BN + 63) / 64;
     constexpr int A_PASSES_S = BM / 16, B_PASSES_S = BN / 16;
@@ -108,6 +122,9 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     // VEC K order: channel chunk outer, filter tap inner -- the R*S taps of one 16-channel chunk re-read the
     // same 64-B lines of x (shifted rows), so they hit L1/L2 instead of streaming x once per tap.
     int tap = 0, c0 = 0, ky = 0, kx = 0;
+    if constexpr (VEC) {
+        if (kbeg) { tap = kbeg % (p.R * p.S); c0 = (kbeg / (p.R * p.S)) * BK; ky = tap / p.S; kx = tap - ky * p.S; }
+    }
     // VEC: this thread's rows (pixel base / top-left input coordinate) live in registers; invalid rows can never
     // pass the bounds test
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -270,7 +287,47 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     // ---- epilogue (igemm_epilogue.h); the stage buffers are idle now and serve as its reduction scratch ----
     // (the LDS-staged float4 form of igemm_epilogue.h measured 1 % slower on the whole fp32 step: other blocks of the CU
     // cover a scalar epilogue with their MFMAs, and the strip round trip adds LDS traffic)
+    if constexpr (VEC) {
+        if (piece >= 0) {                             // block-uniform: the fix-up kernel owns this tile's epilogue
+            float* dst = p.partial + (size_t)piece * (BM * BN) + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * TN + j) * 4 + r) * 256] = acc[i][j][r];
+            return;
+        }
+    }
     igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
+}
+
+// Sums the K-slices of the last round's tiles (fixed order: deterministic) and applies the epilogue the main kernel skipped.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_tail_fixup_kernel(const IgemmArgs p) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    __shared__ double red[2 * BN * 4];
+    const int tid = threadIdx.x;
+    const int tile = p.full_tiles + blockIdx.x;
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
+    floatx4 acc[TM][TN];
+    const float* src = p.partial + (size_t)blockIdx.x * p.splits * (BM * BN) + tid;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = src[((i * TN + j) * 4 + r) * 256];
+    for (int c = 1; c < p.splits; ++c) {
+        src += BM * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * TN + j) * 4 + r) * 256];
+    }
+    igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, red);
 }
 
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int taps,
@@ -286,18 +343,87 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// ---- balanced last round (opt-in: SIMQ_TAIL_SPLIT=1 / simq_tune_tail_split(1)) ----------------------------------------
+// A launch of T tiles on S = 256 CUs x (resident blocks per CU) slots runs floor(T / S) full rounds and then a partial one
+// in which T mod S blocks have the chip to themselves: a 29-sample next-state batch through a 512-channel layer is 1392
+// tiles of 96x64 on 1280 slots, i.e. 112 CUs end with ONE block (4 waves).  With this switch the tiles of that last round
+// are cut along K into `splits` slices (splits x (T mod S) <= S), which fill the slots the finished blocks of the last
+// full round free up, with 1/splits of a tile each.  Slices leave raw accumulators in a per-stream scratch (plain stores
+// in the kernel's own register order, fully coalesced); the fix-up kernel adds them in a fixed order (deterministic).
+// Measured (tools/tail_split.py): isolated launches gain +9..13 % at B = 29 and +3 % at B = 32 on the 512-channel layers;
+// the whole step LOSES 0.4 % (1782 vs 1790 tr/s, three alternating runs): the next-state forwards of the policy and the
+// target net already run concurrently on two streams and fill each other's last rounds, and at B = 32 the gain does not
+// pay for the extra launch.  Hence off by default; it is the better setting when the forwards run serialised.
+constexpr int kNumCU = 256;
+constexpr int kMaxTailSplits = 8;
+constexpr size_t kTailScratchBytes = 48u << 20;   // >= S x BM x BN x 4 for every menu tile (1536 slots x 64x64 = 25 MB, 768 x 96x128 = 38 MB)
+
+float* tail_scratch(hipStream_t stream) {
+    struct Entry { int dev; hipStream_t stream; float* ptr; };
+    static std::mutex mu;
+    static std::vector<Entry> entries;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : entries)
+        if (e.dev == dev && e.stream == stream) return e.ptr;
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, kTailScratchBytes) != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; }
+    entries.push_back({dev, stream, static_cast<float*>(ptr)});
+    return static_cast<float*>(ptr);
+}
+
+int g_tail_split = -1;   // SIMQ_TAIL_SPLIT=1 switches the balanced last round on
+
+template <int BM, int BN, bool VEC>
+int resident_blocks() {
+    static int cached = 0;
+    if (!cached) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_conv_kernel<BM, BN, VEC>, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        cached = n;
+    }
+    return cached;
+}
+
 template <int BM, int BN, bool VEC>
 int run(const IgemmArgs& a, hipStream_t stream) {
     IgemmArgs p = a;
     p.tilesN = p.Cout / BN;
     int tilesM = (p.M + BM - 1) / BM;
-    dim3 grid((unsigned)(tilesM * p.tilesN));
+    const int tiles = tilesM * p.tilesN;
+    p.full_tiles = tiles; p.splits = 1; p.kper = 0; p.partial = nullptr;
+    int tail = 0;
+    if constexpr (VEC) {
+        if (g_tail_split < 0) { const char* s = getenv("SIMQ_TAIL_SPLIT"); g_tail_split = (s && atoi(s) != 0) ? 1 : 0; }
+        const int slots = kNumCU * resident_blocks<BM, BN, VEC>();
+        const int rem = tiles % slots, nk = p.K / BK;
+        // worth it when the last round leaves a CU with one or two blocks (three or more co-resident blocks already keep the
+        // matrix pipe busy: slicing a half-full round of the 64x64 tile measured 4 % slower) and a slice still has a
+        // pipeline's worth of K-steps
+        if (g_tail_split && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
+            int s = slots / rem;
+            if (s > kMaxTailSplits) s = kMaxTailSplits;
+            while (s > 1 && nk / s < 24) --s;
+            if (s > 1 && (size_t)rem * s * BM * BN * 4 <= kTailScratchBytes && (p.partial = tail_scratch(stream)) != nullptr) {
+                p.full_tiles = tiles - rem;
+                p.splits = s;
+                p.kper = (nk + s - 1) / s;
+                tail = rem;
+            }
+        }
+    }
+    dim3 grid((unsigned)(p.full_tiles + tail * p.splits));
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant tile of the headline workload (96x64), 2 = every other implicit-GEMM tile, 1 = wgrad
     prof_launch_begin((BM == 96 && BN == 64 && VEC) ? 0 : 2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
     hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC>), grid, dim3(256), 0, stream, p);
+    if (tail) hipLaunchKernelGGL((igemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -317,8 +443,6 @@ constexpr TileCfg kMenu[] = {
     {128, 32, 0.86f, 0.915f}, {64, 32, 0.86f, 0.877f},  {32, 64, 0.86f, 0.854f}, {96, 32, 0.84f, 0.882f}, {128, 128, 0.75f, 0.70f},
     {32, 32, 0.72f, 0.75f},
 };
-constexpr int kNumCU = 256;
-
 int g_forced_bm = -1, g_forced_bn = -1;   // tuning aid (tools/tune_conv.py): SIMQ_IGEMM_TILE=BMxBN or simq_tune_force_tile()
 
 int forced_tile(int* bm, int* bn) {
@@ -379,6 +503,8 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 }
 
 int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }
+
+void tune_tail_split(int on) { g_tail_split = on ? 1 : 0; }
 
 void tune_force_tile(int bm, int bn) { g_forced_bm = bm > 0 ? bm : 0; g_forced_bn = bn; }
 

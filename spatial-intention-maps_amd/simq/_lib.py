@@ -90,6 +90,7 @@ _SIGS = {
     'simq_profile_start': (c_int, []),
     'simq_profile_stop': (c_int, [c_void_p, c_int]),
     'simq_tune_force_tile': (c_int, [c_int, c_int]),
+    'simq_tune_tail_split': (c_int, [c_int]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -318,3 +318,35 @@ def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k)
     # and both are bf16-class against an fp64 convolution of the same inputs
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
     assert rel(y_dma, ref) < 2e-2
+
+
+@pytest.mark.parametrize('B,H', [(29, 24), (39, 20)], ids=['112_tail_tiles', 'ragged_tail'])
+def test_conv_fp32_balanced_last_round(L, B, H):
+    """conv_igemm.hip's opt-in balanced last round (simq_tune_tail_split): the tiles of a partial last round are contracted
+    in K-slices by several blocks and finished by igemm_tail_fixup_kernel.  Same output (up to the fp32 summation order of
+    the slices) and the same fused bias + batch statistics as the plain launch.  (29, 24): 1392 tiles of 96x64 on 1280
+    slots; (39, 20): M = 15600 is not a multiple of 96 -- the 24 tail tiles include the ragged last row tile."""
+    Cin, Cout, k = 512, 512, 3
+    g = torch.Generator().manual_seed(91 + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    st = L.stream_ptr()
+    outs = []
+    try:
+        L.lib.call('simq_tune_force_tile', 96, 64)
+        for on in (0, 1):
+            L.lib.call('simq_tune_tail_split', on)
+            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st)
+            outs.append((y, stats))
+    finally:
+        L.lib.call('simq_tune_tail_split', 0)
+        L.lib.call('simq_tune_force_tile', 0, 0)
+    (y0, s0), (y1, s1) = outs
+    assert torch.isfinite(y1).all()
+    assert rel(y1, y0) < 5e-6 and rel(s1, s0) < 1e-6
+    assert not torch.equal(y1, y0)                           # the sliced path really ran (different summation order)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel(y1, ref) < 1e-4
