@@ -194,6 +194,13 @@ int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, 
 int simq_conv2d_fwd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                     int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
                     double* d_stats /* NULL or [2*cout] zeroed */, void* stream);
+/* The same 3x3 / stride-1 / pad-1 convolution through the Winograd F(2x2,3x3) path (conv_winograd.hip: input transform,
+ * 16 batched transform-domain GEMMs, output transform + epilogue), as the plan uses it for the 512-channel layers.
+ * Requirements: hin, win even; cin % 16 == 0; cout % 64 == 0; cin / 4 and cout / 4 divide 256.
+ * d_scratch: 16*cout*cin + 16*T*(cin+cout) floats, T = batch*(hin/2)*(win/2) (transformed weights | V | Mt). */
+int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
+                             int batch, int hin, int win, int cin, int cout,
+                             double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scratch, float* d_dx,
                       int batch, int hin, int win, int cin, int cout, int r, int s, int pad, void* stream);
 int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* zeroed by callee */,
@@ -221,6 +228,8 @@ int simq_tune_force_tile(int bm, int bn);
 /* tuning aid: switch the fp32 implicit-GEMM kernel's balanced last round (K-sliced tail tiles + fix-up kernel) on (1) /
  * off (0); default off (it pays only when the forwards run serialised), also SIMQ_TAIL_SPLIT=1 in the environment */
 int simq_tune_tail_split(int on);
+/* tuning aid: Winograd path of the plan's eligible layers on (1, default) / off (0); also SIMQ_WINOGRAD=0 */
+int simq_tune_winograd(int on);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,20 @@ void tune_tail_split(int on);           // conv_igemm.hip: balanced last round o
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream);
+// conv_igemm.hip: `batch` independent row-major GEMMs y_g = x_g * w_g^T in one launch
+int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
+// conv_winograd.hip: Winograd F(2x2,3x3) for the wide 3x3 layers; U = transformed weights [16][Cout][Cin]
+bool winograd_enabled();
+void tune_winograd(int on);
+bool winograd_eligible(const ConvGeom& g);
+bool winograd_pays(int cin, int cout);
+int64_t winograd_scratch_floats(const ConvGeom& g);
+int launch_wino_weight(const float* w_ohwi, float* U, int cout, int cin, hipStream_t stream);
+struct WinoWeightDesc { int64_t src_off, u_off; int cout, cin, from_wt, pad_; };   // cout / cin of the convolution U serves
+struct WinoWeightTable { WinoWeightDesc d[40]; int n; };
+int launch_wino_weight_all(const float* params, const float* wt, float* ubase, const WinoWeightTable& t, hipStream_t stream);
+int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
+                         hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
 int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs

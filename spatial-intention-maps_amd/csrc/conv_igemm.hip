@@ -53,6 +53,9 @@ struct IgemmArgs {
     // and leave their accumulators in `partial`; igemm_tail_fixup_kernel adds the pieces and runs the epilogue
     int full_tiles, splits, kper;
     float* partial;
+    // batched launch (blockIdx.y = g): g-th problem reads x + g*gx, w + g*gw and writes y + g*gy (elements); the Winograd
+    // path runs its 16 transform-domain GEMMs this way (conv_winograd.hip)
+    long gx, gw, gy;
 };
 
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
@@ -127,8 +130,10 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     }
     // VEC: this thread's rows (pixel base / top-left input coordinate) live in registers; invalid rows can never
     // pass the bounds test
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const float* px = p.x + blockIdx.y * p.gx;
+    const float* pw = p.w + blockIdx.y * p.gw;
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
     // VEC: per row of this thread, the byte offset of tap (0,0) / channel 0 and the bit mask of the filter taps that fall
     // inside the image (R*S <= 32; rows past M have an empty mask) -- a K-step then costs one add, one mask test and one
     // select per load instead of re-deriving the input coordinates
@@ -181,12 +186,12 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
                 int4 ri = rowinfo[srow + 16 * ps];
                 int iy = ri.y + yy, ix = ri.z + xx;
                 bool ok = kok && ri.w && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                sa[SET][ps] = ok ? p.x[(size_t)(ri.x + iy * p.Win + ix) * p.Cin + ci] : 0.f;
+                sa[SET][ps] = ok ? px[(size_t)(ri.x + iy * p.Win + ix) * p.Cin + ci] : 0.f;
             }
 #pragma unroll
             for (int ps = 0; ps < B_PASSES_S; ++ps) {
                 int n = srow + 16 * ps;
-                sb[SET][ps] = kok ? p.w[(size_t)(n0 + n) * p.K + k] : 0.f;
+                sb[SET][ps] = kok ? pw[(size_t)(n0 + n) * p.K + k] : 0.f;
             }
         }
     };
@@ -299,6 +304,12 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
             return;
         }
     }
+    if (p.gy) {                                       // batched launch: plain store into the g-th output
+        EpiArgs eg = p.epi;
+        eg.y += blockIdx.y * p.gy;
+        igemm_epilogue<BM, BN, TM, TN>(eg, acc, m0, n0, p.M, p.Cout, smem);
+        return;
+    }
     igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 
@@ -390,7 +401,7 @@ int resident_blocks() {
 }
 
 template <int BM, int BN, bool VEC>
-int run(const IgemmArgs& a, hipStream_t stream) {
+int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     IgemmArgs p = a;
     p.tilesN = p.Cout / BN;
     int tilesM = (p.M + BM - 1) / BM;
@@ -404,7 +415,7 @@ int run(const IgemmArgs& a, hipStream_t stream) {
         // worth it when the last round leaves a CU with one or two blocks (three or more co-resident blocks already keep the
         // matrix pipe busy: slicing a half-full round of the 64x64 tile measured 4 % slower) and a slice still has a
         // pipeline's worth of K-steps
-        if (g_tail_split && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
+        if (g_tail_split && batch == 1 && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
             int s = slots / rem;
             if (s > kMaxTailSplits) s = kMaxTailSplits;
             while (s > 1 && nk / s < 24) --s;
@@ -416,11 +427,11 @@ int run(const IgemmArgs& a, hipStream_t stream) {
             }
         }
     }
-    dim3 grid((unsigned)(p.full_tiles + tail * p.splits));
+    dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant tile of the headline workload (96x64), 2 = every other implicit-GEMM tile, 1 = wgrad
-    prof_launch_begin((BM == 96 && BN == 64 && VEC) ? 0 : 2, 2.0 * p.M * p.Cout * p.K,
-                      4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
+    prof_launch_begin((BM == 96 && BN == 64 && VEC) ? 0 : 2, 2.0 * p.M * p.Cout * p.K * batch,
+                      4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
     hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC>), grid, dim3(256), 0, stream, p);
     if (tail) hipLaunchKernelGGL((igemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, stream, p);
@@ -456,8 +467,8 @@ int forced_tile(int* bm, int* bn) {
 }
 
 template <bool VEC>
-int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream) {
-#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream)
+int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream, int batch = 1) {
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream, batch)
     if constexpr (VEC) {
         SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
         SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
@@ -479,6 +490,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
+    a.gx = a.gw = a.gy = 0;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, wb = 4.0 * g.Cout * a.K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
@@ -500,6 +512,27 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
         }
     }
     return vec ? dispatch<true>(bm, bn, a, stream) : dispatch<false>(bm, bn, a, stream);
+}
+
+// `batch` independent GEMMs  y_g[M][N] = x_g[M][K] * w_g[N][K]^T  (row-major, g-th operand at base + g * rows * cols) in one
+// launch (grid.y = batch): the transform-domain contractions of conv_winograd.hip.  K % 16 == 0, N % 64 == 0.
+int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream) {
+    SIMQ_REQUIRE(M > 0 && K % BK == 0 && N % 64 == 0 && batch >= 1, "gemm_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
+    IgemmArgs a;
+    a.x = x; a.w = w;
+    ConvEpilogue e;
+    a.epi = make_epi(y, e);
+    a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
+    a.M = M; a.K = K; a.tilesN = 0;
+    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N;
+    const double xb = 4.0 * M * K, wb = 4.0 * N * K;
+    SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "gemm_batched: operand exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    // many rounds of short-K blocks: the 64x64 tile (6 resident blocks per CU) measured best on these shapes
+    // (tools/probes/wino_gemm_probe.py: 104-107 TF/s at K = 256..512), 96x64 when the rows do not fill 64-row tiles evenly
+    int bm = 64, bn = 64, fbm = 0, fbn = 0;
+    if (forced_tile(&fbm, &fbn) && N % fbn == 0) { bm = fbm; bn = fbn; }
+    return dispatch<true>(bm, bn, a, stream, batch);
 }
 
 int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }

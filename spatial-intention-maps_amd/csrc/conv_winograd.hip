@@ -1,0 +1,289 @@
+// Winograd F(2x2, 3x3) convolution in fp32 for the wide 3x3 / stride-1 / pad-1 layers (layer4 of the encoder: 73 % of the
+// network's multiply-adds).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A          per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiplies per 2x2 outputs instead of 36: the 3x3 convolution becomes 16 independent GEMMs
+//   Mt[g][t][co] = sum_ci V[g][t][ci] * U[g][co][ci]        t = (b, tile_y, tile_x), T = B * (H/2) * (W/2)
+// with 2.25x fewer matrix-core FLOPs than the implicit GEMM of conv_igemm.hip.  All arithmetic stays fp32 (the transform
+// matrices only hold 0, +-1, +-1/2), the result differs from the direct convolution by a few fp32 ulps of the accumulated
+// magnitude (tests/test_gpu_ops.py: <= 2e-6 of the output range, the bar for the network outputs is 1e-4).
+//
+// Three launches per convolution (the GEMM is the batched form of igemm_conv_kernel, conv_igemm.hip):
+//   wino_input_kernel    x [B][H][W][Cin] (NHWC)        -> V  [16][T][Cin]      HBM-bound: reads x (4x from L2), writes 4x |x|
+//   launch_gemm_batched  V, U [16][Cout][Cin]           -> Mt [16][T][Cout]     MFMA-bound
+//   wino_output_kernel   Mt                             -> y  [B][H][W][Cout]   HBM-bound, carries the WHOLE conv epilogue:
+//        +bias, BatchNorm batch statistics, folded-BN affine, residual add, ReLU, fused BN-backward reduction (dgrad) --
+//        the same operations in the same order as igemm_epilogue.h.
+// U = G g G^T is part of the weight cache (wino_weight_kernel, refreshed by simq_weights_prepare with the other derived
+// weights); a dgrad is the same convolution over the flipped / transposed weight.
+#include "common.h"
+#include "igemm_epilogue.h"
+
+namespace simq {
+
+namespace {
+
+// ---- U[g][co][ci] = (G w[co][:, :][ci] G^T)[g / 4][g % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] ----
+__global__ void __launch_bounds__(256) wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int cout, int cin) {
+    const int total = cout * cin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i / cin, ci = i - co * cin;
+        const float* g = w + (size_t)co * 9 * cin + ci;
+        float t[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g0 = g[(0 * 3 + c) * cin], g1 = g[(1 * 3 + c) * cin], g2 = g[(2 * 3 + c) * cin];
+            t[0][c] = g0;
+            t[1][c] = 0.5f * (g0 + g1 + g2);
+            t[2][c] = 0.5f * (g0 - g1 + g2);
+            t[3][c] = g2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]), u3 = t[r][2];
+            U[(size_t)(r * 4 + 0) * total + i] = u0;
+            U[(size_t)(r * 4 + 1) * total + i] = u1;
+            U[(size_t)(r * 4 + 2) * total + i] = u2;
+            U[(size_t)(r * 4 + 3) * total + i] = u3;
+        }
+    }
+}
+
+// every eligible convolution's U in one launch: blockIdx.y = table entry (source: the OHWI weight in the parameter buffer, or
+// its flipped / transposed dgrad form in the weight cache)
+__global__ void __launch_bounds__(256) wino_weight_all_kernel(const float* __restrict__ params, const float* __restrict__ wt,
+                                                              float* __restrict__ ubase, const WinoWeightTable tab) {
+    const WinoWeightDesc d = tab.d[blockIdx.y];
+    const float* w = (d.from_wt ? wt : params) + d.src_off;
+    float* U = ubase + d.u_off;
+    const int cin = d.cin, total = d.cout * d.cin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i / cin, ci = i - co * cin;
+        const float* g = w + (size_t)co * 9 * cin + ci;
+        float t[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g0 = g[(0 * 3 + c) * cin], g1 = g[(1 * 3 + c) * cin], g2 = g[(2 * 3 + c) * cin];
+            t[0][c] = g0;
+            t[1][c] = 0.5f * (g0 + g1 + g2);
+            t[2][c] = 0.5f * (g0 - g1 + g2);
+            t[3][c] = g2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            U[(size_t)(r * 4 + 0) * total + i] = t[r][0];
+            U[(size_t)(r * 4 + 1) * total + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+            U[(size_t)(r * 4 + 2) * total + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+            U[(size_t)(r * 4 + 3) * total + i] = t[r][2];
+        }
+    }
+}
+
+// ---- V[g][t][c] = (B^T d B)[g / 4][g % 4],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] ----
+// One thread: one tile x 4 channels (float4); the C/4 lanes of a tile read / write full contiguous rows of C floats.
+__global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C,
+                                                         int T) {
+    const int lanes = C >> 2;                       // float4 lanes per tile
+    const int tpb = 256 / lanes;                    // tiles per block iteration
+    const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
+    const int th = H >> 1, tw = W >> 1;
+    const size_t gstride = (size_t)T * C;
+    for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
+        const int b = t / (th * tw), r = t - b * (th * tw);
+        const int ty = r / tw, tx = r - ty * tw;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        floatx4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = y0 + i, xx = x0 + j;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    d[i][j] = *reinterpret_cast<const floatx4*>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4);
+                else
+                    d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        floatx4 e[4][4];                            // B^T d
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[0][j] = d[0][j] - d[2][j];
+            e[1][j] = d[1][j] + d[2][j];
+            e[2][j] = d[2][j] - d[1][j];
+            e[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = V + (size_t)t * C + cl * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 0) * gstride) = e[i][0] - e[i][2];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 1) * gstride) = e[i][1] + e[i][2];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 2) * gstride) = e[i][2] - e[i][1];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 3) * gstride) = e[i][1] - e[i][3];
+        }
+    }
+}
+
+// ---- y = A^T m A (+ epilogue),  A^T = [[1,1,1,0],[0,1,-1,-1]] ----
+// One thread: one tile x 4 channels; a block walks its share of the tiles and keeps the per-channel partial sums of the
+// statistics in registers (fp32 over <= a few dozen values), then reduces them across its tile lanes through LDS and adds
+// them to the fp64 accumulators -- one atomic per channel and block, like the implicit-GEMM epilogue.
+__global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ Mt, const EpiArgs p, int B, int H, int W, int C, int T) {
+    __shared__ float red[4][256][4];
+    const int lanes = C >> 2, tpb = 256 / lanes;
+    const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
+    const int th = H >> 1, tw = W >> 1;
+    const size_t gstride = (size_t)T * C;
+    const int n = cl * 4;
+    const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (p.bias) bias[c] = p.bias[n + c];
+        if (p.scale) { sc[c] = p.scale[n + c]; sh[c] = p.shift[n + c]; }
+        if (bnr) { mu1[c] = p.bnr_mean1[n + c]; is1[c] = p.bnr_invstd1[n + c]; }
+        if (bnr2) { mu2[c] = p.bnr_mean2[n + c]; is2[c] = p.bnr_invstd2[n + c]; }
+    }
+    floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
+        const int b = t / (th * tw), r = t - b * (th * tw);
+        const int ty = r / tw, tx = r - ty * tw;
+        const float* src = Mt + (size_t)t * C + n;
+        floatx4 m[4][4];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) m[g >> 2][g & 3] = *reinterpret_cast<const floatx4*>(src + g * gstride);
+        floatx4 a[2][4];                            // A^T m
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[0][j] = m[0][j] + m[1][j] + m[2][j];
+            a[1][j] = m[1][j] - m[2][j] - m[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                floatx4 v = j == 0 ? a[i][0] + a[i][1] + a[i][2] : a[i][1] - a[i][2] - a[i][3];
+                v += bias;
+                if (p.stats) { s0 += v; s1 += v * v; }
+                v = v * sc + sh;
+                const size_t o = ((size_t)(b * H + 2 * ty + i) * W + 2 * tx + j) * C + n;
+                if (p.addend) v += *reinterpret_cast<const floatx4*>(p.addend + o);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<floatx4*>(p.y + o) = v;
+                if (bnr) {
+                    floatx4 dz;
+                    if (p.bnr_mask) {
+                        const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
+                    } else {
+                        const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
+                        dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
+                        dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
+                    }
+                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
+                    s0 += dz;
+                    s1 += dz * ((y1 - mu1) * is1);
+                    if (bnr2) {
+                        const floatx4 y2 = *reinterpret_cast<const floatx4*>(p.bnr_y2 + o);
+                        s2 += dz;
+                        s3 += dz * ((y2 - mu2) * is2);
+                    }
+                }
+            }
+    }
+    if (!p.stats && !bnr) return;                   // block-uniform
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        red[0][threadIdx.x][c] = s0[c]; red[1][threadIdx.x][c] = s1[c];
+        red[2][threadIdx.x][c] = s2[c]; red[3][threadIdx.x][c] = s3[c];
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {  // channel ch lives in lane ch / 4, component ch % 4 of every tile lane group
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int k = 0; k < tpb; ++k) {
+            const int src = k * lanes + (ch >> 2);
+            a0 += (double)red[0][src][ch & 3]; a1 += (double)red[1][src][ch & 3];
+            a2 += (double)red[2][src][ch & 3]; a3 += (double)red[3][src][ch & 3];
+        }
+        double* dst = p.stats ? p.stats : p.bnr_red1;
+        unsafeAtomicAdd(dst + ch, a0);
+        unsafeAtomicAdd(dst + C + ch, a1);
+        if (bnr2) {
+            unsafeAtomicAdd(p.bnr_red2 + ch, a2);
+            unsafeAtomicAdd(p.bnr_red2 + C + ch, a3);
+        }
+    }
+}
+
+int g_winograd = -1;   // SIMQ_WINOGRAD=0 keeps every convolution on the implicit-GEMM kernel (A-B runs)
+
+}  // namespace
+
+bool winograd_enabled() {
+    if (g_winograd < 0) { const char* s = getenv("SIMQ_WINOGRAD"); g_winograd = (s && atoi(s) == 0) ? 0 : 1; }
+    return g_winograd != 0;
+}
+
+void tune_winograd(int on) { g_winograd = on ? 1 : 0; }
+
+// Geometry the kernels handle: 3x3 / stride 1 / pad 1 on an even-sized map, channel counts that fill the float4 lanes of the
+// transform kernels (C / 4 divides 256) and the GEMM's tiles.
+bool winograd_eligible(const ConvGeom& g) {
+    auto lanes_ok = [](int c) { return c % 4 == 0 && c / 4 <= 256 && 256 % (c / 4) == 0; };
+    return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.Hin % 2 == 0 && g.Win % 2 == 0 && g.Hout == g.Hin && g.Wout == g.Win &&
+           g.Cin % 16 == 0 && g.Cout % 64 == 0 && lanes_ok(g.Cin) && lanes_ok(g.Cout);
+}
+
+// Layers the transform pays for: enough multiply-adds per transformed element (tools/winograd_probe.py); SIMQ_WINOGRAD_MIN
+// overrides the Cin * Cout threshold.
+bool winograd_pays(int cin, int cout) {
+    static long min_cc = -1;
+    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 256L * 512; }
+    return (long)cin * cout >= min_cc;
+}
+
+int64_t winograd_scratch_floats(const ConvGeom& g) {
+    const int64_t T = (int64_t)g.B * (g.Hin / 2) * (g.Win / 2);
+    return 16 * T * (g.Cin + g.Cout);
+}
+
+int launch_wino_weight(const float* w_ohwi, float* U, int cout, int cin, hipStream_t stream) {
+    const int total = cout * cin;
+    int blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks), dim3(256), 0, stream, w_ohwi, U, cout, cin);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_wino_weight_all(const float* params, const float* wt, float* ubase, const WinoWeightTable& t, hipStream_t stream) {
+    if (t.n == 0) return 0;
+    hipLaunchKernelGGL(wino_weight_all_kernel, dim3(256, (unsigned)t.n), dim3(256), 0, stream, params, wt, ubase, t);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// scratch: winograd_scratch_floats(g) floats (V | Mt), 16-byte aligned
+int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
+                         hipStream_t stream) {
+    SIMQ_REQUIRE(winograd_eligible(g), "conv_winograd: geometry not supported (3x3 s1 p1, even map, Cin %% 16, Cout %% 64)");
+    const int T = g.B * (g.Hin / 2) * (g.Win / 2);
+    SIMQ_REQUIRE((double)T * 16 * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4.0 < 68719476736.0, "conv_winograd: batch too large");
+    float* V = scratch;
+    float* Mt = scratch + (size_t)16 * T * g.Cin;
+    const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
+    int bin = (T + tpb_in - 1) / tpb_in;
+    if (bin > 4096) bin = 4096;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T);
+    SIMQ_CHECK_LAUNCH();
+    if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
+    int bout = (T + tpb_out - 1) / tpb_out;
+    const int cap = (e.stats || e.bnr_red1) ? 512 : 4096;    // statistics: few blocks, one fp64 atomic per channel and block
+    if (bout > cap) bout = cap;
+    const EpiArgs ea = make_epi(y, e);
+    hipLaunchKernelGGL(wino_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace simq

@@ -33,6 +33,7 @@ struct ConvL {
     int64_t w_off = -1, b_off = -1;   // into the flat parameter buffer
     int64_t wt_off = -1;              // into the transposed-weight scratch (dgrad), -1: no dgrad
     int64_t wp_off = -1;              // into the bf16 weight-plane scratch (matrix-core precisions), -1: stays fp32
+    int64_t wu_off = -1, wut_off = -1;   // Winograd-transformed weights (forward / dgrad form) in the weight cache, -1: direct conv
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int64_t wcount() const { return (int64_t)cout * k * k * cin; }
 };
@@ -68,7 +69,8 @@ struct simq_plan {
     BlockL blocks[8];
     std::vector<TensorInfo> tensors;
     std::vector<BnL*> bns;
-    int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0;
+    int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0, wu_total = 0;
+    int64_t wino_scratch_per_sample = 0;   // floats of V | Mt scratch per transition (max over the Winograd layers)
 };
 
 namespace {
@@ -86,6 +88,21 @@ struct Builder {
             p->nparams += cout;
         }
         if (dgrad) { c.wt_off = p->wt_total; p->wt_total += c.wcount(); c.wp_off = p->wp_total; p->wp_total += c.wcount(); }
+        // fp32 plans: the wide 3x3 layers run as Winograd F(2x2,3x3) (conv_winograd.hip); every one of them sits on the 24x24 maps
+        if (p->precision == SIMQ_PREC_FP32 && dgrad && k == 3 && stride == 1 && pad == 1 && winograd_enabled() && winograd_pays(cin, cout)) {
+            ConvGeom g;
+            g.B = 1; g.Hin = g.Win = g.Hout = g.Wout = 24; g.Cin = cin; g.Cout = cout; g.R = g.S = 3; g.stride = 1; g.pad = 1;
+            ConvGeom gt = g;
+            gt.Cin = cout; gt.Cout = cin;
+            if (winograd_eligible(g)) {
+                c.wu_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
+                p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(g));
+            }
+            if (winograd_eligible(gt)) {
+                c.wut_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
+                p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(gt));
+            }
+        }
     }
     void bn(BnL& b, const std::string& name, int C) {
         b.name = name; b.C = C;
@@ -109,6 +126,7 @@ struct Layout {
     int64_t S[4];
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
     int64_t p_pooled, p_up1, DP[2];
+    int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
     int64_t total;
 };
 
@@ -150,6 +168,7 @@ Layout make_layout(const simq_plan* p, int B) {
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
+    L.wino = p->wino_scratch_per_sample > 0 ? take((int64_t)B * p->wino_scratch_per_sample * f) : -1;
     L.total = off;
     return L;
 }
@@ -157,14 +176,15 @@ Layout make_layout(const simq_plan* p, int B) {
 // Weight cache (caller-owned, one per parameter set): derived copies of the convolution weights that only change when
 // the parameters do -- fp32: flipped/transposed weights for dgrad; matrix-core precisions: bf16 planes of the weights
 // and of their flipped/transposed form.  Filled by simq_weights_prepare.
-struct WLayout { int64_t wt, wpl, wtpl, total; };
+struct WLayout { int64_t wt, wpl, wtpl, wu, total; };
 WLayout make_wlayout(const simq_plan* p) {
     WLayout W;
-    W.wt = W.wpl = W.wtpl = -1;
+    W.wt = W.wpl = W.wtpl = W.wu = -1;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
     if (p->precision == SIMQ_PREC_FP32) {
         W.wt = take(p->wt_total * (int64_t)sizeof(float));
+        if (p->wu_total > 0) W.wu = take(p->wu_total * (int64_t)sizeof(float));
     } else {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
         W.wpl = take(p->wp_total * h);
@@ -236,6 +256,8 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
         c.wplanes(cv, false, wsp);
         return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
     }
+    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
+        return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream);
     return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream);
 }
 
@@ -409,6 +431,8 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
         c.wplanes(cv, true, wsp);
         return launch_conv_igemm_bf16(ds, wsp, c.p->np(), dx, g, e, c.stream);
     }
+    if (cv.wut_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
+        return launch_conv_winograd(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wut_off, dx, g, e, c.f(c.L.wino), c.stream);
     return launch_conv_igemm(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wt) + cv.wt_off, dx, g, e, c.stream);
 }
 
@@ -647,9 +671,20 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
     SIMQ_REQUIRE(plan && d_params && d_wcache, "weights_prepare: NULL argument");
     const WLayout W = make_wlayout(plan);
     char* wc = static_cast<char*>(d_wcache);
-    if (plan->precision == SIMQ_PREC_FP32)
-        return launch_weight_prep_all(d_params, weight_table(plan), reinterpret_cast<float*>(wc + W.wt), nullptr, nullptr, 1, 0,
+    if (plan->precision == SIMQ_PREC_FP32) {
+        RC(launch_weight_prep_all(d_params, weight_table(plan), reinterpret_cast<float*>(wc + W.wt), nullptr, nullptr, 1, 0,
+                                  static_cast<hipStream_t>(stream)));
+        if (W.wu < 0) return 0;
+        WinoWeightTable t;                             // Winograd layers: U = G w G^T of the weight and of its dgrad form
+        t.n = 0;
+        (void)for_each_mc_conv(plan, [&](const ConvL& cv) {
+            if (cv.wu_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu_off, cv.cout, cv.cin, 0, 0};
+            if (cv.wut_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut_off, cv.cin, cv.cout, 1, 0};
+            return 0;
+        });
+        return launch_wino_weight_all(d_params, reinterpret_cast<const float*>(wc + W.wt), reinterpret_cast<float*>(wc + W.wu), t,
                                       static_cast<hipStream_t>(stream));
+    }
     return launch_weight_prep_all(d_params, weight_table(plan), nullptr, reinterpret_cast<uint16_t*>(wc + W.wpl),
                                   reinterpret_cast<uint16_t*>(wc + W.wtpl), plan->np(), plan->wp_total,
                                   static_cast<hipStream_t>(stream));
@@ -813,6 +848,19 @@ int simq_conv2d_fwd(const float* d_x, const float* d_w, const float* d_bias, flo
     ConvEpilogue e;
     e.bias = d_bias; e.stats = d_stats;
     return launch_conv_igemm(d_x, d_w, d_y, g, e, static_cast<hipStream_t>(stream));
+}
+
+int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
+                             int cin, int cout, double* d_stats, float* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_x && d_w && d_y && d_scratch && batch >= 1, "conv2d_fwd_winograd: bad argument");
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
+    SIMQ_REQUIRE(winograd_eligible(g), "conv2d_fwd_winograd: geometry not supported (even map, cin %% 16, cout %% 64)");
+    ConvEpilogue e;
+    e.bias = d_bias; e.stats = d_stats;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
+    return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
 }
 
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, float* d_dx, int batch, int hin, int win,

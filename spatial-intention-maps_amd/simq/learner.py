@@ -16,6 +16,7 @@ Additions for the MI355X path:
   train_step(...)          the fused step over flat buffers (no torch autograd), used by train()
 All arithmetic goes through libsimq (HIP); there is no torch/CPU fallback.
 """
+import os
 import random
 from collections import namedtuple
 
@@ -294,7 +295,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
 
 _SIDE_STREAMS = {}
 FUSED_LIBRARY_STEP = True       # single-process steps go through ONE library call (simq_train_step) instead of ~15 ctypes calls
-OVERLAP_TARGET_FORWARD = True    # run the (independent) target-net forward on a side stream; bench.py turns it off
+OVERLAP_TARGET_FORWARD = os.environ.get('SIMQ_OVERLAP', '1') != '0'   # run the (independent) target-net forward on a side stream; bench.py turns it off
                                  # for its per-kernel HIP-event pass, where concurrent kernels would share the GPU
 
 
