@@ -76,6 +76,11 @@ int launch_wino_weight_all(const float* params, const float* wt, float* ubase, c
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                          hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
+// conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
+int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
+bool winograd_wgrad_eligible(const ConvGeom& g);
+bool winograd_wgrad_enabled();
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream);
 int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
 int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,

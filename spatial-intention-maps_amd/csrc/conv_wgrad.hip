@@ -30,6 +30,7 @@ struct WgradArgs {
     int M, K;
     int tilesI, tilesJ, rows_per_split;
     unsigned x_bytes, dy_bytes;
+    long gx, gdy, gdw;   // batched launch (blockIdx.y = g): element offsets of the g-th x / dy / dw (conv_winograd.hip)
 };
 
 template <int TI, int TJ, int WI, int WJ, bool VEC>
@@ -83,8 +84,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int X_PASSES_S = BR * TJ / 256;
     float4 vy[2][Y_PASSES], vx[2][VEC ? X_PASSES_V : 1];
     float sx[2][VEC ? 1 : X_PASSES_S];
-    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + blockIdx.y * p.gx), 0, p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + blockIdx.y * p.gdy), 0, p.dy_bytes, 0x00020000);
 
     // pixel decomposition of the rows this lane loads from x (VEC path), for the first tile; load_tile advances it
     int xb[VEC ? X_PASSES_V : 1], xoy[VEC ? X_PASSES_V : 1], xox[VEC ? X_PASSES_V : 1];
@@ -219,18 +220,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wi * (TI / WI) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                unsafeAtomicAdd(p.dw + (size_t)i * p.K + col, acc[a][b][r]);
+                unsafeAtomicAdd(p.dw + blockIdx.y * p.gdw + (size_t)i * p.K + col, acc[a][b][r]);
             }
         }
     }
 }
 
 template <int TI, int TJ, int WI, int WJ, bool VEC>
-int run(const WgradArgs& a, hipStream_t stream) {
+int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     WgradArgs p = a;
     p.tilesI = p.Cout / TI;
     p.tilesJ = VEC ? p.R * p.S * (p.Cin / TJ) : (p.K + TJ - 1) / TJ;
     const int tiles = p.tilesI * p.tilesJ;
+    const int ltiles = tiles * batch;                // blocks per split over the whole (batched) launch
     // Split the pixel reduction so that the block count fills the 256 CUs in whole rounds:
     // time ~ ceil(tiles*s / 256) * (reduction steps per block + fixed prologue/atomic-epilogue cost).
     const int rsteps = (p.M + BR - 1) / BR;
@@ -242,7 +244,7 @@ int run(const WgradArgs& a, hipStream_t stream) {
     for (int s = 1; s <= max_splits; ++s) {
         // blocks per CU share the matrix pipe, so time ~ (blocks per CU) x (steps per block + fixed cost); one or two blocks
         // per CU cannot hide their own barriers / load latency (measured utilisation ~0.6 / ~0.85 of three resident blocks)
-        const long rounds = ((long)tiles * s + 255) / 256;
+        const long rounds = ((long)ltiles * s + 255) / 256;
         const double util = rounds == 1 ? 0.6 : rounds == 2 ? 0.85 : 1.0;
         const double cost = (double)rounds * ((rsteps + s - 1) / s + 6) / util;
         if (cost < best * 0.999) { best = cost; splits = s; }
@@ -252,10 +254,10 @@ int run(const WgradArgs& a, hipStream_t stream) {
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
-    prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K,
-                      4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
+    prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K * batch,
+                      4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -270,6 +272,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K();
     a.tilesI = a.tilesJ = a.rows_per_split = 0;
+    a.gx = a.gdy = a.gdw = 0;
     SIMQ_REQUIRE(a.M > 0, "wgrad: empty problem");
     SIMQ_REQUIRE(g.Cout % 32 == 0, "conv_wgrad: Cout=%d must be a multiple of 32", g.Cout);
     const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, yb = 4.0 * a.M * g.Cout;
@@ -289,6 +292,22 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
     }
     SIMQ_REQUIRE(g.Cout % 64 == 0, "conv_wgrad (generic gather): Cout=%d must be a multiple of 64", g.Cout);
     return run<64, 64, 2, 2, false>(a, stream);
+}
+
+// `batch` independent contractions over the rows  dw_g[N][K] += dy_g[M][N]^T * x_g[M][K]  (row-major operands, g-th at
+// base + g * rows * cols; dw zeroed by the caller) in one launch: the transform-domain weight gradients of conv_winograd.hip.
+int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream) {
+    SIMQ_REQUIRE(M > 0 && N % 128 == 0 && K % 128 == 0 && batch >= 1, "wgrad_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.dw = dw;
+    a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
+    a.M = M; a.K = K;
+    a.tilesI = a.tilesJ = a.rows_per_split = 0;
+    a.gx = (long)M * K; a.gdy = (long)M * N; a.gdw = (long)N * K;
+    const double xb = 4.0 * M * K, yb = 4.0 * M * N;
+    SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "wgrad_batched: operand exceeds the 4 GiB buffer-addressing limit");
+    a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    return run<128, 128, 2, 2, true>(a, stream, batch);
 }
 
 }  // namespace simq

@@ -215,6 +215,60 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     }
 }
 
+// ---- weight gradient in the transform domain --------------------------------------------------------------------------
+//   Y = A^T Mt A  =>  dMt = A dY A^T ;   Mt[g] = V[g] U[g]^T  =>  dU[g] = dMt[g]^T V[g] ;   U = G w G^T  =>  dw = G^T dU G
+// dMt[g][t][c] = (A dY A^T)[g / 4][g % 4],  A = [[1,0],[1,1],[1,-1],[0,-1]]
+__global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int B, int H, int W, int C, int T) {
+    const int lanes = C >> 2, tpb = 256 / lanes;
+    const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
+    const int th = H >> 1, tw = W >> 1;
+    const size_t gstride = (size_t)T * C;
+    for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
+        const int b = t / (th * tw), r = t - b * (th * tw);
+        const int ty = r / tw, tx = r - ty * tw;
+        const float* src = dy + ((size_t)(b * H + 2 * ty) * W + 2 * tx) * C + cl * 4;
+        const floatx4 y00 = *reinterpret_cast<const floatx4*>(src), y01 = *reinterpret_cast<const floatx4*>(src + C);
+        const floatx4 y10 = *reinterpret_cast<const floatx4*>(src + (size_t)W * C), y11 = *reinterpret_cast<const floatx4*>(src + (size_t)W * C + C);
+        floatx4 a[4][2];                            // A dY
+        a[0][0] = y00; a[0][1] = y01;
+        a[1][0] = y00 + y10; a[1][1] = y01 + y11;
+        a[2][0] = y00 - y10; a[2][1] = y01 - y11;
+        a[3][0] = -y10; a[3][1] = -y11;
+        float* dst = dM + (size_t)t * C + cl * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 0) * gstride) = a[i][0];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 1) * gstride) = a[i][0] + a[i][1];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 2) * gstride) = a[i][0] - a[i][1];
+            *reinterpret_cast<floatx4*>(dst + (i * 4 + 3) * gstride) = -a[i][1];
+        }
+    }
+}
+
+// dw[co][ky][kx][ci] = (G^T dU[.][co][ci] G)[ky][kx],  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+__global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin) {
+    const int total = cout * cin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i / cin, ci = i - co * cin;
+        float t[3][4];                              // G^T dU
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u0 = dU[(size_t)(0 * 4 + c) * total + i], u1 = dU[(size_t)(1 * 4 + c) * total + i];
+            const float u2 = dU[(size_t)(2 * 4 + c) * total + i], u3 = dU[(size_t)(3 * 4 + c) * total + i];
+            t[0][c] = u0 + 0.5f * (u1 + u2);
+            t[1][c] = 0.5f * (u1 - u2);
+            t[2][c] = 0.5f * (u1 + u2) + u3;
+        }
+        float* o = dw + (size_t)co * 9 * cin + ci;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[(r * 3 + 0) * cin] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[(r * 3 + 1) * cin] = 0.5f * (t[r][1] - t[r][2]);
+            o[(r * 3 + 2) * cin] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
 int g_winograd = -1;   // SIMQ_WINOGRAD=0 keeps every convolution on the implicit-GEMM kernel (A-B runs)
 
 }  // namespace
@@ -225,6 +279,12 @@ bool winograd_enabled() {
 }
 
 void tune_winograd(int on) { g_winograd = on ? 1 : 0; }
+
+bool winograd_wgrad_enabled() {   // SIMQ_WINOGRAD_WGRAD=0: weight gradients of the Winograd layers stay on the direct kernel
+    static int on = -1;
+    if (on < 0) { const char* s = getenv("SIMQ_WINOGRAD_WGRAD"); on = (s && atoi(s) == 0) ? 0 : 1; }
+    return on != 0;
+}
 
 // Geometry the kernels handle: 3x3 / stride 1 / pad 1 on an even-sized map, channel counts that fill the float4 lanes of the
 // transform kernels (C / 4 divides 256) and the GEMM's tiles.
@@ -238,7 +298,7 @@ bool winograd_eligible(const ConvGeom& g) {
 // overrides the Cin * Cout threshold.
 bool winograd_pays(int cin, int cout) {
     static long min_cc = -1;
-    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 256L * 512; }
+    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 128L * 256; }
     return (long)cin * cout >= min_cc;
 }
 
@@ -282,6 +342,32 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     if (bout > cap) bout = cap;
     const EpiArgs ea = make_epi(y, e);
     hipLaunchKernelGGL(wino_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// Weight gradient of an eligible convolution through the transform domain: dw (OHWI, overwritten) from x and dy.
+// scratch: winograd_scratch_floats(g) + 16*Cout*Cin floats (V | dMt | dU).  Cin % 128 == 0 and Cout % 128 == 0.
+bool winograd_wgrad_eligible(const ConvGeom& g) { return winograd_eligible(g) && g.Cin % 128 == 0 && g.Cout % 128 == 0; }
+
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream) {
+    SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
+    const int T = g.B * (g.Hin / 2) * (g.Win / 2);
+    float* V = scratch;
+    float* dM = scratch + (size_t)16 * T * g.Cin;
+    float* dU = dM + (size_t)16 * T * g.Cout;
+    const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
+    int bin = (T + tpb_in - 1) / tpb_in, bout = (T + tpb_out - 1) / tpb_out;
+    if (bin > 4096) bin = 4096;
+    if (bout > 4096) bout = 4096;
+    hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dM, g.B, g.Hin, g.Win, g.Cout, T);
+    SIMQ_CHECK_LAUNCH();
+    SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
+    if (int rc = launch_wgrad_batched(V, dM, dU, T, g.Cout, g.Cin, 16, stream)) return rc;
+    int blocks = (g.Cout * g.Cin + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3(blocks), dim3(256), 0, stream, dU, dw, g.Cout, g.Cin);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

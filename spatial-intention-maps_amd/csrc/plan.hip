@@ -7,6 +7,7 @@
 // walks it with the HIP kernels of this directory:
 //   simq_forward   == FCN.forward (networks.py:16-26) in eval / train / train-no-grad mode
 //   simq_backward  == the autograd graph torch builds for it (loss.backward(), train.py:132)
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,7 @@ struct simq_plan {
     std::vector<BnL*> bns;
     int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0, wu_total = 0;
     int64_t wino_scratch_per_sample = 0;   // floats of V | Mt scratch per transition (max over the Winograd layers)
+    int64_t wino_du_floats = 0;            // transform-domain weight gradient of the largest Winograd layer
 };
 
 namespace {
@@ -95,6 +97,7 @@ struct Builder {
             ConvGeom gt = g;
             gt.Cin = cout; gt.Cout = cin;
             if (winograd_eligible(g)) {
+                p->wino_du_floats = std::max(p->wino_du_floats, 16 * c.wcount() / 9);
                 c.wu_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
                 p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(g));
             }
@@ -168,7 +171,7 @@ Layout make_layout(const simq_plan* p, int B) {
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
-    L.wino = p->wino_scratch_per_sample > 0 ? take((int64_t)B * p->wino_scratch_per_sample * f) : -1;
+    L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.total = off;
     return L;
 }
@@ -413,6 +416,8 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
     }
+    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && winograd_wgrad_enabled())
+        return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream);
     return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
 }
 
