@@ -61,7 +61,7 @@ struct IgemmArgs {
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
 // (168 / 96).  (Six waves for 96x64 compile to 78 registers without spilling but lose the software pipeline: 1445 vs 1737 tr/s;
 // four for 96x128 spill.)  LDS is not the limit: 20.5 KB (96x64) / 28.7 KB (96x128) per block with unpadded swizzled rows.
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool BATCHED = false>
 __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave (2x2 waves)
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     const int wm = wave >> 1, wn = wave & 1;
     int tile = blockIdx.x, piece = -1, kbeg = 0;
     int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
-    if constexpr (VEC) {
+    if constexpr (VEC && !BATCHED) {
         if (tile >= p.full_tiles) {                   // a K-slice of one of the last round's tiles
             piece = tile - p.full_tiles;
             tile = p.full_tiles + piece / p.splits;
@@ -130,8 +130,8 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     }
     // VEC: this thread's rows (pixel base / top-left input coordinate) live in registers; invalid rows can never
     // pass the bounds test
-    const float* px = p.x + blockIdx.y * p.gx;
-    const float* pw = p.w + blockIdx.y * p.gw;
+    const float* px = BATCHED ? p.x + blockIdx.y * p.gx : p.x;
+    const float* pw = BATCHED ? p.w + blockIdx.y * p.gw : p.w;
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
     // VEC: per row of this thread, the byte offset of tap (0,0) / channel 0 and the bit mask of the filter taps that fall
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     // ---- epilogue (igemm_epilogue.h); the stage buffers are idle now and serve as its reduction scratch ----
     // (the LDS-staged float4 form of igemm_epilogue.h measured 1 % slower on the whole fp32 step: other blocks of the CU
     // cover a scalar epilogue with their MFMAs, and the strip round trip adds LDS traffic)
-    if constexpr (VEC) {
+    if constexpr (VEC && !BATCHED) {
         if (piece >= 0) {                             // block-uniform: the fix-up kernel owns this tile's epilogue
             float* dst = p.partial + (size_t)piece * (BM * BN) + tid;
 #pragma unroll
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
             return;
         }
     }
-    if (p.gy) {                                       // batched launch: plain store into the g-th output
+    if constexpr (BATCHED) {                          // batched launch: plain store into the g-th output
         EpiArgs eg = p.epi;
         eg.y += blockIdx.y * p.gy;
         igemm_epilogue<BM, BN, TM, TN>(eg, acc, m0, n0, p.M, p.Cout, smem);
@@ -400,7 +400,7 @@ int resident_blocks() {
     return cached;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool BATCHED = false>
 int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     IgemmArgs p = a;
     p.tilesN = p.Cout / BN;
@@ -408,14 +408,14 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     const int tiles = tilesM * p.tilesN;
     p.full_tiles = tiles; p.splits = 1; p.kper = 0; p.partial = nullptr;
     int tail = 0;
-    if constexpr (VEC) {
+    if constexpr (VEC && !BATCHED) {
         if (g_tail_split < 0) { const char* s = getenv("SIMQ_TAIL_SPLIT"); g_tail_split = (s && atoi(s) != 0) ? 1 : 0; }
         const int slots = kNumCU * resident_blocks<BM, BN, VEC>();
         const int rem = tiles % slots, nk = p.K / BK;
         // worth it when the last round leaves a CU with one or two blocks (three or more co-resident blocks already keep the
         // matrix pipe busy: slicing a half-full round of the 64x64 tile measured 4 % slower) and a slice still has a
         // pipeline's worth of K-steps
-        if (g_tail_split && batch == 1 && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
+        if (g_tail_split && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
             int s = slots / rem;
             if (s > kMaxTailSplits) s = kMaxTailSplits;
             while (s > 1 && nk / s < 24) --s;
@@ -429,11 +429,12 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     }
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
-    // profiling kinds: 0 = the dominant tile of the headline workload (96x64), 2 = every other implicit-GEMM tile, 1 = wgrad
-    prof_launch_begin((BM == 96 && BN == 64 && VEC) ? 0 : 2, 2.0 * p.M * p.Cout * p.K * batch,
+    // profiling kinds: 0 = the dominant kernel of the headline workload (the batched transform-domain GEMM of the Winograd
+    // layers), 2 = every other implicit-GEMM launch, 1 = wgrad
+    prof_launch_begin(BATCHED ? 0 : 2, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC, BATCHED>), grid, dim3(256), 0, stream, p);
     if (tail) hipLaunchKernelGGL((igemm_tail_fixup_kernel<BM, BN>), dim3((unsigned)tail), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
@@ -467,8 +468,8 @@ int forced_tile(int* bm, int* bn) {
 }
 
 template <bool VEC>
-int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream, int batch = 1) {
-#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream, batch)
+int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream) {
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream)
     if constexpr (VEC) {
         SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
         SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
@@ -530,9 +531,7 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     // many rounds of short-K blocks: the 64x64 tile (6 resident blocks per CU) measured best on these shapes
     // (tools/probes/wino_gemm_probe.py: 104-107 TF/s at K = 256..512), 96x64 when the rows do not fill 64-row tiles evenly
-    int bm = 64, bn = 64, fbm = 0, fbn = 0;
-    if (forced_tile(&fbm, &fbn) && N % fbn == 0) { bm = fbm; bn = fbn; }
-    return dispatch<true>(bm, bn, a, stream, batch);
+    return run<64, 64, true, true>(a, stream, batch);
 }
 
 int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }

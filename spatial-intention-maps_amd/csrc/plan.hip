@@ -416,7 +416,8 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
     }
-    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && winograd_wgrad_enabled())
+    // (the 128 -> 256 layer loses in the transform domain: 0.118 vs 0.112 ms, tools/winograd_probe.py)
+    if (cv.wu_off >= 0 && c.L.wino >= 0 && (long)cv.cin * cv.cout >= 256L * 256 && winograd_wgrad_eligible(g) && winograd_wgrad_enabled())
         return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream);
     return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
 }
@@ -866,6 +867,15 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
+                               float* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_x && d_dy && d_dw && d_scratch && batch >= 1, "conv2d_wgrad_winograd: bad argument");
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
+    SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv2d_wgrad_winograd: geometry not supported (even map, cin %% 128, cout %% 128)");
+    return launch_conv_wgrad_winograd(d_x, d_dy, d_dw, g, d_scratch, static_cast<hipStream_t>(stream));
 }
 
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, float* d_dx, int batch, int hin, int win,

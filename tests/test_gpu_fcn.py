@@ -566,3 +566,28 @@ def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_d
     # momentum = the last gradients: run-to-run noise of the atomically accumulated BN statistics, amplified by the
     # conditioning described in this file's header (two identical runs differ by ~1e-3 here)
     assert rel(policy2._simq_opt_state.momentum, policy._simq_opt_state.momentum) < 1e-2
+
+
+def test_winograd_layers_equal_direct_convolution_network(simq_mod):
+    """The fp32 plan runs its 256/512-channel 3x3 layers as Winograd F(2x2,3x3) (conv_winograd.hip).  A plan created with
+    the path switched off (simq_tune_winograd(0): every layer on the implicit-GEMM kernel) gives the same Q-maps, batch
+    statistics, loss and gradients to fp32 round-off."""
+    from simq import _lib
+    import simq.learner as sl
+    cin, cout, B = 4, 2, 6
+    batch = cases.make_batch(cin, cout, B, 321)
+    res = []
+    try:
+        for on in (1, 0):
+            _lib.lib.call('simq_tune_winograd', on)
+            policy, target = make_net(simq_mod, cin, cout, 81, True), make_net(simq_mod, cin, cout, 82, False)
+            info = sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                                 use_double_dqn=True)
+            res.append((info, policy._last['q'].clone(), policy._last['y'].clone(), policy.flat_grads.clone(), policy.bn_buffers.clone()))
+    finally:
+        _lib.lib.call('simq_tune_winograd', 1)
+    (ia, qa, ya, ga, ba), (ib, qb, yb, gb, bb) = res
+    assert rel(qa, qb) < 1e-5 and rel(ya, yb) < 1e-5 and rel(ba, bb) < 1e-5
+    assert abs(ia['loss'] - ib['loss']) <= 1e-5 * abs(ib['loss'])
+    # gradient conditioning, see this file's header (both forms are judged against the fp64 oracle elsewhere)
+    assert float((ga - gb).double().norm() / gb.double().norm()) < 2e-2

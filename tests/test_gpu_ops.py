@@ -350,3 +350,57 @@ def test_conv_fp32_balanced_last_round(L, B, H):
     assert not torch.equal(y1, y0)                           # the sliced path really ran (different summation order)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
     assert rel(y1, ref) < 1e-4
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 12, 128, 256), (2, 8, 64, 64)],
+                         ids=['l4', 'l4a', 'l3a_small_map', 'narrow'])
+def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
+    """conv_winograd.hip (input transform, 16 batched transform-domain GEMMs, output transform + epilogue) against the
+    implicit-GEMM kernel and an fp64 convolution: outputs within 1e-5 of the output range (the transforms only add and
+    halve, measured ~7e-7), fused bias + batch statistics identical to round-off."""
+    g = torch.Generator().manual_seed(17 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    T = B * (H // 2) ** 2
+    scratch = torch.empty(16 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+    st = L.stream_ptr()
+    y0, y1 = torch.empty(B, H, H, Cout, device='cuda'), torch.full((B, H, H, Cout), float('nan'), device='cuda')
+    s0, s1 = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda'), torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+    L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y0), B, H, H, Cin, Cout, 3, 3, 1, 1, L.ptr(s0), st)
+    L.lib.call('simq_conv2d_fwd_winograd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y1), B, H, H, Cin, Cout, L.ptr(s1), L.ptr(scratch), st)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(y1).all()
+    assert rel(y1, ref) < 1e-5 and rel(y1, y0) < 1e-5
+    assert rel(s1, s0) < 1e-6
+    sref = torch.cat([ref.reshape(-1, Cout).sum(0), (ref * ref).reshape(-1, Cout).sum(0)])
+    assert rel(s1, sref) < 1e-5
+
+
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (6, 12, 256, 256)], ids=['l4', 'l4a', 'l3_small_map'])
+def test_conv_winograd_wgrad_matches_direct(L, B, H, Cin, Cout):
+    """Transform-domain weight gradient (dy / x transforms, 16 batched contractions over the tiles, G^T dU G) against the
+    direct wgrad kernel and fp64."""
+    g = torch.Generator().manual_seed(29 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    dy = torch.randn(B, H, H, Cout, generator=g).cuda()
+    T = B * (H // 2) ** 2
+    scratch = torch.empty(16 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+    st = L.stream_ptr()
+    d0, d1 = torch.empty(Cout, 3, 3, Cin, device='cuda'), torch.full((Cout, 3, 3, Cin), float('nan'), device='cuda')
+    L.lib.call('simq_conv2d_wgrad', L.ptr(x), L.ptr(dy), L.ptr(d0), B, H, H, Cin, Cout, 3, 3, 1, 1, st)
+    L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d1), B, H, H, Cin, Cout, L.ptr(scratch), st)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
+                                      padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(d1).all()
+    assert rel(d1, ref) < 1e-5 and rel(d0, ref) < 1e-5
+
+
+def test_conv_winograd_rejects_unsupported_geometry(L):
+    """Odd map sizes / channel counts the transform kernels cannot tile are refused with a message, not mis-computed."""
+    x = torch.zeros(1, 23, 23, 64, device='cuda'); w = torch.zeros(64, 3, 3, 64, device='cuda'); y = torch.zeros(1, 23, 23, 64, device='cuda')
+    scratch = torch.zeros(1 << 20, device='cuda')
+    with pytest.raises(Exception, match='geometry not supported'):
+        L.lib.call('simq_conv2d_fwd_winograd', L.ptr(x), L.ptr(w), None, L.ptr(y), 1, 23, 23, 64, 64, None, L.ptr(scratch), L.stream_ptr())
+    with pytest.raises(Exception, match='geometry not supported'):
+        L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(y), L.ptr(w), 1, 24, 24, 64, 64, L.ptr(scratch), L.stream_ptr())

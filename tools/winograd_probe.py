@@ -38,3 +38,22 @@ for B in [int(a) for a in sys.argv[1:]] or [32, 29]:
         flops = 2.0 * B * H * H * Cout * 9 * Cin
         print('B=%3d %-7s direct %.3f ms (%.1f TF)  winograd %.3f ms (%.1f TF effective, incl. weight transform)  x%.2f | err vs fp64: direct %.1e winograd %.1e  stats diff %.1e'
               % (B, name, md, flops / md / 1e9, mw, flops / mw / 1e9, md / mw, e0, e1, es))
+
+print('--- weight gradient: direct kernel vs transform domain ---')
+for B in (32,):
+    for name, Cin, Cout in [('l4', 512, 512), ('l4a', 256, 512), ('l3', 256, 256), ('l3a', 128, 256)]:
+        H = 24
+        x = torch.randn(B, H, H, Cin, device='cuda'); dy = torch.randn(B, H, H, Cout, device='cuda')
+        T = B * (H // 2) ** 2
+        scratch = torch.empty(16 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+        d0, d1 = torch.empty(Cout, 3, 3, Cin, device='cuda'), torch.empty(Cout, 3, 3, Cin, device='cuda')
+        f0 = lambda: L.lib.call('simq_conv2d_wgrad', L.ptr(x), L.ptr(dy), L.ptr(d0), B, H, H, Cin, Cout, 3, 3, 1, 1, st)
+        f1 = lambda: L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d1), B, H, H, Cin, Cout, L.ptr(scratch), st)
+        m0, m1 = timeit(f0), timeit(f1)
+        xd = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+        wref = torch.nn.grad.conv2d_weight(xd, (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+        sc = float(wref.abs().max())
+        flops = 2.0 * B * H * H * Cout * 9 * Cin
+        print('B=%3d %-5s direct %.3f ms (%.1f TF)  winograd %.3f ms (%.1f TF effective)  x%.2f | err vs fp64: direct %.1e winograd %.1e  [batched splits %s]'
+              % (B, name, m0, flops / m0 / 1e9, m1, flops / m1 / 1e9, m0 / m1, float((d0 - wref).abs().max()) / sc, float((d1 - wref).abs().max()) / sc,
+                 os.environ.get('SIMQ_WGRAD_BATCHED_SPLITS', 'auto')))
