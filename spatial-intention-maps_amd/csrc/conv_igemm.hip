@@ -56,6 +56,10 @@ struct IgemmArgs {
     // batched launch (blockIdx.y = g): g-th problem reads x + g*gx, w + g*gw and writes y + g*gy (elements); the Winograd
     // path runs its 16 transform-domain GEMMs this way (conv_winograd.hip)
     long gx, gw, gy;
+    // XCD-aware tile order: block b runs on XCD b % 8 (observed dispatch order), each XCD has its own L2.  Blocks
+    // b < 8 * xcd_chunk take tile (b % 8) * xcd_chunk + b / 8, so one XCD walks a CONTIGUOUS run of tiles (all N-tiles of the
+    // same rows back to back) and the A rows are fetched into one L2 instead of all eight; the rest keep tile = b.
+    int xcd_chunk;
 };
 
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
@@ -79,6 +83,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tile = blockIdx.x, piece = -1, kbeg = 0;
+    if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
     int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
     if constexpr (VEC && !BATCHED) {
         if (tile >= p.full_tiles) {                   // a K-slice of one of the last round's tiles
@@ -384,6 +389,7 @@ float* tail_scratch(hipStream_t stream) {
     return static_cast<float*>(ptr);
 }
 
+int g_xcd_remap = -1;    // SIMQ_XCD_REMAP=0: tiles in launch order (A-B runs)
 int g_tail_split = -1;   // SIMQ_TAIL_SPLIT=1 switches the balanced last round on
 
 template <int BM, int BN, bool VEC>
@@ -427,6 +433,8 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
             }
         }
     }
+    if (g_xcd_remap < 0) { const char* s = getenv("SIMQ_XCD_REMAP"); g_xcd_remap = (s && atoi(s) == 0) ? 0 : 1; }
+    p.xcd_chunk = (g_xcd_remap && p.tilesN > 1 && p.full_tiles >= 64) ? p.full_tiles / 8 : 0;
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant kernel of the headline workload (the batched transform-domain GEMM of the Winograd
@@ -491,7 +499,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
-    a.gx = a.gw = a.gy = 0;
+    a.gx = a.gw = a.gy = 0; a.xcd_chunk = 0;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, wb = 4.0 * g.Cout * a.K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
@@ -525,7 +533,7 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     a.epi = make_epi(y, e);
     a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
     a.M = M; a.K = K; a.tilesN = 0;
-    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N;
+    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N; a.xcd_chunk = 0;
     const double xb = 4.0 * M * K, wb = 4.0 * N * K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "gemm_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
