@@ -60,6 +60,10 @@ struct IgemmArgs {
     // b < 8 * xcd_chunk take tile (b % 8) * xcd_chunk + b / 8, so one XCD walks a CONTIGUOUS run of tiles (all N-tiles of the
     // same rows back to back) and the A rows are fetched into one L2 instead of all eight; the rest keep tile = b.
     int xcd_chunk;
+    // batched launches: a block contracts `nt_run` consecutive N-tiles of its row block in ONE software pipeline (the loads of
+    // the next N-tile's first K-steps are in flight while the last MFMAs of the current one run), so a short K = Cin (16-32
+    // K-steps) does not pay the pipeline prologue per tile (tools/probes/shortk_probe.py); measured neutral, default 1 (see run())
+    int nt_run;
 };
 
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
@@ -93,8 +97,12 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
             nk = min(nk - kbeg, p.kper);
         }
     }
-    const int tile_m = tile / p.tilesN, tile_n = tile % p.tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int groupsN = BATCHED ? p.tilesN / p.nt_run : p.tilesN;
+    const int tile_m = tile / groupsN, tile_n = (tile % groupsN) * (BATCHED ? p.nt_run : 1);
+    const int m0 = tile_m * BM;
+    int n0 = tile_n * BN;
+    const int nk1 = nk;                               // K-steps of one tile
+    if constexpr (BATCHED) nk *= p.nt_run;            // ... of the block's whole run of N-tiles
 
     // ---- row -> pixel decode, once per block (rows do not change along K) ----
     for (int r = tid; r < BM; r += 256) {
@@ -227,6 +235,14 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
         ++kx;
         if (kx >= p.S) { kx = 0; ++ky; }
         if (tap >= p.R * p.S) { tap = 0; kx = 0; ky = 0; c0 += BK; }
+        if constexpr (BATCHED) {
+            if (c0 >= p.K) {                          // next N-tile of the run: same rows, the following BN weight rows
+                c0 = 0;
+#pragma unroll
+                for (int ps = 0; ps < B_PASSES_V; ++ps)
+                    if (bbase[ps] != 0xFFFFFFFFu) bbase[ps] += (unsigned)(BN * p.K * 4);
+            }
+        }
     };
 
     // v_mfma_f32_16x16x4_f32 operands: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]
@@ -256,6 +272,25 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[SET][i][e], bf[SET][j][e], acc[i][j], 0, 0, 0);
+    };
+    // batched launches: plain bounds-checked buffer stores of the finished N-tile (rows past M get offset 0xFFFFFFFF and are dropped)
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(BATCHED ? p.epi.y + blockIdx.y * p.gy : p.epi.y, 0,
+                                                                     BATCHED ? (unsigned)p.M * (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    const int st_row0 = m0 + wm * (BM / 2) + 4 * fq;             // this lane's first output row; + i * 16 + r
+    auto store_plain = [&](int ncol0) {
+        const unsigned base = (unsigned)((st_row0 * p.Cout + ncol0 + wn * (BN / 2) + fi) * 4);
+        const int left = p.M - st_row0;                           // rows of this lane's column that exist
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned rowoff = (i * 16 + r) < left ? base + (unsigned)((i * 16 + r) * p.Cout * 4) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v = acc[i][j][r];     // (bit_cast straight from the vector element stored element 0 four times)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, rowoff == 0xFFFFFFFFu ? rowoff : rowoff + j * 64, 0, 0);
+                }
+            }
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -290,6 +325,16 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
         if constexpr (VEC) advance();
         load_tile(S1{}, kt + 5, kt + 5 < nk);
         __syncthreads();
+        if constexpr (BATCHED) {
+            if ((kt + 2) % nk1 == 0 && kt + 2 < nk) { // an N-tile of the run is complete: store it, keep the pipeline going
+                store_plain(n0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                n0 += BN;
+            }
+        }
     }
     if (kt < nk) mfma_step(S0{});                     // odd tile count: last step's fragments are in set 0
     __syncthreads();
@@ -310,9 +355,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
         }
     }
     if constexpr (BATCHED) {                          // batched launch: plain store into the g-th output
-        EpiArgs eg = p.epi;
-        eg.y += blockIdx.y * p.gy;
-        igemm_epilogue<BM, BN, TM, TN>(eg, acc, m0, n0, p.M, p.Cout, smem);
+        store_plain(n0);
         return;
     }
     igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
@@ -392,12 +435,12 @@ float* tail_scratch(hipStream_t stream) {
 int g_xcd_remap = -1;    // SIMQ_XCD_REMAP=0: tiles in launch order (A-B runs)
 int g_tail_split = -1;   // SIMQ_TAIL_SPLIT=1 switches the balanced last round on
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool BATCHED = false>
 int resident_blocks() {
     static int cached = 0;
     if (!cached) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_conv_kernel<BM, BN, VEC>, 256, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_conv_kernel<BM, BN, VEC, BATCHED>, 256, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 1;
         }
@@ -433,8 +476,20 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
             }
         }
     }
+    p.nt_run = 1;
+    int launch_tiles = p.full_tiles;
+    if constexpr (BATCHED) {
+        // N-tiles per block (SIMQ_GEMM_NT_RUN, default 1).  Measured on the headline step: runs of 1 / 2 / 4 N-tiles give
+        // 2422 / 2426 / 2391 tr/s -- carrying the pipeline across tiles does NOT recover the short-K loss (the shortk probe's
+        // 97 -> 130 TF/s from K = 256 to 1024 comes with 4x fewer output bytes per flop, not only fewer prologues), and
+        // longer runs cost block-level parallelism.  Kept as a switch for other shapes.
+        static const int forced = getenv("SIMQ_GEMM_NT_RUN") ? atoi(getenv("SIMQ_GEMM_NT_RUN")) : 1;
+        if ((p.K / BK) % 2 == 0 && forced >= 1 && p.tilesN % forced == 0) p.nt_run = forced;
+        launch_tiles = tilesM * (p.tilesN / p.nt_run);
+        p.full_tiles = launch_tiles;
+    }
     if (g_xcd_remap < 0) { const char* s = getenv("SIMQ_XCD_REMAP"); g_xcd_remap = (s && atoi(s) == 0) ? 0 : 1; }
-    p.xcd_chunk = (g_xcd_remap && p.tilesN > 1 && p.full_tiles >= 64) ? p.full_tiles / 8 : 0;
+    p.xcd_chunk = (g_xcd_remap && p.tilesN / p.nt_run > 1 && p.full_tiles >= 64) ? p.full_tiles / 8 : 0;
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant kernel of the headline workload (the batched transform-domain GEMM of the Winograd
@@ -499,7 +554,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
-    a.gx = a.gw = a.gy = 0; a.xcd_chunk = 0;
+    a.gx = a.gw = a.gy = 0; a.xcd_chunk = 0; a.nt_run = 1;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, wb = 4.0 * g.Cout * a.K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
@@ -533,7 +588,7 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     a.epi = make_epi(y, e);
     a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
     a.M = M; a.K = K; a.tilesN = 0;
-    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N; a.xcd_chunk = 0;
+    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N; a.xcd_chunk = 0; a.nt_run = 1;
     const double xb = 4.0 * M * K, wb = 4.0 * N * K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "gemm_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
