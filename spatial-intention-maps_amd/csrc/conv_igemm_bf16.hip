@@ -54,7 +54,9 @@ __global__ void __launch_bounds__(256) igemm_bf16_kernel(const IgemmBfArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / p.tilesN, tile_n = blockIdx.x % p.tilesN;
+    int tile = blockIdx.x;
+    if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
+    const int tile_m = tile / p.tilesN, tile_n = tile % p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     for (int r = tid; r < BM; r += 256) {
@@ -251,6 +253,7 @@ template <int BM, int BN, int NP, int BKB>
 int run(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
+    p.xcd_chunk = bf16_xcd_chunk(((p.M + BM - 1) / BM) * p.tilesN, p.tilesN);
     int tilesM = (p.M + BM - 1) / BM;
     prof_launch_begin(2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),

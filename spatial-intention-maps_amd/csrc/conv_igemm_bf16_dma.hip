@@ -66,7 +66,9 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_m = blockIdx.x / p.tilesN, tile_n = blockIdx.x % p.tilesN;
+    int tile = blockIdx.x;
+    if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
+    const int tile_m = tile / p.tilesN, tile_n = tile % p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int taps = p.R * p.S;
 
@@ -240,6 +242,7 @@ template <int BM, int BN, int WM, int NW = 4, int DBG = 0>
 int run(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
+    p.xcd_chunk = bf16_xcd_chunk(((p.M + BM - 1) / BM) * p.tilesN, p.tilesN);
     const int tilesM = (p.M + BM - 1) / BM;
     prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),

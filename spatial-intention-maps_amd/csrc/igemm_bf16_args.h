@@ -1,5 +1,6 @@
 // Kernel arguments shared by the bf16 implicit-GEMM kernels (conv_igemm_bf16.hip, conv_igemm_bf16_dma.hip).
 #pragma once
+#include <cstdlib>
 #include "igemm_epilogue.h"
 
 namespace simq {
@@ -11,6 +12,7 @@ struct IgemmBfArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesN;
+    int xcd_chunk;                 // XCD-aware tile order (see IgemmArgs in conv_igemm.hip): blocks b < 8 * xcd_chunk take tile (b % 8) * xcd_chunk + b / 8
     unsigned x_bytes, w_bytes;     // plane sizes for the bounds-checked buffer loads
 };
 
@@ -18,5 +20,11 @@ struct IgemmBfArgs {
 // conv_igemm_bf16_dma.hip: large-tile LDS-DMA kernel for plain bf16 operands; returns 1 when it took the launch,
 // 0 when the shape is not covered (the caller falls back to the register-staged kernel), < 0 on error.
 int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream);
+
+// SIMQ_XCD_REMAP=0 keeps launch order
+inline int bf16_xcd_chunk(int tiles, int tilesN) {
+    static const int on = (getenv("SIMQ_XCD_REMAP") && atoi(getenv("SIMQ_XCD_REMAP")) == 0) ? 0 : 1;
+    return (on && tilesN > 1 && tiles >= 64) ? tiles / 8 : 0;
+}
 
 }  // namespace simq
