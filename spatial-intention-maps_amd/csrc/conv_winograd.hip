@@ -245,6 +245,80 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
     }
 }
 
+// Transposed-output forms for the weight gradient: out[g][c][t] (tile index contiguous), so that dU[g] = dMt[g]^T V[g] is a plain
+// K-contiguous batched GEMM over K = T for the implicit-GEMM kernel (long K, no split / atomics).  A block covers 32 tiles x 32
+// channels: reads are 128-B channel segments, the 16 transform elements go through an LDS tile [4 g][32 c][32 t] four at a time
+// and leave as 128-B rows of 32 consecutive tiles.  DY = false: x -> (B^T d B)^T layout; DY = true: dy -> (A dY A^T).
+template <bool DY>
+__global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T) {
+    __shared__ float tbuf[4][32][33];
+    const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
+    const int cblocks = C >> 5;
+    const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
+    const int t = t0 + tl, c = c0 + cq * 4;
+    const int th = H >> 1, tw = W >> 1;
+    floatx4 v[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        const int b = t / (th * tw), r = t - b * (th * tw);
+        const int ty = r / tw, tx = r - ty * tw;
+        if constexpr (DY) {
+            const float* p0 = src + ((size_t)(b * H + 2 * ty) * W + 2 * tx) * C + c;
+            const floatx4 y00 = *reinterpret_cast<const floatx4*>(p0), y01 = *reinterpret_cast<const floatx4*>(p0 + C);
+            const floatx4 y10 = *reinterpret_cast<const floatx4*>(p0 + (size_t)W * C), y11 = *reinterpret_cast<const floatx4*>(p0 + (size_t)W * C + C);
+            floatx4 a[4][2];
+            a[0][0] = y00; a[0][1] = y01;
+            a[1][0] = y00 + y10; a[1][1] = y01 + y11;
+            a[2][0] = y00 - y10; a[2][1] = y01 - y11;
+            a[3][0] = -y10; a[3][1] = -y11;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i * 4 + 0] = a[i][0]; v[i * 4 + 1] = a[i][0] + a[i][1]; v[i * 4 + 2] = a[i][0] - a[i][1]; v[i * 4 + 3] = -a[i][1];
+            }
+        } else {
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            floatx4 d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = y0 + i, xx = x0 + j;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                        d[i][j] = *reinterpret_cast<const floatx4*>(src + ((size_t)(b * H + yy) * W + xx) * C + c);
+                    else
+                        d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            floatx4 e[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[0][j] = d[0][j] - d[2][j]; e[1][j] = d[1][j] + d[2][j]; e[2][j] = d[2][j] - d[1][j]; e[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i * 4 + 0] = e[i][0] - e[i][2]; v[i * 4 + 1] = e[i][1] + e[i][2]; v[i * 4 + 2] = e[i][2] - e[i][1]; v[i * 4 + 3] = e[i][1] - e[i][3];
+            }
+        }
+    }
+    const int wr = threadIdx.x >> 5, wc = threadIdx.x & 31;        // write phase: row group / tile column
+#pragma unroll
+    for (int gp = 0; gp < 4; ++gp) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tbuf[k][cq * 4 + e][tl] = v[gp * 4 + k][e];
+        __syncthreads();
+        if (t0 + wc < T) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = wr + 8 * i, k = row >> 5, cc = row & 31;
+                out[((size_t)(gp * 4 + k) * C + c0 + cc) * T + t0 + wc] = tbuf[k][cc][wc];
+            }
+        }
+    }
+}
+
 // dw[co][ky][kx][ci] = (G^T dU[.][co][ci] G)[ky][kx],  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
 __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin) {
     const int total = cout * cin;
@@ -355,18 +429,29 @@ bool winograd_wgrad_eligible(const ConvGeom& g) { return winograd_eligible(g) &&
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
     const int T = g.B * (g.Hin / 2) * (g.Win / 2);
-    float* V = scratch;
-    float* dM = scratch + (size_t)16 * T * g.Cin;
-    float* dU = dM + (size_t)16 * T * g.Cout;
-    const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
-    int bin = (T + tpb_in - 1) / tpb_in, bout = (T + tpb_out - 1) / tpb_out;
-    if (bin > 4096) bin = 4096;
-    if (bout > 4096) bout = 4096;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dM, g.B, g.Hin, g.Win, g.Cout, T);
-    SIMQ_CHECK_LAUNCH();
-    SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
-    if (int rc = launch_wgrad_batched(V, dM, dU, T, g.Cout, g.Cin, 16, stream)) return rc;
+    float* Vt = scratch;                                   // [16][Cin][T]
+    float* dMt = scratch + (size_t)16 * T * g.Cin;         // [16][Cout][T]
+    float* dU = dMt + (size_t)16 * T * g.Cout;             // [16][Cout][Cin]
+    static const int direct_form = getenv("SIMQ_WINOGRAD_WGRAD_SPLITK") ? atoi(getenv("SIMQ_WINOGRAD_WGRAD_SPLITK")) : 0;
+    if (direct_form || T % 16 != 0) {   // [g][t][c] operands, pixel-split batched wgrad_kernel with fp32 atomics: tile counts that are
+                                        // not a multiple of the GEMM's K-step (never the 24x24 maps of the network), and A-B runs
+        const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
+        int bin = (T + tpb_in - 1) / tpb_in, bout = (T + tpb_out - 1) / tpb_out;
+        if (bin > 4096) bin = 4096;
+        if (bout > 4096) bout = 4096;
+        hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T);
+        hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
+        SIMQ_CHECK_LAUNCH();
+        SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
+        if (int rc = launch_wgrad_batched(Vt, dMt, dU, T, g.Cout, g.Cin, 16, stream)) return rc;
+    } else {
+        // tile index contiguous: dU[g] = dMt[g] (Cout x T) * Vt[g]^T (T x Cin) is a K-contiguous GEMM with K = T
+        const int tb = (T + 31) / 32;
+        hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T);
+        hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
+        SIMQ_CHECK_LAUNCH();
+        if (int rc = launch_gemm_batched(dMt, Vt, dU, g.Cout, g.Cin, T, 16, stream)) return rc;
+    }
     int blocks = (g.Cout * g.Cin + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wino_dw_kernel, dim3(blocks), dim3(256), 0, stream, dU, dw, g.Cout, g.Cin);
