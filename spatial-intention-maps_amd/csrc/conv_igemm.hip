@@ -594,6 +594,8 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     // many rounds of short-K blocks: the 64x64 tile (6 resident blocks per CU) measured best on these shapes
     // (tools/probes/wino_gemm_probe.py: 104-107 TF/s at K = 256..512), 96x64 when the rows do not fill 64-row tiles evenly
+    // (64x32 / 32x32 tiles for the few-block transform-domain weight gradients -- 256 blocks of a 256 x 256 x 16 problem -- measured
+    // slower than one 64x64 block per CU: 0.181 vs 0.150 ms)
     return run<64, 64, true, true>(a, stream, batch);
 }
 
