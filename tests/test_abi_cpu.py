@@ -140,3 +140,29 @@ def test_reference_written_checkpoint_loads_without_the_reference(golden_dir):
     assert buf.buffer[1].next_state is buf.buffer[2].state                     # one ndarray, pickled once
     buf.push(tr[0][0], 1, 0.0, None)                                           # and it is a working ring
     assert buf.position == 2 and len(buf) == 3
+
+
+def test_winograd_transform_matrices_are_an_exact_restatement_of_the_convolution():
+    """The matrices conv_winograd.hip hard-codes (F(2x2,3x3): B^T, G, A^T and the transposes its weight gradient uses), in
+    fp64 numpy: Y = A^T[(G g G^T) . (B^T d B)]A is the 3x3 correlation of a 4x4 patch, and dMt = A dY A^T, dU = dMt . V,
+    dg = G^T dU G is its exact weight gradient."""
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    rng = np.random.RandomState(0)
+    d, g, dY = rng.randn(4, 4), rng.randn(3, 3), rng.randn(2, 2)
+    direct = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(2)] for i in range(2)])
+    V, U = BT @ d @ BT.T, G @ g @ G.T
+    assert np.allclose(AT @ (U * V) @ AT.T, direct, atol=1e-13)
+    dg_direct = np.array([[(dY * d[ky:ky + 2, kx:kx + 2]).sum() for kx in range(3)] for ky in range(3)])
+    dU = (AT.T @ dY @ AT) * V
+    assert np.allclose(G.T @ dU @ G, dg_direct, atol=1e-13)
+    # data gradient = the same forward transform applied to dY with the flipped filter (what the plan's dgrad launches do)
+    dd_direct = np.zeros((4, 4))
+    for i in range(2):
+        for j in range(2):
+            dd_direct[i:i + 3, j:j + 3] += dY[i, j] * g
+    dyp = np.zeros((6, 6)); dyp[2:4, 2:4] = dY                       # zero-padded dY, 'full' correlation with the flipped filter
+    gf = g[::-1, ::-1]
+    full = np.array([[(dyp[i:i + 3, j:j + 3] * gf).sum() for j in range(4)] for i in range(4)])
+    assert np.allclose(full, dd_direct, atol=1e-13)
