@@ -203,7 +203,8 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const floa
                              double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
 /* Weight gradient of the same convolution through the transform domain (dy / x transforms, 16 batched contractions over
  * the tiles, G^T dU G).  Additionally cin % 128 == 0 and cout % 128 == 0.  d_dw is overwritten.
- * d_scratch: 16*T*(cin+cout) + 16*cout*cin floats. */
+ * the tiles, G^T dU G); uses F(4x4,3x3) when hin, win are multiples of 4 and batch*(hin/4)*(win/4) is a multiple of 16.
+ * d_scratch: 16*T*(cin+cout) + 36*cout*cin floats. */
 int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw_ohwi,
                                int batch, int hin, int win, int cin, int cout, float* d_scratch, void* stream);
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scratch, float* d_dx,

@@ -80,6 +80,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
 int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
 bool winograd_wgrad_eligible(const ConvGeom& g);
 bool winograd_wgrad_enabled();
+bool winograd_wgrad_pays(const ConvGeom& g);
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream);
 int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs

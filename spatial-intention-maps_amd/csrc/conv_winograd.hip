@@ -319,6 +319,131 @@ __global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ 
     }
 }
 
+// ---- F(4x4, 3x3) for the weight gradient only --------------------------------------------------------------------------
+// 36 products per 4x4 outputs (2.25 per output instead of 4): 1.78x fewer matrix FLOPs again and 2.25x instead of 4x transform
+// volume.  Its larger transform coefficients (up to 8, 1/24) cost ~10x the round-off of F(2x2,3x3) -- 6e-6 of the gradient's range in
+// fp32 (simulated and measured, tests/test_gpu_ops.py) -- which is harmless HERE because a weight gradient is a leaf: nothing is
+// propagated through it, whereas forward / dgrad errors would compound through eight layers (those stay F(2x2,3x3)).
+//   dMt = A dY A^T (6x6 from 4x4),  V = B^T d B (6x6 patch, stride 4),  dU[g] = dMt[g] . V[g]^T over the tiles,  dw = G^T dU G
+__device__ __forceinline__ void w4_bt(floatx4 (&a)[6]) {      // a <- B^T a
+    const floatx4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+    a[0] = 4.f * a0 - 5.f * a2 + a4;
+    a[1] = -4.f * (a1 + a2) + a3 + a4;
+    a[2] = 4.f * (a1 - a2) - a3 + a4;
+    a[3] = 2.f * (a3 - a1) - a2 + a4;
+    a[4] = 2.f * (a1 - a3) - a2 + a4;
+    a[5] = 4.f * a1 - 5.f * a3 + a5;
+}
+__device__ __forceinline__ void w4_a(const floatx4 (&y)[4], floatx4 (&r)[6]) {   // r <- A y  (A = (A^T)^T, 6x4)
+    const floatx4 e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.f * y[2], o8 = 2.f * y[1] + 8.f * y[3];
+    r[0] = y[0];
+    r[1] = e + o;
+    r[2] = e - o;
+    r[3] = e4 + o8;
+    r[4] = e4 - o8;
+    r[5] = y[3];
+}
+
+template <bool DY>
+__global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T) {
+    __shared__ float tbuf[4][32][33];
+    const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
+    const int cblocks = C >> 5;
+    const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
+    const int t = t0 + tl, c = c0 + cq * 4;
+    const int th = H >> 2, tw = W >> 2;
+    floatx4 v[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        const int b = t / (th * tw), r = t - b * (th * tw);
+        const int ty = r / tw, tx = r - ty * tw;
+        if constexpr (DY) {
+            floatx4 col[4][6];                       // A dY, column by column of dY
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                floatx4 y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const floatx4*>(src + ((size_t)(b * H + 4 * ty + i) * W + 4 * tx + j) * C + c);
+                w4_a(y, col[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {            // (A dY) A^T, row by row
+                const floatx4 y[4] = {col[0][i], col[1][i], col[2][i], col[3][i]};
+                w4_a(y, v[i]);
+            }
+        } else {
+            const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {            // B^T d, column by column
+                floatx4 a[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int yy = y0 + i, xx = x0 + j;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                        a[i] = *reinterpret_cast<const floatx4*>(src + ((size_t)(b * H + yy) * W + xx) * C + c);
+                    else
+                        a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+                w4_bt(a);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[i][j] = a[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w4_bt(v[i]); // (B^T d) B, row by row
+        }
+    }
+    const int wr = threadIdx.x >> 5, wc = threadIdx.x & 31;
+#pragma unroll
+    for (int gp = 0; gp < 9; ++gp) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tbuf[k][cq * 4 + e][tl] = v[(gp * 4 + k) / 6][(gp * 4 + k) % 6][e];
+        __syncthreads();
+        if (t0 + wc < T) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = wr + 8 * i, k = row >> 5, cc = row & 31;
+                out[((size_t)(gp * 4 + k) * C + c0 + cc) * T + t0 + wc] = tbuf[k][cc][wc];
+            }
+        }
+    }
+}
+
+// dw[co][ky][kx][ci] = (G^T dU[.][co][ci] G)[ky][kx],  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+__device__ __forceinline__ void w4_gt(const float (&u)[6], float (&s)[3]) {
+    const float p = u[1] + u[2], m = u[2] - u[1], q = u[3] + u[4], n = u[3] - u[4];
+    s[0] = 0.25f * u[0] - (1.f / 6.f) * p + (1.f / 24.f) * q;
+    s[1] = (1.f / 6.f) * m + (1.f / 12.f) * n;
+    s[2] = -(1.f / 6.f) * p + (1.f / 6.f) * q + u[5];
+}
+__global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin) {
+    const int total = cout * cin;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i / cin, ci = i - co * cin;
+        float t[3][6];                              // G^T dU
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float u[6], s3[3];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r] = dU[(size_t)(r * 6 + c) * total + i];
+            w4_gt(u, s3);
+            t[0][c] = s3[0]; t[1][c] = s3[1]; t[2][c] = s3[2];
+        }
+        float* o = dw + (size_t)co * 9 * cin + ci;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s3[3];
+            w4_gt(t[r], s3);
+            o[(r * 3 + 0) * cin] = s3[0]; o[(r * 3 + 1) * cin] = s3[1]; o[(r * 3 + 2) * cin] = s3[2];
+        }
+    }
+}
+
 // dw[co][ky][kx][ci] = (G^T dU[.][co][ci] G)[ky][kx],  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
 __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin) {
     const int total = cout * cin;
@@ -423,8 +548,18 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
 }
 
 // Weight gradient of an eligible convolution through the transform domain: dw (OHWI, overwritten) from x and dy.
-// scratch: winograd_scratch_floats(g) + 16*Cout*Cin floats (V | dMt | dU).  Cin % 128 == 0 and Cout % 128 == 0.
+// scratch: winograd_scratch_floats(g) + 36*Cout*Cin floats (V | dMt | dU; the F(4x4,3x3) form needs 9*T*(Cin+Cout) + 36*Cout*Cin).
+// Cin % 128 == 0 and Cout % 128 == 0.
 bool winograd_wgrad_eligible(const ConvGeom& g) { return winograd_eligible(g) && g.Cin % 128 == 0 && g.Cout % 128 == 0; }
+
+bool winograd_wgrad_f4(const ConvGeom& g) {   // the F(4x4,3x3) form applies (SIMQ_WINOGRAD_WGRAD_F4=0 switches it off)
+    static const int f4 = getenv("SIMQ_WINOGRAD_WGRAD_F4") ? atoi(getenv("SIMQ_WINOGRAD_WGRAD_F4")) : 1;
+    return f4 && g.Hin % 4 == 0 && g.Win % 4 == 0 && (g.B * (g.Hin / 4) * (g.Win / 4)) % 16 == 0;
+}
+
+// where the transform domain beats the direct wgrad kernel (tools/winograd_probe.py): from 256 x 256 channels with F(2x2,3x3),
+// from 128 x 256 with F(4x4,3x3) (0.081 vs 0.118 ms; F(2x2,3x3) loses there)
+bool winograd_wgrad_pays(const ConvGeom& g) { return (long)g.Cin * g.Cout >= (winograd_wgrad_f4(g) ? 128L * 256 : 256L * 256); }
 
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
@@ -433,6 +568,22 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
     float* dMt = scratch + (size_t)16 * T * g.Cin;         // [16][Cout][T]
     float* dU = dMt + (size_t)16 * T * g.Cout;             // [16][Cout][Cin]
     static const int direct_form = getenv("SIMQ_WINOGRAD_WGRAD_SPLITK") ? atoi(getenv("SIMQ_WINOGRAD_WGRAD_SPLITK")) : 0;
+    const int T4 = g.B * (g.Hin / 4) * (g.Win / 4);
+    if (!direct_form && winograd_wgrad_f4(g)) {   // F(4x4,3x3): 36 GEMMs over T4 = T / 4 tiles
+        float* Vt4 = scratch;                                   // [36][Cin][T4]
+        float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][Cout][T4]
+        float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][Cout][Cin]
+        const int tb = (T4 + 31) / 32;
+        hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4);
+        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4);
+        SIMQ_CHECK_LAUNCH();
+        if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, T4, 36, stream)) return rc;
+        int blocks4 = (g.Cout * g.Cin + 255) / 256;
+        if (blocks4 > 2048) blocks4 = 2048;
+        hipLaunchKernelGGL(wino4_dw_kernel, dim3(blocks4), dim3(256), 0, stream, dU4, dw, g.Cout, g.Cin);
+        SIMQ_CHECK_LAUNCH();
+        return 0;
+    }
     if (direct_form || T % 16 != 0) {   // [g][t][c] operands, pixel-split batched wgrad_kernel with fp32 atomics: tile counts that are
                                         // not a multiple of the GEMM's K-step (never the 24x24 maps of the network), and A-B runs
         const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);

@@ -97,7 +97,7 @@ struct Builder {
             ConvGeom gt = g;
             gt.Cin = cout; gt.Cout = cin;
             if (winograd_eligible(g)) {
-                p->wino_du_floats = std::max(p->wino_du_floats, 16 * c.wcount() / 9);
+                p->wino_du_floats = std::max(p->wino_du_floats, 36 * c.wcount() / 9);   // dU of the F(4x4,3x3) weight gradient
                 c.wu_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
                 p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(g));
             }
@@ -416,8 +416,7 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
     }
-    // (the 128 -> 256 layer loses in the transform domain: 0.118 vs 0.112 ms, tools/winograd_probe.py)
-    if (cv.wu_off >= 0 && c.L.wino >= 0 && (long)cv.cin * cv.cout >= 256L * 256 && winograd_wgrad_eligible(g) && winograd_wgrad_enabled())
+    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && winograd_wgrad_pays(g) && winograd_wgrad_enabled())
         return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream);
     return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
 }

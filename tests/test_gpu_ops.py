@@ -377,15 +377,18 @@ def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
     assert rel(s1, sref) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (6, 12, 256, 256)], ids=['l4', 'l4a', 'l3_small_map'])
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (6, 12, 256, 256), (8, 24, 512, 512), (4, 24, 256, 256)],
+                         ids=['l4', 'l4a', 'l3_small_map', 'l4_f4', 'l3_f4'])
 def test_conv_winograd_wgrad_matches_direct(L, B, H, Cin, Cout):
-    """Transform-domain weight gradient (dy / x transforms, 16 batched contractions over the tiles, G^T dU G) against the
-    direct wgrad kernel and fp64."""
+    """Transform-domain weight gradient (dy / x transforms, batched contractions over the tiles, G^T dU G) against the
+    direct wgrad kernel and fp64.  Tile counts that allow it ('*_f4': batch * 36 a multiple of 16) take the F(4x4,3x3) form,
+    whose larger coefficients cost ~10x the round-off (measured 0.6-3e-5 of the gradient's range) -- held to the 1e-4
+    per-kernel bar (a weight gradient is a leaf: the error does not propagate); the others run F(2x2,3x3) (GEMM form, or the pixel-split form when the tile count is not a multiple of 16)."""
     g = torch.Generator().manual_seed(29 + Cin + Cout + B)
     x = torch.randn(B, H, H, Cin, generator=g).cuda()
     dy = torch.randn(B, H, H, Cout, generator=g).cuda()
     T = B * (H // 2) ** 2
-    scratch = torch.empty(16 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+    scratch = torch.empty(36 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
     st = L.stream_ptr()
     d0, d1 = torch.empty(Cout, 3, 3, Cin, device='cuda'), torch.full((Cout, 3, 3, Cin), float('nan'), device='cuda')
     L.lib.call('simq_conv2d_wgrad', L.ptr(x), L.ptr(dy), L.ptr(d0), B, H, H, Cin, Cout, 3, 3, 1, 1, st)
@@ -393,7 +396,7 @@ def test_conv_winograd_wgrad_matches_direct(L, B, H, Cin, Cout):
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
                                       padding=1).permute(0, 2, 3, 1)
     assert torch.isfinite(d1).all()
-    assert rel(d1, ref) < 1e-5 and rel(d0, ref) < 1e-5
+    assert rel(d1, ref) < (1e-4 if B % 4 == 0 else 1e-5) and rel(d0, ref) < 1e-5
 
 
 def test_conv_winograd_rejects_unsupported_geometry(L):

@@ -41,11 +41,11 @@ for B in [int(a) for a in sys.argv[1:]] or [32, 29]:
 
 print('--- weight gradient: direct kernel vs transform domain ---')
 for B in (32,):
-    for name, Cin, Cout in [('l4', 512, 512), ('l4a', 256, 512), ('l3', 256, 256), ('l3a', 128, 256)]:
+    for name, Cin, Cout in [('l4', 512, 512), ('l4a', 256, 512), ('l3', 256, 256), ('l3a', 128, 256), ('l2', 128, 128)]:
         H = 24
         x = torch.randn(B, H, H, Cin, device='cuda'); dy = torch.randn(B, H, H, Cout, device='cuda')
         T = B * (H // 2) ** 2
-        scratch = torch.empty(16 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+        scratch = torch.empty(36 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
         d0, d1 = torch.empty(Cout, 3, 3, Cin, device='cuda'), torch.empty(Cout, 3, 3, Cin, device='cuda')
         f0 = lambda: L.lib.call('simq_conv2d_wgrad', L.ptr(x), L.ptr(dy), L.ptr(d0), B, H, H, Cin, Cout, 3, 3, 1, 1, st)
         f1 = lambda: L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d1), B, H, H, Cin, Cout, L.ptr(scratch), st)
