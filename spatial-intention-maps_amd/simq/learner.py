@@ -116,6 +116,35 @@ class _DeviceObs:
         return '_DeviceObs(slot=%d, shape=%s)' % (self.slot, self.shape)
 
 
+class _PinnedStaging:
+    """Host side of the collector hand-off: observations are copied into a small ring of pinned host slots and
+    uploaded with asynchronous H2D copies, so `push` returns as soon as the ndarray is staged and the environment can keep stepping
+    while the copy (and the learner's kernels) run.  A slot is reused only after the copy that last read it has finished."""
+
+    def __init__(self, item_shape, device, slots=32):
+        self.device = device
+        self.enabled = device.type == 'cuda' and torch.cuda.is_available()
+        self.slots = slots
+        self.pos = 0
+        if self.enabled:
+            self.buf = torch.empty((slots,) + tuple(item_shape), dtype=torch.float32).pin_memory()
+            self.events = [None] * slots
+
+    def upload(self, arr, dst):
+        if not self.enabled:
+            dst.copy_(torch.as_tensor(arr))
+            return
+        i = self.pos
+        self.pos = (i + 1) % self.slots
+        if self.events[i] is not None:
+            self.events[i].synchronize()                       # the copy that last used this slot (32 pushes ago) is long done
+        self.buf[i].copy_(torch.as_tensor(arr))                # host memcpy into pinned memory
+        dst.copy_(self.buf[i], non_blocking=True)              # asynchronous H2D on the current stream
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[i] = ev
+
+
 class DeviceReplayBuffer:
     """ReplayBuffer (train.py:28-45) with the states in an HBM ring.
 
@@ -132,6 +161,7 @@ class DeviceReplayBuffer:
         self.item = W * W * self.C
         self.states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
         self.next_states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
+        self._staging = _PinnedStaging((W, W, self.C), self.device)
         self.buffer = []
         self.position = 0
 
@@ -139,9 +169,9 @@ class DeviceReplayBuffer:
         if len(self.buffer) < self.capacity:
             self.buffer.append(None)
         slot = self.position
-        self.states[slot].copy_(torch.as_tensor(state), non_blocking=True)
+        self._staging.upload(state, self.states[slot])
         if next_state is not None:
-            self.next_states[slot].copy_(torch.as_tensor(next_state), non_blocking=True)
+            self._staging.upload(next_state, self.next_states[slot])
         self.buffer[slot] = Transition(_DeviceObs(self.states, slot), int(action), float(reward),
                                        _DeviceObs(self.next_states, slot) if next_state is not None else None)
         self.position = (self.position + 1) % self.capacity
@@ -237,6 +267,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
         n = int(pool_slots) if pool_slots is not None else self.capacity + max(256, self.capacity // 4)
         self.pool = torch.empty((n, W, W, self.C), dtype=torch.float32, device=self.device)
         self.states = self.next_states = self.pool          # both gathers of the base class read the one pool
+        self._staging = _PinnedStaging((W, W, self.C), self.device)
         self._free = list(range(n - 1, -1, -1))
         self._ref = [0] * n
         self._recent = {}                                   # id(ndarray) -> (slot, ndarray): observations uploaded lately
@@ -252,7 +283,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
             raise SimqError('AliasedDeviceReplayBuffer: observation pool exhausted (%d slots); the pushes do not alias '
                             'next_state/state -- construct with pool_slots=2*capacity' % len(self._ref))
         slot = self._free.pop()
-        self.pool[slot].copy_(torch.as_tensor(arr), non_blocking=True)
+        self._staging.upload(arr, self.pool[slot])
         self._recent[id(arr)] = (slot, arr)
         self._recent_order.append(id(arr))
         if len(self._recent_order) > 256:

@@ -591,3 +591,32 @@ def test_winograd_layers_equal_direct_convolution_network(simq_mod):
     assert abs(ia['loss'] - ib['loss']) <= 1e-5 * abs(ib['loss'])
     # gradient conditioning, see this file's header (both forms are judged against the fp64 oracle elsewhere)
     assert float((ga - gb).double().norm() / gb.double().norm()) < 2e-2
+
+
+def test_replay_push_stages_through_pinned_memory(simq_mod):
+    """Collector hand-off: push() copies the observation into a pinned staging slot and issues an asynchronous
+    H2D copy.  The caller may overwrite its ndarray right after push() returns, and more pushes than staging slots recycle
+    the slots without corrupting earlier uploads."""
+    from simq.learner import AliasedDeviceReplayBuffer, DeviceReplayBuffer
+    rng = np.random.RandomState(12)
+    C = 4
+    for cls in (DeviceReplayBuffer, AliasedDeviceReplayBuffer):
+        ring = cls(80, C)
+        assert ring._staging.enabled and ring._staging.buf.is_pinned()
+        kept, scratch = [], np.empty((96, 96, C), dtype=np.float32)
+        for i in range(70):                                    # > 2 x 32 staging slots
+            obs = rng.rand(96, 96, C).astype(np.float32)
+            nxt = rng.rand(96, 96, C).astype(np.float32)
+            kept.append((obs.copy(), nxt.copy()))
+            if cls is DeviceReplayBuffer:
+                scratch[...] = obs
+                ring.push(scratch, i, 0.5, nxt)
+                scratch[...] = -1.0                            # the collector reuses its buffer immediately
+            else:                                              # the aliased ring identifies an observation by its ndarray OBJECT
+                ring.push(obs, i, 0.5, nxt)                    # (train.py:61-66), so every observation is its own array ...
+                obs[...] = -1.0                                # ... which may still be overwritten once push() has returned
+            nxt[...] = -2.0
+        torch.cuda.synchronize()
+        for i in (0, 1, 31, 32, 33, 64, 69):
+            rec = ring.buffer[i]
+            assert np.array_equal(np.asarray(rec.state), kept[i][0]) and np.array_equal(np.asarray(rec.next_state), kept[i][1])
