@@ -15,13 +15,15 @@ _LAZY = {
     'ReplayBuffer': ('.learner', 'ReplayBuffer'),
     'DeviceReplayBuffer': ('.learner', 'DeviceReplayBuffer'),
     'AliasedDeviceReplayBuffer': ('.learner', 'AliasedDeviceReplayBuffer'),
-    'TransitionTracker': ('.learner', 'TransitionTracker'),
+    'TransitionTracker': ('.tracker', 'TransitionTracker'),
     'Transition': ('.learner', 'Transition'),
     'train': ('.learner', 'train'),
     'train_step': ('.learner', 'train_step'),
     'train_intention': ('.learner', 'train_intention'),
     'train_intention_step': ('.learner', 'train_intention_step'),
     'lib': ('._lib', 'lib'),
+    'Collector': ('.collector', 'Collector'),
+    'CollectWorker': ('.collector', 'CollectWorker'),
     'save_policy': ('.checkpoint', 'save_policy'),
     'save_checkpoint': ('.checkpoint', 'save_checkpoint'),
     'load_checkpoint': ('.checkpoint', 'load_checkpoint'),

@@ -26,6 +26,7 @@ import torch
 from . import arch, dist as sdist
 from ._lib import MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD, SimqError, TrainArgs, lib, ptr, stream_ptr
 from .fcn import FCN
+from .tracker import TransitionTracker  # noqa: F401  (train.py:47-68; lives in its own torch-free module for the collector workers)
 
 Transition = namedtuple('Transition', ('state', 'action', 'reward', 'next_state'))   # train.py:26
 W = arch.STATE_WIDTH
@@ -219,35 +220,6 @@ class DeviceReplayBuffer:
 
     def sample(self, batch_size):
         return self.gather(self.sample_indices(batch_size))
-
-
-class TransitionTracker:
-    """Drop-in for train.TransitionTracker (train.py:47-68): remembers, per robot, the observation and action the robot is
-    waiting on and turns (reward, new observation, done) into replay transitions.  The SAME ndarray object is handed out
-    as `next_state` of one transition and `state` of the next one -- AliasedDeviceReplayBuffer uploads it once."""
-
-    def __init__(self, initial_state):
-        self.num_buffers = len(initial_state)
-        self.prev_state = initial_state
-        self.prev_action = [[None] * len(group) for group in initial_state]
-
-    def update_action(self, action):
-        for i, group in enumerate(action):
-            for j, a in enumerate(group):
-                if a is not None:
-                    self.prev_action[i][j] = a
-
-    def update_step_completed(self, reward, state, done):
-        out = [[] for _ in range(self.num_buffers)]
-        for i, group in enumerate(state):
-            for j, s in enumerate(group):
-                if s is None and not done:
-                    continue                                    # this robot has not finished its action yet
-                before = self.prev_state[i][j]
-                if before is not None:
-                    out[i].append((before, self.prev_action[i][j], reward[i][j], s))
-                self.prev_state[i][j] = s
-        return out
 
 
 class AliasedDeviceReplayBuffer(DeviceReplayBuffer):

@@ -87,6 +87,39 @@ class DQNPolicy:
         return action
 
 
+    def step_many(self, states, exploration_eps=None):
+        """`step` for several environments at once (train_multiprocess.py:254-264 serves its collector workers
+        one B=1 `policy.step` at a time): the awaiting robots of ALL environments share one eval forward + one argmax launch per
+        robot group.  The epsilon-greedy draws are made in the order sequential `step(states[0])`, `step(states[1])`, ... calls
+        would make them, so a seeded run selects the same actions.  Returns one action structure per environment."""
+        if exploration_eps is None:
+            exploration_eps = self.cfg.final_exploration
+        actions = [[[None for _ in g] for g in st] for st in states]
+        greedy = {}
+        with torch.no_grad():
+            for i in range(self.num_robot_groups):
+                live = [(e, j) for e, st in enumerate(states) for j, s in enumerate(st[i]) if s is not None]
+                if not live:
+                    continue
+                net = self.policy_nets[i]
+                net.eval()
+                idx, _ = net.infer_argmax_batch([states[e][i][j] for e, j in live], need_q=False)
+                for (e, j), a in zip(live, idx):
+                    greedy[(e, i, j)] = a
+                if self.train:
+                    net.train()
+        for e, st in enumerate(states):                          # RNG draws: environment by environment, then (i, j) as in step()
+            for i, g in enumerate(st):
+                for j, s in enumerate(g):
+                    if s is None:
+                        continue
+                    if random.random() < exploration_eps:
+                        actions[e][i][j] = random.randrange(arch.get_action_space(self.robot_group_types[i]))
+                    else:
+                        actions[e][i][j] = greedy[(e, i, j)]
+        return actions
+
+
 class DQNIntentionPolicy(DQNPolicy):
     """Drop-in for policies.DQNIntentionPolicy (policies.py:76-146): one intention net FCN(C-1, 1) per robot group
     predicts the other robots' intention map, which is appended to the state before the Q-network runs.  The predicted

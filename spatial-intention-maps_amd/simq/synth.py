@@ -86,3 +86,33 @@ def make_transitions(n, num_input_channels, num_output_channels, seed, terminal_
     for i in range(n):
         out.append((states[i], int(actions[i]), float(rewards[i]), None if terminal[i] else next_states[i]))
     return out
+
+
+class SyntheticEnv:
+    """reset() -> state ; step(action) -> (state, reward, done, info) with the nested [group][robot] lists of envs.py."""
+
+    def __init__(self, robot_config, channels, seed, episode_len=25):
+        self.groups = [next(iter(g.values())) for g in robot_config]
+        self.C, self.rng, self.episode_len, self.t = channels, np.random.RandomState(seed), episode_len, 0
+
+    def _obs(self):
+        return self.rng.rand(arch.STATE_WIDTH, arch.STATE_WIDTH, self.C).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        return [[self._obs() for _ in range(n)] for n in self.groups]
+
+    def step(self, action):
+        self.t += 1
+        done = self.t >= self.episode_len
+        state = [[self._obs() if (self.rng.rand() < 0.7 and not done) else None for _ in range(n)] for n in self.groups]
+        if not done and all(s is None for g in state for s in g):
+            state[0][0] = self._obs()
+        reward = [[float(np.clip(self.rng.randn(), -1.5, 2.0)) for _ in range(n)] for n in self.groups]
+        return state, reward, done, {'steps': self.t}
+
+
+def synthetic_env_from_cfg(cfg, worker_index=0):
+    """Environment factory for simq.collector (stands where utils.get_env_from_cfg is in train_multiprocess.py:162)."""
+    return SyntheticEnv(cfg.robot_config, cfg.num_input_channels, seed=getattr(cfg, 'seed', 0) + 1000 * worker_index,
+                        episode_len=getattr(cfg, 'episode_len', 25))

@@ -266,3 +266,67 @@ def test_reference_style_main_loop_on_synthetic_env(simq_mod, tmp_path, intentio
     _, log3, _, checkpoint3 = ts.run(cfg3, str(tmp_path), verbose=False)
     assert log3 and min(t for t, _, _ in log3) > 45 and all(np.isfinite(v) for _, _, info in log3 for v in info.values())
     assert os.path.basename(checkpoint3) == 'checkpoint_00000055.pth.tar' and not os.path.exists(checkpoint_path)
+
+
+def test_multiprocess_collector_round_robin_and_batched(simq_mod):
+    """train_multiprocess.py:147-275 on the drop-ins: environments step in spawned worker processes (CPU only), the learner
+    process serves them.  (1) Collector.step is the reference's round-robin and, for the same seeds, produces exactly the
+    transitions the in-process collector produces for worker 0's environment; (2) Collector.step_all serves all workers from ONE
+    batched forward (DQNPolicy.step_many), whose greedy actions equal per-environment policy.step; the transitions go into a
+    device replay ring and a training step runs on them."""
+    import types
+    from simq.collector import Collector
+    from simq.synth import synthetic_env_from_cfg
+    cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], num_input_channels=4, final_exploration=0.01,
+                                checkpoint_path=None, policy_path=None, seed=3, episode_len=6, batch_size=8, use_double_dqn=True,
+                                grad_norm_clipping=100)
+    policy = simq_mod.DQNPolicy(cfg, train=True, random_seed=7)
+    # step_many == step, environment by environment (greedy: eps = 0)
+    envs = [synthetic_env_from_cfg(cfg, w) for w in range(3)]
+    states = [e.reset() for e in envs]
+    states[1][0][1] = None                                      # a robot that is not awaiting an action
+    many = policy.step_many(states, exploration_eps=0.0)
+    assert many == [policy.step(st, exploration_eps=0.0) for st in states]
+    random.seed(5); a = policy.step_many(states, exploration_eps=0.5)
+    random.seed(5); b = [policy.step(st, exploration_eps=0.5) for st in states]
+    assert a == b                                               # same epsilon-greedy draw order as sequential step() calls
+
+    # (1) round-robin over 2 worker processes vs the in-process collector (same env seeds for worker 0)
+    col = Collector(cfg, policy, num_workers=2, env_fn=synthetic_env_from_cfg)
+    ref = Collector(cfg, policy, num_workers=None, env_fn=synthetic_env_from_cfg)
+    try:
+        got0 = []
+        for k in range(16):
+            tr, done = col.step(0.0)
+            if k % 2 == 0 and k >= 2:                           # call k serves worker k % 2 and returns the result of ITS previous
+                got0.append((tr, done))                         # action, i.e. worker 0's env step k // 2 - 1
+        want0 = [ref.step(0.0) for _ in range(7)]
+        assert len(got0) == 7
+        for (tg, dg), (tw, dw) in zip(got0, want0):
+            assert dg == dw and len(tg) == len(tw)
+            for bg, bw in zip(tg, tw):
+                assert len(bg) == len(bw)
+                for (s, a_, r, ns), (s2, a2, r2, ns2) in zip(bg, bw):
+                    assert np.array_equal(s, s2) and a_ == a2 and r == r2 and ((ns is None) == (ns2 is None))
+    finally:
+        col.close()
+        ref.close()
+
+    # (2) batched service of 3 workers feeding device rings, then one training step per robot group
+    col = Collector(cfg, policy, num_workers=3, env_fn=synthetic_env_from_cfg)
+    rings = [simq_mod.DeviceReplayBuffer(256, 4) for _ in range(2)]
+    try:
+        for _ in range(14):
+            for tr, done in col.step_all(0.3):
+                for i, per_buffer in enumerate(tr):
+                    for t in per_buffer:
+                        rings[i].push(*t)
+    finally:
+        col.close()
+    assert all(len(r) >= cfg.batch_size for r in rings)
+    targets = policy.build_policy_nets()
+    for i in range(2):
+        targets[i].load_state_dict(policy.policy_nets[i].state_dict()); targets[i].eval()
+        opt = torch.optim.SGD(policy.policy_nets[i].parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        info = simq_mod.train(cfg, policy.policy_nets[i], targets[i], opt, rings[i].sample(cfg.batch_size), policy.apply_transform, 0.85)
+        assert np.isfinite(info['loss']) and np.isfinite(info['td_error'])

@@ -20,28 +20,7 @@ import simq  # noqa: E402
 from simq import arch  # noqa: E402
 
 
-class SyntheticEnv:
-    """reset() -> state ; step(action) -> (state, reward, done, info) with the nested [group][robot] lists of envs.py."""
-
-    def __init__(self, robot_config, channels, seed, episode_len=25):
-        self.groups = [next(iter(g.values())) for g in robot_config]
-        self.C, self.rng, self.episode_len, self.t = channels, np.random.RandomState(seed), episode_len, 0
-
-    def _obs(self):
-        return self.rng.rand(arch.STATE_WIDTH, arch.STATE_WIDTH, self.C).astype(np.float32)
-
-    def reset(self):
-        self.t = 0
-        return [[self._obs() for _ in range(n)] for n in self.groups]
-
-    def step(self, action):
-        self.t += 1
-        done = self.t >= self.episode_len
-        state = [[self._obs() if (self.rng.rand() < 0.7 and not done) else None for _ in range(n)] for n in self.groups]
-        if not done and all(s is None for g in state for s in g):
-            state[0][0] = self._obs()
-        reward = [[float(np.clip(self.rng.randn(), -1.5, 2.0)) for _ in range(n)] for n in self.groups]
-        return state, reward, done, {'steps': self.t}
+from simq.synth import SyntheticEnv  # noqa: E402,F401
 
 
 def run(cfg, checkpoint_dir, verbose=True):
