@@ -186,3 +186,11 @@ class DQNIntentionPolicy(DQNPolicy):
             info['output_intention'] = info_intention['output_intention']
             return action, info
         return action
+
+    def step_many(self, states, exploration_eps=None, use_ground_truth_intention=False):
+        """Several environments at once.  With ground-truth intention maps the batched DQNPolicy.step_many applies; the
+        predicted-intention path chains two networks per robot group and is served environment by environment (same results
+        and RNG order as sequential step() calls)."""
+        if self.train and use_ground_truth_intention:
+            return super().step_many(states, exploration_eps=exploration_eps)
+        return [self.step(st, exploration_eps=exploration_eps, use_ground_truth_intention=use_ground_truth_intention) for st in states]
