@@ -133,8 +133,10 @@ def test_train_intention_golden(case, golden_dir):
     info = [learner.train_intention_step(st, spec, mom, batch, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, extras=ex[i])
             for i in range(2)]
     assert all(set(i) == {'loss_intention'} for i in info)
-    assert rel([i['loss_intention'] for i in info], g['loss_intention']) < 2e-5
-    assert rel(ex[0]['output'].numpy(), g['output_step1']) < 2e-5
+    # bit-exact on the host that wrote the fixture; other CPUs select different MKL-DNN kernels (fp32 summation order), and the
+    # second call's loss sees the first update: bars as for the other train-mode fixtures
+    assert rel([i['loss_intention'] for i in info], g['loss_intention']) < 5e-4
+    assert rel(ex[0]['output'].numpy(), g['output_step1']) < 2e-4
     assert all(int(st[k]) == 2 for k in st if k.endswith('num_batches_tracked'))      # one train-mode forward per call
     g32 = cases.grad_summary(ex[0]['grads'])
     num = sum(((g32[k][1:] - g['grad64'][i][1:]) ** 2).sum() for i, k in enumerate(g32))
@@ -152,7 +154,7 @@ def test_intention_policy_step_golden(golden_dir):
     s = synth.make_states(2, 4, 81)
     a, info = pol.step([[s[0]], [s[1]]], exploration_eps=0.0, debug=True)
     assert [a[0][0], a[1][0]] == g['actions'].tolist()
-    assert rel(np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]), g['output_intention']) < 1e-5
+    assert rel(np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]), g['output_intention']) < 1e-4   # host-independent bar
     si = info['state_intention'][0][0]
     assert si.shape == (96, 96, 5) and np.array_equal(si[:, :, :4], s[0]) and 0.0 <= si[:, :, 4].min() <= si[:, :, 4].max() <= 1.0
     # train-mode policy: the ground-truth map (last channel) is dropped before predicting, or used as is
