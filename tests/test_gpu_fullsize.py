@@ -330,3 +330,23 @@ def test_multiprocess_collector_round_robin_and_batched(simq_mod):
         opt = torch.optim.SGD(policy.policy_nets[i].parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
         info = simq_mod.train(cfg, policy.policy_nets[i], targets[i], opt, rings[i].sample(cfg.batch_size), policy.apply_transform, 0.85)
         assert np.isfinite(info['loss']) and np.isfinite(info['td_error'])
+
+
+def test_multiprocess_trainer_loop_on_synthetic_envs(simq_mod, tmp_path):
+    """train_multiprocess.py:main on the drop-ins (tools/train_synthetic.py::run_multiprocess): 3 spawned environment processes,
+    batched service, HBM rings, training, target sync, checkpoints -- and a resumed second run continues from the files."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('train_synthetic', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tools', 'train_synthetic.py'))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    cfg = ts.default_cfg(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], total_timesteps=36, episode_len=8)
+    policy, log, policy_path, checkpoint_path = ts.run_multiprocess(cfg, str(tmp_path), num_workers=3, verbose=False)
+    assert len(log) >= 8 and all(np.isfinite(v) for _, _, info in log for v in info.values())
+    assert {i for _, i, _ in log} == {0, 1}                         # both robot groups trained
+    ck = simq_mod.load_checkpoint(checkpoint_path)
+    assert ck['timestep'] >= 45 and len(ck['replay_buffers']) == 2 and all(len(b) > 8 for b in ck['replay_buffers'])
+    cfg2 = ts.default_cfg(**{**vars(cfg), 'checkpoint_path': checkpoint_path, 'policy_path': policy_path, 'total_timesteps': 44})
+    _, log2, _, checkpoint2 = ts.run_multiprocess(cfg2, str(tmp_path), num_workers=2, verbose=False)
+    assert log2 and min(t for t, _, _ in log2) > ck['timestep'] and os.path.exists(checkpoint2) and not os.path.exists(checkpoint_path)

@@ -86,6 +86,55 @@ def run(cfg, checkpoint_dir, verbose=True):
     return policy, log, policy_path, checkpoint_path
 
 
+def run_multiprocess(cfg, checkpoint_dir, num_workers=3, verbose=True):
+    """train_multiprocess.py:main (:423-470) on the drop-ins: `num_workers` spawned CPU processes step the environments, the
+    learner serves them all from one batched forward per robot group (Collector.step_all / DQNPolicy.step_many), stores their
+    transitions in the HBM rings, trains every `train_freq` collected steps, syncs the target nets and writes the checkpoints."""
+    from simq.synth import synthetic_env_from_cfg
+    num_robot_groups = len(cfg.robot_config)
+    policy = simq.DQNPolicy(cfg, train=True, random_seed=cfg.seed)
+    sgd = lambda net: torch.optim.SGD(net.parameters(), lr=cfg.learning_rate, momentum=0.9, weight_decay=cfg.weight_decay)
+    optimizers = [sgd(n) for n in policy.policy_nets]
+    replay_buffers = [simq.DeviceReplayBuffer(cfg.replay_buffer_size, cfg.num_input_channels) for _ in range(num_robot_groups)]
+    start_timestep = 0
+    if cfg.checkpoint_path is not None:
+        start_timestep, _, replay_buffers = simq.resume(cfg.checkpoint_path, optimizers, cfg.num_input_channels, aliased=False)
+    target_nets = policy.build_policy_nets()
+    for i in range(num_robot_groups):
+        target_nets[i].load_state_dict(policy.policy_nets[i].state_dict())
+        target_nets[i].eval()
+    learning_starts = int(round(cfg.learning_starts_frac * cfg.total_timesteps))
+    total = learning_starts + cfg.total_timesteps
+    collector = simq.Collector(cfg, policy, None, num_workers=num_workers, env_fn=synthetic_env_from_cfg)
+    log, timestep, episodes = [], start_timestep, 0
+    try:
+        while timestep < total:
+            eps = 1 - (1 - cfg.final_exploration) * min(1, max(0, timestep - learning_starts) / (cfg.exploration_frac * cfg.total_timesteps))
+            for transitions_per_buffer, done in collector.step_all(eps):             # one env step of every worker
+                for i, transitions in enumerate(transitions_per_buffer):              # Trainer.store_transitions
+                    for transition in transitions:
+                        replay_buffers[i].push(*transition)
+                episodes += int(done)
+                timestep += 1
+                if timestep >= learning_starts and timestep % cfg.train_freq == 0:   # Trainer.step
+                    for i in range(num_robot_groups):
+                        if len(replay_buffers[i]) < cfg.batch_size:
+                            continue
+                        info = simq.train(cfg, policy.policy_nets[i], target_nets[i], optimizers[i], replay_buffers[i].sample(cfg.batch_size),
+                                          policy.apply_transform, cfg.discount_factors[i])
+                        log.append((timestep, i, info))
+                        if verbose:
+                            print('t=%d group %d %s' % (timestep, i, {k: round(v, 4) for k, v in info.items()}))
+                if timestep % cfg.target_update_freq == 0:                            # Trainer.update_target_networks
+                    for i in range(num_robot_groups):
+                        target_nets[i].load_state_dict(policy.policy_nets[i].state_dict())
+    finally:
+        collector.close()
+    policy_path = simq.save_policy(checkpoint_dir, timestep, policy.policy_nets)     # Trainer.save_checkpoint
+    checkpoint_path = simq.save_checkpoint(checkpoint_dir, timestep, episodes, optimizers, replay_buffers)
+    return policy, log, policy_path, checkpoint_path
+
+
 def default_cfg(**over):
     cfg = types.SimpleNamespace(
         robot_config=[{'lifting_robot': 2}], num_input_channels=4, use_predicted_intention=False, use_predicted_intention_frac=0.5,
@@ -99,6 +148,7 @@ def default_cfg(**over):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
+    ap.add_argument('--workers', type=int, default=0, help='collect with this many spawned environment processes (train_multiprocess.py)')
     ap.add_argument('--timesteps', type=int, default=40)
     ap.add_argument('--intention', action='store_true')
     ap.add_argument('--out', default='/tmp/simq_synthetic')
@@ -106,5 +156,5 @@ if __name__ == '__main__':
     c = default_cfg(total_timesteps=a.timesteps, use_predicted_intention=a.intention,
                     num_input_channels=5 if a.intention else 4,
                     robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}] if a.intention else [{'lifting_robot': 2}])
-    _, lg, pp, cp = run(c, a.out)
+    _, lg, pp, cp = run_multiprocess(c, a.out, a.workers) if a.workers > 0 else run(c, a.out)
     print('%d training calls; saved %s and %s' % (len(lg), pp, cp))
