@@ -537,9 +537,8 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
     int bout = (T + tpb_out - 1) / tpb_out;
-    static const int cap_stats = getenv("SIMQ_WINO_OUT_CAP") ? atoi(getenv("SIMQ_WINO_OUT_CAP")) : 512;
-    static const int cap_plain = getenv("SIMQ_WINO_OUT_CAP2") ? atoi(getenv("SIMQ_WINO_OUT_CAP2")) : 4096;
-    const int cap = (e.stats || e.bnr_red1) ? cap_stats : cap_plain;    // statistics: few blocks, one fp64 atomic per channel and block
+    // statistics: few blocks, one fp64 atomic per channel and block (the step is insensitive to this cap from 256 to 2048)
+    const int cap = (e.stats || e.bnr_red1) ? 512 : 4096;
     if (bout > cap) bout = cap;
     const EpiArgs ea = make_epi(y, e);
     hipLaunchKernelGGL(wino_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T);
