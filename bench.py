@@ -142,6 +142,32 @@ def main():
     from simq._lib import lib
     from simq.learner import _opt_state, train_step
 
+    # gradient exchange: libsimq's own RCCL communicator (simq_comm_*: the data-parallel step is then ONE library call, buckets on
+    # the communicator's stream); checked once against torch.distributed's all-reduce.  If RCCL cannot be initialised through
+    # the library on this node the step falls back to torch.distributed's RCCL collectives around the backward phases -- still
+    # RCCL over xGMI, never a CPU path.  `transport` in the JSON line says which one ran.
+    comm, transport = None, 'none (single GPU)'
+    if pg is not None:
+        transport = 'torch.distributed (%s)' % args.backend
+        if args.backend == 'nccl' and os.environ.get('SIMQ_BENCH_COMM', '1') != '0':
+            try:
+                comm = sdist.Comm(pg, dev)
+                probe = torch.arange(1024, dtype=torch.float32, device=dev) * (rank + 1)
+                want = probe.clone()
+                torch.distributed.all_reduce(want, group=pg)
+                comm.all_reduce(probe)
+                comm.wait()
+                torch.cuda.synchronize(dev)
+                ok = torch.tensor([1.0 if torch.equal(probe, want) else 0.0], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=pg)
+                if float(ok.item()) != 1.0:
+                    raise RuntimeError('simq_comm all-reduce disagrees with torch.distributed')
+                transport = 'libsimq simq_comm (RCCL, library-owned stream)'
+            except Exception as ex:            # noqa: BLE001  (report and use the other RCCL transport)
+                if rank == 0:
+                    print('bench: simq_comm unavailable (%r); using torch.distributed collectives' % (ex,), file=sys.stderr)
+                comm = None
+
     def run_workload(CIN, BATCH_PER_GPU, precision, steps, warmup, replay_items):
         # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
         # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
@@ -165,7 +191,7 @@ def main():
 
         def draw():
             idx = ring.sample_indices(gB)
-            return ring.gather(sdist.shard_indices(idx, world, rank))
+            return ring.gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
 
         drawn = [None]
 
@@ -176,7 +202,7 @@ def main():
             # order and the work per step are unchanged (the replay ring is static during the benchmark).
             batch = drawn[0] if drawn[0] is not None else draw()
             out4 = train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
-                              opt_state=st_opt, process_group=pg, global_batch=gB, sync=False)
+                              opt_state=st_opt, process_group=pg, global_batch=gB, sync=False, comm=comm)
             drawn[0] = draw()
             o = out4.tolist()
             return {'td_error': o[1] / gB, 'loss': o[0] / gB}
@@ -204,7 +230,7 @@ def main():
         # backward only -- no next-state forwards, clip or SGD.  Reported beside the full-step `value`, never instead of it.
         from simq._lib import MODE_TRAIN, ptr, stream_ptr
         idx = ring.sample_indices(gB)
-        fb = ring.gather(sdist.shard_indices(idx, world, rank))
+        fb = ring.gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
         nq = COUT * 96 * 96
         fb_out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
         fb_o4 = torch.empty(4, dtype=torch.float32, device=dev)
@@ -312,7 +338,7 @@ def main():
             'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMA products, f32 accumulate)', 'bf16': 'bf16 (f32 accumulate / BN / optimiser)'}[args.precision], 'data': 'synthetic',
             'config': {'workload': '%s (Cin=%d, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
                                    'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
-                       'global_batch': gB, 'parallelism': 'dp%d' % world,
+                       'global_batch': gB, 'parallelism': 'dp%d' % world, 'gradient_transport': transport,
                        'flop_per_transition': FLOP_M2,
                        'fwd_bwd_only': None if args.no_m1 else {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
                                         'ms_per_step': round(dt_m1 / args.steps * 1e3, 3), 'flop_per_transition': FLOP_M1,
@@ -322,6 +348,8 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if pg is not None:
         torch.distributed.destroy_process_group()
 

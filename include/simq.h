@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 100            /* 0.1.0 */
+#define SIMQ_VERSION 200            /* 0.2.0 */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -160,7 +160,7 @@ int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* 
  * launches simq.learner.train_step issues, sequenced by the library.  All pointers are device memory owned by the caller; both
  * weight caches must be current on entry (simq_weights_prepare).  side_stream (may be NULL): the target forward runs there,
  * fork/join by events.  Results: out4[0] = sum of Huber terms, out4[1] = sum of |td| over this rank's batch; q_sa, y, td per
- * transition; *total_norm = pre-clip gradient norm.  Single-process form (no gradient all-reduce between backward and SGD).
+ * transition; *total_norm = pre-clip gradient norm.  With `comm` set the gradient buckets are all-reduced between backward and SGD.
  * dq may be NULL: the backward then starts from the one-hot form (simq_backward_onehot) and no dense dQ map is written. */
 typedef struct simq_train_args {
     const simq_plan* plan;
@@ -173,8 +173,33 @@ typedef struct simq_train_args {
     float* nsv; float* vals; int64_t* best; float* q_sa; float* y; float* td; float* out4;
     void* opt_scratch; float* total_norm;
     void* stream; void* side_stream;
+    struct simq_comm* comm;      /* NULL: single process.  Otherwise the data-parallel form: `batch` is this rank's shard of a
+                                  * minibatch of `global_batch` transitions; head + layer4 gradients (simq_grad_bucket_split) are
+                                  * summed over the ranks while layers 3..1 + stem are still being differentiated, then the rest
+                                  * and out4; every rank applies the identical clip + SGD.  num_nonfinal may then be 0 (a shard
+                                  * whose transitions are all terminal still has to join the collectives). */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
+
+/* ---- gradient exchange between data-parallel ranks (replaces the reduce-add of nn.DataParallel, policies.py:39) --------------
+ * One process per GPU; RCCL (librccl.so.1, bound at run time) over xGMI.  Rank 0 obtains a SIMQ_COMM_ID_BYTES identifier and
+ * hands it to the other ranks out of band (the Python host: torch.distributed broadcast / a file); every rank then calls
+ * simq_comm_init with its HIP device current.  The communicator owns one non-blocking stream: simq_comm_allreduce /
+ * simq_comm_broadcast enqueue there, ordered behind everything already submitted to `producer_stream`, and return at once;
+ * simq_comm_wait makes `consumer_stream` wait for every collective enqueued so far.  All ranks must issue the same sequence.
+ * In-place sum of `count` elements (dtype SIMQ_COMM_F32 / SIMQ_COMM_F64); broadcast of raw bytes from rank `root`. */
+#define SIMQ_COMM_ID_BYTES 128
+#define SIMQ_COMM_F32 0
+#define SIMQ_COMM_F64 1
+typedef struct simq_comm simq_comm;
+int simq_comm_unique_id(void* id_out /* SIMQ_COMM_ID_BYTES, host memory */);
+int simq_comm_init(const void* id, int world_size, int rank, simq_comm** out);
+int simq_comm_world_size(const simq_comm* comm);
+int simq_comm_rank(const simq_comm* comm);
+int simq_comm_allreduce(simq_comm* comm, void* d_buf, int64_t count, int dtype, void* producer_stream);
+int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, void* producer_stream);
+int simq_comm_wait(simq_comm* comm, void* consumer_stream);
+int simq_comm_destroy(simq_comm* comm);
 
 /* ---- intention-prediction head (train_intention, train.py:143-158; step_intention, policies.py:97-117) ----------
  * simq_bce_with_logits: nn.BCEWithLogitsLoss() ('mean') over n logits vs targets; *d_loss_sum (double) receives the SUM

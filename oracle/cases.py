@@ -27,6 +27,9 @@ FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), (
 TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
 # the bench workload's own size (BASELINE configs[1]); summaries only, checked on the GPU without re-running the oracle
 TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
+# data-parallel emulation (SURVEY 8e / fixture G7): (name, cin, cout, global batch, shards, weight seed, data seed)
+DP_CASES = [('dp_c5o2_b8_w1', 5, 2, 8, 1, 37, 50), ('dp_c5o2_b8_w2', 5, 2, 8, 2, 37, 50), ('dp_c5o2_b8_w4', 5, 2, 8, 4, 37, 50),
+            ('dp_c5o2_b8_w8', 5, 2, 8, 8, 37, 50), ('dp_c5o1_b8_w2', 5, 1, 8, 2, 38, 48)]
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 

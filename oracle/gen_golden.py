@@ -144,6 +144,87 @@ def gen_train(case_list=None):
               % out['ref_fp32_grad_relerr'])
 
 
+def gen_dp():
+    """Fixture G7: the reference's multi-GPU form is nn.DataParallel (policies.py:39) -- the minibatch is cut
+    into contiguous chunks, every replica runs the reference's own FCN on its chunk with ITS OWN train-mode BatchNorm statistics,
+    the replicas' gradients are summed and only replica 0's running statistics persist.  Emulated here on the CPU with the
+    reference classes themselves: replica r > 0 is a deepcopy of the reference module (what DataParallel.replicate produces),
+    each runs train.py:114-129 on its chunk with the Huber SUM divided by the GLOBAL batch, gradients are added in rank order.
+    The oracle's dp_emulation must agree bit for bit; the fp64 oracle is the yardstick stored beside it."""
+    import copy
+    from torch.nn.functional import smooth_l1_loss
+    for name, cin, cout, gB, world, wseed, dseed in cases.DP_CASES:
+        cfg = cases.make_cfg(gB)
+        batch = cases.make_batch(cin, cout, gB, dseed)
+        spec = fcn.state_spec(cin, cout)
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        chunk = -(-gB // world)
+        total, sums, q_all, y_all, empty_shards = None, torch.zeros(2), [], [], 0
+        for r in range(world):
+            lo, hi = min(r * chunk, gB), min((r + 1) * chunk, gB)
+            if lo == hi:
+                continue
+            replica = policy if r == 0 else copy.deepcopy(policy)
+            replica.zero_grad()
+            st_b = torch.cat([learner.apply_transform(s) for s in batch.state[lo:hi]])
+            act = torch.tensor(batch.action[lo:hi], dtype=torch.long)
+            rew = torch.tensor(batch.reward[lo:hi], dtype=torch.float32)
+            nf = [learner.apply_transform(s) for s in batch.next_state[lo:hi] if s is not None]
+            mask = torch.tensor([s is not None for s in batch.next_state[lo:hi]], dtype=torch.bool)
+            out = replica(st_b)                                                                  # train.py:114
+            q = out.view(hi - lo, -1).gather(1, act.unsqueeze(1)).squeeze(1)                     # train.py:115
+            nsv = torch.zeros(hi - lo)
+            if nf:
+                nfns = torch.cat(nf)
+                with torch.no_grad():                                                            # train.py:118-122
+                    best = replica(nfns).view(len(nf), -1).max(1)[1].view(len(nf), 1)
+                    nsv[mask] = target(nfns).view(len(nf), -1).gather(1, best).view(-1)
+            else:
+                empty_shards += 1
+            y = rew + cases.GAMMA * nsv                                                          # train.py:126
+            huber = smooth_l1_loss(q, y, reduction='sum')
+            (huber / gB).backward()
+            flat = torch.cat([p.grad.reshape(-1) for p in replica.parameters() if p.grad is not None])
+            total = flat if total is None else total + flat
+            sums = sums + torch.stack([huber.detach(), torch.abs(q - y).detach().sum()])
+            q_all.append(q.detach()); y_all.append(y.detach())
+        # oracle restatement, fp32: bit-exact with the emulation above
+        st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        o_total, o_loss, o_td = learner.dp_emulation(cfg, st, tg, spec, batch, world, cases.GAMMA)
+        assert_same(o_total, total, name + ' gradient sum')
+        assert o_loss == float(sums[0]) / gB and o_td == float(sums[1]) / gB, (name, o_loss, o_td, sums)
+        for k, v in policy.state_dict().items():
+            assert_same(st[k], v, name + ' replica-0 buffer ' + k)
+        # fp64 yardstick
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        t64, loss64, td64 = learner.dp_emulation(cfg, st64, tg64, spec, batch, world, cases.GAMMA, dtype=torch.float64)
+        gkeys = learner.grad_keys(spec)
+
+        def split(flat):
+            out, off = {}, 0
+            for k in gkeys:
+                n = st[k].numel()
+                out[k] = flat[off:off + n].view(st[k].shape)
+                off += n
+            return out
+        g32, g64 = cases.grad_summary(split(total)), cases.grad_summary(split(t64))
+        relerr = float((total.double() - t64).norm() / t64.norm())
+        # the same minibatch as ONE replica (what a single device computes): how far per-shard BN statistics move the gradient
+        st1, tg1 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        one, _, _ = learner.dp_emulation(cfg, st1, tg1, spec, batch, 1, cases.GAMMA, dtype=torch.float64)
+        np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'),
+                 loss=np.array(o_loss), td_error=np.array(o_td), loss64=np.array(loss64), td_error64=np.array(td64),
+                 total_norm=np.array(float(total.norm())), total_norm64=np.array(float(t64.norm())),
+                 q_sa=torch.cat(q_all).numpy(), y=torch.cat(y_all).numpy(), grad_keys=np.array(gkeys),
+                 grad32=np.stack(list(g32.values())), grad64=np.stack(list(g64.values())), ref_fp32_grad_relerr=np.array(relerr),
+                 bn_buffers_after=cases.bn_buffer_vector(st).astype(np.float32), all_terminal_shards=np.array(empty_shards),
+                 shard_vs_single_replica_relerr=np.array(float((t64 - one).norm() / one.norm())))
+        print('dp case', name, 'oracle.dp_emulation == reference replicas (bit-exact); fp32 grad rel err vs fp64 = %.3g; '
+              'all-terminal shards: %d; per-shard-BN vs single replica: %.3g' % (relerr, empty_shards, float((t64 - one).norm() / one.norm())))
+
+
 def gen_intention():
     """train.train_intention (train.py:143-158) run twice on the reference vs the oracle restatement, bit-exact."""
     for name, cin_full, B, wseed, dseed in cases.INTENTION_CASES:
@@ -267,6 +348,7 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint}
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
+            'dp': gen_dp}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+struct simq_comm;
+
 namespace simq {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -171,5 +173,9 @@ int launch_split_last_channel(const float* x, float* head, float* last, int64_t 
 int launch_sigmoid_concat(const float* state, const float* logit, float* out, float* prob, int64_t pixels, int Cs, hipStream_t stream);
 int launch_replay_gather(const float* ring, int64_t item_floats, const int64_t* index, int count, float* out,
                          hipStream_t stream);
+
+// comm.hip: RCCL all-reduce on the communicator's own stream, ordered behind `producer` / awaited by `consumer`
+int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_t producer);
+int comm_wait(simq_comm* c, hipStream_t consumer);
 
 }  // namespace simq

@@ -738,8 +738,10 @@ int simq_train_step(const simq_train_args* a) {
                  a->t_wcache && a->t_bnbuf && a->t_ws && a->state && a->next_state && a->action && a->reward && a->nonfinal_pos &&
                  a->q && a->q_tgt && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
                  "train_step: NULL buffer");
-    SIMQ_REQUIRE(!a->use_double_dqn || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
-    SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= 1 && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
+    SIMQ_REQUIRE(!a->use_double_dqn || a->num_nonfinal == 0 || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
+    // single process: the reference itself fails on a minibatch without any non-final next state (torch.cat([]) at train.py:112);
+    // a data-parallel SHARD may have none and still has to join the collectives
+    SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= (a->comm ? 0 : 1) && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
                  "train_step: batch=%d num_nonfinal=%d global_batch=%d", a->batch, a->num_nonfinal, a->global_batch);
     const simq_plan* p = a->plan;
     hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
@@ -766,6 +768,7 @@ int simq_train_step(const simq_train_args* a) {
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     }
+    if (Nn > 0) {
     RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side ? side : main));
     if (side) SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
     if (a->use_double_dqn) {                                                                                          // train.py:119-122
@@ -777,12 +780,28 @@ int simq_train_step(const simq_train_args* a) {
         if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
         RC(launch_q_argmax(a->q_tgt, Nn, n, nullptr, a->vals, main));
     }
+    }
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
-    if (a->dq) RC(simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, 0, main));           // train.py:131-132
-    else RC(simq_backward_onehot(p, B, a->params, a->wcache, a->action, a->q_sa, a->y, 1.0f / (float)a->global_batch, a->grads,
-                                 a->ws_train, 0, main));
+    const float gscale = 1.0f / (float)a->global_batch;
+    auto backward = [&](int phase) {                                                                                 // train.py:131-132
+        return a->dq ? simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, phase, main)
+                     : simq_backward_onehot(p, B, a->params, a->wcache, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main);
+    };
+    if (!a->comm) {
+        RC(backward(0));
+    } else {
+        // data parallel (DataParallel's reduce-add, policies.py:39, as RCCL all-reduces): the head + layer4 bucket (75 % of the
+        // bytes) is final after phase 1 and travels on the communicator's stream while phase 2 differentiates layers 3..1 + stem
+        const int64_t split = simq_grad_bucket_split(p);
+        RC(backward(1));
+        RC(comm_allreduce(a->comm, a->grads + split, p->nparams - split, SIMQ_COMM_F32, main));
+        RC(backward(2));
+        RC(comm_allreduce(a->comm, a->grads, split, SIMQ_COMM_F32, main));
+        RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
+        RC(comm_wait(a->comm, main));
+    }
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);

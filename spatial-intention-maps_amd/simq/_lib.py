@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'libsimq.so')
 MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD = 0, 1, 2
 KIND_CONV_W, KIND_CONV_B, KIND_BN_W, KIND_BN_B = 0, 1, 2, 3
 PRECISIONS = {'fp32': 0, 'bf16x3': 1, 'bf16': 2}
+COMM_ID_BYTES, COMM_F32, COMM_F64 = 128, 0, 1
 
 
 class SimqError(RuntimeError):
@@ -41,7 +42,7 @@ class TrainArgs(ctypes.Structure):
                     't_params', 't_wcache', 't_bnbuf', 't_ws',
                     'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
                     'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
-                    'opt_scratch', 'total_norm', 'stream', 'side_stream')]
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream', 'comm')]
 
 
 _SIGS = {
@@ -94,6 +95,14 @@ _SIGS = {
     'simq_tune_winograd': (c_int, [c_int]),
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_comm_unique_id': (c_int, [c_void_p]),
+    'simq_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    'simq_comm_world_size': (c_int, [c_void_p]),
+    'simq_comm_rank': (c_int, [c_void_p]),
+    'simq_comm_allreduce': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'simq_comm_broadcast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'simq_comm_wait': (c_int, [c_void_p, c_void_p]),
+    'simq_comm_destroy': (c_int, [c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -13,9 +13,16 @@ MI355X-native equivalent keeps exactly those semantics with one process per GPU:
   * running statistics are per-rank; rank 0's are the ones that count: broadcast_bn_buffers()
     before a target sync / checkpoint.
 
-This module only uses torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests)
-and never touches the HIP library, so the sharding / reduction logic is testable without a GPU.
+Two transports for the gradient sum:
+  * `Comm` -- libsimq's own RCCL communicator (include/simq.h simq_comm_*): collectives run on a library-owned HIP stream,
+    ordered by events behind the backward kernels; torch.distributed is used ONCE, to hand rank 0's 128-byte RCCL
+    identifier to the other ranks.  With it the whole data-parallel step is a single library call (simq_train_step).
+  * torch.distributed collectives on the caller's process group ("nccl" == RCCL on ROCm; "gloo" in the CPU tests and when
+    several ranks share one GPU, which RCCL refuses).
+The sharding helpers below never touch the HIP library, so the rank logic is testable without a GPU.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -60,3 +67,59 @@ def max_over_ranks(value, device, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class Comm:
+    """libsimq's RCCL communicator (simq_comm_*, include/simq.h) for the ranks of a torch.distributed process group.
+
+    Construction is collective: rank 0 draws the RCCL identifier, torch.distributed broadcasts its 128 bytes (the only use of
+    the process group), every rank joins with its CURRENT HIP device.  all_reduce / broadcast are asynchronous with respect to
+    the host and to torch's current stream: they are enqueued on the communicator's own stream behind the work already
+    submitted to the current stream; wait() makes the current stream wait for them."""
+
+    def __init__(self, group=None, device=None):
+        from ._lib import COMM_ID_BYTES, lib
+        self._lib = lib
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        ident = (ctypes.c_ubyte * COMM_ID_BYTES)()
+        if self.rank == 0:
+            lib.call('simq_comm_unique_id', ident)
+        on_device = dist.get_backend(group) == 'nccl'
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=self.device if on_device else 'cpu')
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (ctypes.c_ubyte * COMM_ID_BYTES)(*t.cpu().tolist())
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            lib.call('simq_comm_init', ident, self.world, self.rank, ctypes.byref(h))
+        self.handle = h
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def all_reduce(self, tensor):
+        from ._lib import COMM_F32, COMM_F64, SimqError
+        if tensor.dtype not in (torch.float32, torch.float64) or not tensor.is_contiguous() or tensor.device != self.device:
+            raise SimqError('Comm.all_reduce: contiguous fp32 / fp64 tensor on %s expected' % self.device)
+        self._lib.call('simq_comm_allreduce', self.handle, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+                       COMM_F32 if tensor.dtype == torch.float32 else COMM_F64, self._stream())
+        return tensor
+
+    def broadcast(self, tensor, src=0):
+        self._lib.call('simq_comm_broadcast', self.handle, ctypes.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(),
+                       int(src), self._stream())
+        return tensor
+
+    def wait(self):
+        self._lib.call('simq_comm_wait', self.handle, self._stream())
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.call('simq_comm_destroy', self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,9 +10,11 @@ Interface kept from the reference (what train.py / policies.py touch):
   .train() / .eval()   BatchNorm batch statistics vs running statistics
 
 Device layout: ONE flat fp32 parameter buffer (OHWI conv weights) + identically laid-out
-gradient buffer; every nn.Parameter is a view into the flat buffer, so torch.optim.SGD /
-clip_grad_norm_ operate on it unchanged, and the fused learner (simq.learner) can update
-all parameters with one kernel and all-reduce one message.
+gradient buffer; every nn.Parameter is a view into the flat buffer with the reference's logical
+shape (conv weights: [O,I,H,W] as a permuted view of the OHWI storage), so torch.optim.SGD /
+clip_grad_norm_ / optimizer.state_dict() operate on it unchanged and interchangeably with the
+reference, and the fused learner (simq.learner) can update all parameters with one kernel and
+all-reduce one message.
 """
 import math
 from collections import OrderedDict
@@ -44,8 +46,16 @@ class _FCNFunction(torch.autograd.Function):
             raise SimqError('simq.FCN: backward() after a newer grad-mode forward of the same net -- the saved '
                             'activations were overwritten (one grad-mode forward per backward)')
         g = net._backward_raw(dq.contiguous(), ctx.batch)
-        grads = tuple(g[off:off + n].view(shape) for (off, n, shape) in net._grad_views)
-        return (None, None) + grads
+        return (None, None) + tuple(net.reference_views(g))
+
+
+def _reference_view(flat, shape):
+    """View of one tensor of a flat (parameter-layout) buffer under the reference's LOGICAL shape: convolution weights are stored
+    OHWI and presented as [O, I, H, W] through a permuted (channels-last strided) view, so that everything torch sees -- parameter
+    shapes, .grad, torch.optim state, optimizer.state_dict() in a checkpoint -- indexes exactly like the reference's OIHW tensors
+    while the kernels keep their K-contiguous rows."""
+    v = flat.view(shape)
+    return v.permute(0, 3, 1, 2) if len(shape) == 4 else v
 
 
 class FCN(torch.nn.Module):
@@ -76,7 +86,7 @@ class FCN(torch.nn.Module):
                 off, shape, kind = by_name[k]
                 n = int(math.prod(shape))
                 pname = k.replace('.', '__')
-                self.register_parameter(pname, torch.nn.Parameter(self.flat_params[off:off + n].view(shape)))
+                self.register_parameter(pname, torch.nn.Parameter(_reference_view(self.flat_params[off:off + n], shape)))
                 self._param_names.append((k, pname, kind))
                 self._grad_views.append((off, n, tuple(shape)))
             elif skind == 'fc_w':
@@ -201,6 +211,10 @@ class FCN(torch.nn.Module):
             self.fc_bias.copy_(other.fc_bias)
         self.num_batches_tracked = OrderedDict(other.num_batches_tracked)
         self.weights_dirty = True
+
+    def reference_views(self, flat):
+        """Per-parameter views (reference order and logical OIHW shapes) of a flat buffer laid out like flat_params."""
+        return [_reference_view(flat[off:off + n], shape) for (off, n, shape) in self._grad_views]
 
     # ------------------------------------------------------------------ raw kernels over flat buffers
     def _workspace(self, slot, batch):

@@ -67,10 +67,11 @@ class DeviceBatch:
         self.next_state, self.nonfinal_pos, self.non_final_mask = next_state, nonfinal_pos, non_final_mask
 
 
-def assemble_batch(batch, device):
+def assemble_batch(batch, device, allow_all_final=False):
     """train.py:109-112,116-117: host Transition-of-tuples -> DeviceBatch.  The reference
     transposes every HWC state to CHW and concatenates; the HIP path consumes HWC directly, so
-    this is one stack + one H2D copy per tensor."""
+    this is one stack + one H2D copy per tensor.  allow_all_final: a data-parallel SHARD may consist of terminal
+    transitions only (the reference fails only when the WHOLE minibatch does); its next_state tensor is then empty."""
     if isinstance(batch, DeviceBatch):
         return batch
     state = torch.from_numpy(np.stack(batch.state)).to(device, non_blocking=True)
@@ -78,9 +79,12 @@ def assemble_batch(batch, device):
     reward = torch.tensor(batch.reward, dtype=torch.float32).to(device, non_blocking=True)
     mask = [s is not None for s in batch.next_state]
     nf = [s for s in batch.next_state if s is not None]
-    if not nf:
+    if not nf and not allow_all_final:
         raise SimqError('train: batch has no non-final next state (the reference raises at train.py:112 too)')
-    next_state = torch.from_numpy(np.stack(nf)).to(device, non_blocking=True)
+    if nf:
+        next_state = torch.from_numpy(np.stack(nf)).to(device, non_blocking=True)
+    else:
+        next_state = torch.empty((0,) + tuple(state.shape[1:]), dtype=torch.float32, device=device)
     pos = torch.tensor([i for i, m in enumerate(mask) if m], dtype=torch.int32).to(device, non_blocking=True)
     return DeviceBatch(state, action, reward, next_state, pos, mask)
 
@@ -198,7 +202,9 @@ class DeviceReplayBuffer:
     def sample_indices(self, batch_size):
         return random.sample(range(len(self.buffer)), batch_size)
 
-    def gather(self, idx):
+    def gather(self, idx, allow_all_final=False):
+        """allow_all_final: data-parallel ranks gather only their slice of the drawn indices, and a slice may hold terminal
+        transitions only (the minibatch as a whole is checked by the caller / fails as the reference does)."""
         recs = [self.buffer[i] for i in idx]
         B = len(recs)
         dev = self.device
@@ -208,11 +214,12 @@ class DeviceReplayBuffer:
         lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
         mask = [r.next_state is not None for r in recs]
         nf = [int(r.next_state) for r in recs if r.next_state is not None]
-        if not nf:
+        if not nf and not allow_all_final:
             raise SimqError('sample: no non-final next state in the batch (train.py:112 would raise)')
-        nindex = torch.tensor(nf, dtype=torch.int64).to(dev, non_blocking=True)
         next_state = torch.empty((len(nf), W, W, self.C), dtype=torch.float32, device=dev)
-        lib.call('simq_replay_gather', ptr(self.next_states), self.item, ptr(nindex), len(nf), ptr(next_state), st)
+        if nf:
+            nindex = torch.tensor(nf, dtype=torch.int64).to(dev, non_blocking=True)
+            lib.call('simq_replay_gather', ptr(self.next_states), self.item, ptr(nindex), len(nf), ptr(next_state), st)
         action = torch.tensor([r.action for r in recs], dtype=torch.long).to(dev, non_blocking=True)
         reward = torch.tensor([r.reward for r in recs], dtype=torch.float32).to(dev, non_blocking=True)
         pos = torch.tensor([i for i, m in enumerate(mask) if m], dtype=torch.int32).to(dev, non_blocking=True)
@@ -329,13 +336,18 @@ def _opt_state(net, optimizer):
     if optimizer is None:
         return st
     if st.views is None:
-        st.views = [st.momentum[off:off + n].view(shape) for (off, n, shape) in net._grad_views]
+        st.views = net.reference_views(st.momentum)     # logical OIHW shapes, like the parameters (fcn._reference_view)
     params = [getattr(net, pname) for _, pname, _ in net._param_names]
-    # adopt momentum buffers that were loaded from a checkpoint (optimizer.load_state_dict)
-    for p, v in zip(params, st.views):
+    # adopt momentum buffers that were loaded from a checkpoint (optimizer.load_state_dict, train.py:204): they index like the
+    # reference's OIHW tensors -- whether the reference or this package wrote the file -- and copy_ moves them element by
+    # logical index into the OHWI storage
+    for (name, _, _), p, v in zip(net._param_names, params, st.views):
         buf = optimizer.state.get(p, {}).get('momentum_buffer')
-        if buf is not None and buf.data_ptr() != v.data_ptr():
-            v.copy_(buf.to(v.device).view_as(v))
+        if buf is not None and (buf.data_ptr() != v.data_ptr() or buf.stride() != v.stride()):
+            if tuple(buf.shape) != tuple(v.shape):
+                raise SimqError('optimizer state of %s has shape %s, expected %s (the reference layout)'
+                                % (name, tuple(buf.shape), tuple(v.shape)))
+            v.copy_(buf.to(v.device))
             optimizer.state[p]['momentum_buffer'] = v
             st.initialised = True
     return st
@@ -354,12 +366,14 @@ def _hyper(optimizer):
 
 def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, momentum, weight_decay,
                grad_norm_clipping, use_double_dqn=True, opt_state=None, process_group=None, global_batch=None,
-               sync=True):
+               sync=True, comm=None):
     """One TD step (train.py:108-141) entirely on the device, over the nets' flat buffers.
 
-    Data-parallel: pass `process_group` / `global_batch`; this rank's `batch` is its slice of the
-    minibatch, BatchNorm uses per-rank statistics (the reference's DataParallel semantics,
-    policies.py:39) and the flat gradient is summed with ONE all-reduce (RCCL) before clip+SGD.
+    Data-parallel: pass `global_batch` and either `comm` (simq.dist.Comm: libsimq's RCCL communicator -- the step stays ONE
+    library call, the gradient buckets travel on the communicator's stream) or `process_group` (torch.distributed
+    collectives around the two backward phases); this rank's `batch` is its slice of the minibatch, BatchNorm uses per-rank
+    statistics (the reference's DataParallel semantics, policies.py:39) and the flat gradient is summed over the ranks in two
+    buckets before every rank applies the identical clip + SGD.
     Returns {'td_error','loss'} floats (sync=True, as the reference's .item() calls do) or the
     device tensor [sum_huber, sum_td] (sync=False).
     """
@@ -367,8 +381,11 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
         raise SimqError('simq.train needs simq.FCN networks (got %s / %s); there is no torch fallback'
                         % (type(policy_net).__name__, type(target_net).__name__))
     dev = policy_net.device_
-    b = assemble_batch(batch, dev)
+    parallel = process_group is not None or comm is not None
+    b = assemble_batch(batch, dev, allow_all_final=parallel)
     B = b.state.shape[0]
+    if b.next_state.shape[0] == 0 and not parallel:
+        raise SimqError('train: batch has no non-final next state (the reference raises at train.py:112 too)')
     if B != batch_size:
         raise SimqError('train: batch has %d transitions but cfg.batch_size is %d' % (B, batch_size))
     gB = B if global_batch is None else int(global_batch)
@@ -380,9 +397,10 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     policy_net._workspace('tmp', B)
     target_net._workspace('tmp', B)
 
-    if process_group is None and FUSED_LIBRARY_STEP:
+    if (process_group is None or comm is not None) and FUSED_LIBRARY_STEP:
         return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                                 use_double_dqn, st_opt, sync)
+                                 use_double_dqn, st_opt, sync, comm)
+    reduce_async = (lambda t: sdist.allreduce_async(t, process_group)) if comm is None else comm.all_reduce
 
     # train.py:114 -- policy forward, train-mode BN, activations kept for backward
     q = policy_net._forward_raw(b.state, MODE_TRAIN)
@@ -391,14 +409,17 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     # on the ~29 non-final samples and fill each other's partially filled rounds of CUs).
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else main
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
-    # train.py:116-124 -- bootstrap values of the non-final next states
     Nn = b.next_state.shape[0]
     nsv = torch.empty(B, dtype=torch.float32, device=dev)
-    vals = torch.empty(Nn, dtype=torch.float32, device=dev)
-    if use_double_dqn:
+    vals = torch.empty(max(Nn, 1), dtype=torch.float32, device=dev)
+    if Nn:           # (Nn == 0: an all-terminal data-parallel shard -- no bootstrap values, but it joins the collectives below)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
+    # train.py:116-124 -- bootstrap values of the non-final next states
+    if Nn == 0:
+        pass
+    elif use_double_dqn:
         # train.py:121: the POLICY net, still in train mode (batch statistics, 2nd running-stat update)
         q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD)
         best = torch.empty(Nn, dtype=torch.int64, device=dev)
@@ -408,7 +429,8 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     else:
         main.wait_stream(side)
         lib.call('simq_q_argmax', ptr(q_tgt), Nn, n, None, ptr(vals), st)
-    q_tgt.record_stream(main)
+    if Nn:
+        q_tgt.record_stream(main)
     lib.call('simq_scatter_next_values', ptr(vals), ptr(b.nonfinal_pos), Nn, ptr(nsv), B, st)
     # train.py:115,126-129 + the gradient autograd would hand to `output`
     q_sa = torch.empty(B, dtype=torch.float32, device=dev)
@@ -419,19 +441,21 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     lib.call('simq_td_huber', ptr(q), B, n, ptr(b.action), ptr(b.reward), ptr(nsv), float(discount_factor),
              1.0 / gB, ptr(q_sa), ptr(y), ptr(td), ptr(out4), None, st)
     # train.py:131-132
-    if process_group is None:
+    if not parallel:
         grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B)
     else:
         # data parallel: the all-reduce of the head + layer4 gradients (75 % of the 45 MB) is issued as soon as they are
         # final and runs on RCCL's stream while layers 3..1 + stem are still being differentiated
         split = policy_net.grad_bucket_split
         grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=1)
-        work = sdist.allreduce_async(grads[split:], process_group)
+        works = [reduce_async(grads[split:])]
         policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=2)
-        work2 = sdist.allreduce_async(grads[:split], process_group)
-        work3 = sdist.allreduce_async(out4, process_group)
-        for wk in (work, work2, work3):
-            wk.wait()
+        works += [reduce_async(grads[:split]), reduce_async(out4)]
+        if comm is not None:
+            comm.wait()
+        else:
+            for wk in works:
+                wk.wait()
     # train.py:133-135
     lib.call('simq_clip_sgd_step', ptr(policy_net.flat_params), ptr(grads), ptr(st_opt.momentum),
              policy_net.plan.param_count, float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0,
@@ -446,10 +470,12 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
 
 
 def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                      use_double_dqn, st_opt, sync):
-    """train_step through simq_train_step: the same launches in the same order, sequenced inside the library."""
+                      use_double_dqn, st_opt, sync, comm=None):
+    """train_step through simq_train_step: the same launches in the same order, sequenced inside the library (with `comm`: the
+    data-parallel form, gradient buckets all-reduced on the communicator's stream between the backward phases and the SGD)."""
     dev = policy_net.device_
     B, Nn = b.state.shape[0], b.next_state.shape[0]
+    Nn_real, Nn = Nn, max(Nn, 1)          # (all-terminal shard: the scratch tensors keep one row, the library is told 0)
     n = policy_net.num_output_channels * W * W
     for t, c in ((b.state, policy_net.num_input_channels), (b.next_state, policy_net.num_input_channels)):
         if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape[1:]) != (W, W, c):
@@ -466,15 +492,18 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else None
     a = TrainArgs()
     a.plan = policy_net.plan.handle
-    a.batch, a.num_nonfinal, a.global_batch = B, Nn, gB
+    a.batch, a.num_nonfinal, a.global_batch = B, Nn_real, gB
+    a.comm = comm.handle if comm is not None else None
+    next_state = b.next_state if Nn_real else torch.empty((1, W, W, policy_net.num_input_channels), **f32)
+    nonfinal_pos = b.nonfinal_pos if Nn_real else torch.zeros(1, dtype=torch.int32, device=dev)
     a.use_double_dqn, a.first_step = int(bool(use_double_dqn)), 0 if st_opt.initialised else 1
     a.gamma, a.lr, a.momentum, a.weight_decay = float(discount_factor), lr, momentum, weight_decay
     a.max_norm = float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0
     tensors = dict(params=policy_net.flat_params, wcache=policy_net.wcache, bnbuf=policy_net.bn_buffers, grads=policy_net.flat_grads,
                    momentum_buf=st_opt.momentum, ws_train=policy_net._workspace('train', B), ws_tmp=policy_net._workspace('tmp', Nn),
                    t_params=target_net.flat_params, t_wcache=target_net.wcache, t_bnbuf=target_net.bn_buffers,
-                   t_ws=target_net._workspace('tmp', Nn), state=b.state, next_state=b.next_state, action=b.action, reward=b.reward,
-                   nonfinal_pos=b.nonfinal_pos, q=q, q_next=q_next, q_tgt=q_tgt, dq=dq, nsv=nsv, vals=vals, best=best, q_sa=q_sa,
+                   t_ws=target_net._workspace('tmp', Nn), state=b.state, next_state=next_state, action=b.action, reward=b.reward,
+                   nonfinal_pos=nonfinal_pos, q=q, q_next=q_next, q_tgt=q_tgt, dq=dq, nsv=nsv, vals=vals, best=best, q_sa=q_sa,
                    y=y, td=td, out4=out4, opt_scratch=st_opt.scratch, total_norm=st_opt.total_norm)
     for k, t in tensors.items():
         setattr(a, k, None if t is None else t.data_ptr())
@@ -487,7 +516,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     # bookkeeping the separate calls do on the Python side
     policy_net._train_generation += 1
     for k in policy_net.num_batches_tracked:
-        policy_net.num_batches_tracked[k] += 2 if use_double_dqn else 1
+        policy_net.num_batches_tracked[k] += 2 if (use_double_dqn and Nn_real) else 1
     policy_net.weights_dirty = False          # the library refreshed the weight cache behind the SGD update
     policy_net._weights_stamp += 1
     st_opt.initialised = True
@@ -513,7 +542,7 @@ def train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_
 
 
 def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state=None, process_group=None,
-                         global_batch=None, sync=True):
+                         global_batch=None, sync=True, comm=None):
     """One intention-map supervision step (train.py:143-158) on the device: split the ground-truth map (last state
     channel) off the replay states, train-mode forward of FCN(C-1, 1), BCE-with-logits + its gradient in one kernel,
     backward, momentum SGD (no clipping on this path).  Returns {'loss_intention': float} or, with sync=False, the
@@ -544,17 +573,20 @@ def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_s
     lib.call('simq_bce_with_logits', ptr(logits), ptr(target), B * W * W, ptr(dlogits), ptr(loss_sum), st)   # :149-150
     if gB != B:
         dlogits.mul_(B / gB)
-    if process_group is None:
+    if process_group is None and comm is None:
         grads = intention_net._backward_raw(dlogits, B)                                               # train.py:151-152
-    else:
+    else:       # data parallel: same two gradient buckets as train_step
+        reduce_async = (lambda t: sdist.allreduce_async(t, process_group)) if comm is None else comm.all_reduce
         split = intention_net.grad_bucket_split
         grads = intention_net._backward_raw(dlogits, B, phase=1)
-        work = sdist.allreduce_async(grads[split:], process_group)
+        works = [reduce_async(grads[split:])]
         intention_net._backward_raw(dlogits, B, phase=2)
-        work2 = sdist.allreduce_async(grads[:split], process_group)
-        work3 = sdist.allreduce_async(loss_sum, process_group)
-        for wk in (work, work2, work3):
-            wk.wait()
+        works += [reduce_async(grads[:split]), reduce_async(loss_sum)]
+        if comm is not None:
+            comm.wait()
+        else:
+            for wk in works:
+                wk.wait()
     lib.call('simq_clip_sgd_step', ptr(intention_net.flat_params), ptr(grads), ptr(st_opt.momentum),
              intention_net.plan.param_count, 0.0, lr, momentum, weight_decay, 0 if st_opt.initialised else 1,
              ptr(st_opt.scratch), ptr(st_opt.total_norm), st)                                         # train.py:153

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(L):
     for s in syms:
         assert hasattr(raw, s), 'libsimq.so does not export %s' % s
     assert sorted(L.EXPORTS) == syms, 'ctypes binding and header disagree'
-    assert L.lib.version == 100
+    assert L.lib.version == 200
 
 
 def test_plan_layout_matches_reference_state_dict(L):
@@ -78,6 +78,17 @@ def test_argument_errors_are_reported_not_thrown(L):
     h2 = ctypes.c_void_p()
     assert L.lib.c.simq_plan_create_ex(4, 2, 7, ctypes.byref(h2)) != 0 and 'precision' in L.last_error()
     assert L.lib.c.simq_workspace_bytes(plan.handle, 32) > L.lib.c.simq_workspace_bytes(plan.handle, 1) > 0
+    # data-parallel gradient exchange (simq_comm_*): librccl.so.1 is bound at run time; arguments are validated before any device call
+    ident = (ctypes.c_ubyte * L.COMM_ID_BYTES)()
+    assert L.lib.c.simq_comm_unique_id(None) != 0 and 'NULL' in L.last_error()
+    hc = ctypes.c_void_p()
+    assert L.lib.c.simq_comm_init(None, 1, 0, ctypes.byref(hc)) != 0 and 'NULL' in L.last_error()
+    assert L.lib.c.simq_comm_init(ident, 2, 5, ctypes.byref(hc)) != 0 and 'rank 5 of 2' in L.last_error()
+    assert L.lib.c.simq_comm_allreduce(None, None, 0, 0, None) != 0 and 'bad argument' in L.last_error()
+    assert L.lib.c.simq_comm_broadcast(None, None, 0, 0, None) != 0
+    assert L.lib.c.simq_comm_wait(None, None) != 0 and 'NULL' in L.last_error()
+    assert L.lib.c.simq_comm_world_size(None) == -1 and L.lib.c.simq_comm_rank(None) == -1
+    assert L.lib.c.simq_comm_destroy(None) == 0
 
 
 def test_product_never_imports_oracle():

@@ -1,0 +1,253 @@
+"""GPU: the data-parallel HIP step (BASELINE configs[3] / configs[4]) -- simq.learner.train_step with a process group /
+libsimq's RCCL communicator, i.e. simq_backward_onehot(phase 1 | 2) + the bucketed gradient all-reduces + identical clip/SGD on
+every rank, one process per rank.
+
+The GPU box has ONE MI355X, so the ranks are
+  (a) a 1-rank "nccl" (== RCCL) group with libsimq's own communicator (simq_comm_*): the whole step is the data-parallel form of
+      simq_train_step -- phases, ncclAllReduce on the communicator's stream, event fork/join;
+  (b) 2 / 8 ranks that SHARE the GPU and talk over gloo (RCCL refuses two ranks on one device): the Python-sequenced form with
+      torch.distributed collectives around the two backward phases.
+Checked against
+  * fixture G7 (tests/golden/dp_*.npz): the reference's own networks.FCN run replica by replica by oracle/gen_golden.py
+    (nn.DataParallel semantics, policies.py:39: per-replica BatchNorm statistics, gradients summed, replica 0's running
+    statistics kept) -- loss, td error, q_sa, TD targets, the fp64 gradient summary, rank-0 BN buffers; one case has shards
+    that hold terminal transitions only;
+  * size-independent properties at the per-GPU shapes of configs[3] (Cin 5, Cout 2 and 1, 64 transitions per rank, fp32) and
+    configs[4] (128 per rank, bf16): the all-reduced gradient equals the sum of the shard gradients computed one after the other
+    by a single process, every rank ends with bit-identical parameters, loss / td error are the global means.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import cases
+from oracle import fcn as ofcn
+from simq import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_nets(simq, cin, cout, wseed, precision, dev):
+    policy = simq.FCN(cin, cout, device=dev, precision=precision)
+    target = simq.FCN(cin, cout, device=dev, precision=precision)
+    policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed)))
+    target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed + 1000)))
+    policy.train()
+    target.eval()
+    return policy, target
+
+
+def _transitions(cin, cout, gB, dseed, terminal_frac):
+    return synth.make_transitions(gB, cin, cout, dseed, terminal_frac=terminal_frac)
+
+
+def _unclipped(policy):
+    """flat gradient as all-reduced, before clip_grad_norm_ scaled it in place."""
+    tn = float(policy._simq_opt_state.total_norm.item())
+    coef = min(1.0, cases.CLIP / (tn + 1e-6))
+    return policy.flat_grads.detach().double().cpu() / coef, tn
+
+
+def _worker(rank, world, port, backend, use_comm, spec, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import simq
+        from simq import dist as sdist
+        from simq.learner import Transition, assemble_batch, train_step
+        cin, cout, gB, wseed, dseed, precision, tfrac, steps = spec
+        trs = _transitions(cin, cout, gB, dseed, tfrac)
+        lo, hi = sdist.shard_bounds(gB, world, rank)
+        policy, target = _make_nets(simq, cin, cout, wseed, precision, dev)
+        comm = sdist.Comm(dist.group.WORLD) if use_comm else None
+        pg = None if use_comm else dist.group.WORLD
+        shard = assemble_batch(Transition(*zip(*trs[lo:hi])), dev, allow_all_final=True)
+        out = {}
+        for s in range(steps):
+            info = train_step(policy, target, shard, cases.GAMMA, hi - lo, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                              use_double_dqn=True, process_group=pg, global_batch=gB, comm=comm)
+            if s == 0:
+                g, tn = _unclipped(policy)
+                out.update(grad=g.numpy(), total_norm=tn, loss=info['loss'], td_error=info['td_error'],
+                           q_sa=policy._last['q_sa'].cpu().numpy(), y=policy._last['y'].cpu().numpy(),
+                           bn=policy.bn_buffers.cpu().numpy(), params1=policy.flat_params.cpu().numpy())
+        out.update(params=policy.flat_params.cpu().numpy(), momentum=policy._simq_opt_state.momentum.cpu().numpy(),
+                   loss_last=info['loss'])
+        if comm is not None:            # broadcast through the communicator: every rank adopts rank 0's running statistics
+            bn = policy.bn_buffers.clone()
+            comm.broadcast(bn, 0)
+            comm.wait()
+            out['bn_bcast'] = bn.cpu().numpy()
+            comm.close()
+        else:
+            out['bn_bcast'] = sdist.broadcast_bn_buffers(policy.bn_buffers.clone(), dist.group.WORLD).cpu().numpy()
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ranks(tmp_path, world, backend, use_comm, spec):
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, use_comm, spec, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail('data-parallel rank did not finish (hang)')
+        assert p.exitcode == 0, 'a data-parallel rank failed (exit code %r)' % p.exitcode
+    return [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
+
+
+def _reference_layout(simq, cin, cout, flat):
+    """flat HIP gradient (OHWI conv weights) -> {reference key: flat tensor in the reference's OIHW order}."""
+    from simq import arch
+    plan = simq._lib.Plan(cin, cout)
+    out = {}
+    t = torch.as_tensor(flat)
+    for name, off, shape, kind in plan.tensors:
+        n = int(np.prod(shape))
+        v = t[off:off + n].view(shape)
+        out[arch.PREFIX + name] = (v.permute(0, 3, 1, 2).contiguous() if len(shape) == 4 else v).reshape(-1)
+    return out
+
+
+def _sampled_relerr(got, g):
+    """relative L2 error over the 16 sampled elements of every tensor against the fixture's fp64 summary + per-tensor norm check."""
+    keys = [str(k) for k in g['grad_keys']]
+    num = den = 0.0
+    worst_norm = 0.0
+    for i, k in enumerate(keys):
+        flat = got[k].double()
+        idx = torch.tensor(cases.sample_indices(flat.numel()))
+        mine = flat[idx].numpy()
+        num += ((mine - g['grad64'][i][1:]) ** 2).sum()
+        den += (g['grad64'][i][1:] ** 2).sum()
+        if g['grad64'][i][0] > 1e-3 * float(g['total_norm64']):
+            worst_norm = max(worst_norm, abs(float(flat.norm()) - g['grad64'][i][0]) / g['grad64'][i][0])
+    return (num / den) ** 0.5, worst_norm
+
+
+DP_GOLDEN = [('dp_c5o2_b8_w1', 'nccl', True), ('dp_c5o2_b8_w2', 'gloo', False), ('dp_c5o2_b8_w8', 'gloo', False),
+             ('dp_c5o1_b8_w2', 'gloo', False)]
+
+
+@pytest.mark.parametrize('name,backend,use_comm', DP_GOLDEN, ids=[c[0] + '-' + c[1] for c in DP_GOLDEN])
+def test_dp_step_against_reference_replica_fixture(tmp_path, golden_dir, name, backend, use_comm):
+    import simq
+    case = [c for c in cases.DP_CASES if c[0] == name][0]
+    _, cin, cout, gB, world, wseed, dseed = case
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    ranks = _run_ranks(tmp_path, world, backend, use_comm, (cin, cout, gB, wseed, dseed, 'fp32', 0.25, 1))
+    r0 = ranks[0]
+    for r in ranks[1:]:                 # identical clip + SGD everywhere: replicas stay bit-identical
+        assert np.array_equal(r0['params'], r['params']) and np.array_equal(r0['grad'], r['grad'])
+        assert r['loss'] == r0['loss'] and r['td_error'] == r0['td_error']
+        assert np.array_equal(r0['bn_bcast'], r['bn_bcast'])
+    assert np.array_equal(r0['bn_bcast'], r0['bn'])                             # rank 0's running statistics are the ones kept
+    rel1 = lambda a, b: abs(a - b) / abs(b)
+    assert rel1(float(r0['loss']), float(g['loss'])) < 1e-4 and rel1(float(r0['td_error']), float(g['td_error'])) < 1e-4
+    q_sa, y = np.concatenate([r['q_sa'] for r in ranks]), np.concatenate([r['y'] for r in ranks])
+    assert np.abs(q_sa - g['q_sa']).max() <= 1e-4 * np.abs(g['q_sa']).max()
+    assert np.abs(y - g['y']).max() <= 1e-4 * np.abs(g['y']).max()
+    # rank 0's BatchNorm buffers == replica 0's of the reference emulation (policy net: train-mode updates of ITS shard only)
+    # (bn_buffers is [mean | var] per layer in reference state_dict order -- the order cases.bn_buffer_vector walks)
+    want, got = g['bn_buffers_after'].astype(np.float64), r0['bn'].astype(np.float64)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    # all-reduced gradient vs the fp64 replica emulation (conditioning: DESIGN section 2; bar as in test_gpu_fcn.py)
+    err, worst_norm = _sampled_relerr(_reference_layout(simq, cin, cout, r0['grad']), g)
+    print('%s: sampled-gradient rel-L2 error %.3g (reference fp32 replicas: %.3g), worst per-tensor norm error %.3g, '
+          'total norm %.6g vs %.6g' % (name, err, float(g['ref_fp32_grad_relerr']), worst_norm, float(r0['total_norm']), float(g['total_norm64'])))
+    assert err <= max(10 * float(g['ref_fp32_grad_relerr']), 5e-3), err
+    assert worst_norm <= 5e-2 and rel1(float(r0['total_norm']), float(g['total_norm64'])) < 5e-2
+
+
+def _single_process_shard_sum(simq, spec, world):
+    """What the ranks' all-reduce must produce, computed by ONE process: each shard's gradient through the ordinary (non-parallel)
+    HIP step with the Huber sum scaled by 1/global_batch (lr = 0: the parameters stay put), summed in rank order."""
+    from simq import dist as sdist
+    from simq.learner import Transition, train_step
+    cin, cout, gB, wseed, dseed, precision, tfrac, _ = spec
+    dev = torch.device('cuda', 0)
+    trs = _transitions(cin, cout, gB, dseed, tfrac)
+    total, sums, bn0 = None, np.zeros(2), None
+    for r in range(world):
+        lo, hi = sdist.shard_bounds(gB, world, r)
+        policy, target = _make_nets(simq, cin, cout, wseed, precision, dev)
+        out = train_step(policy, target, Transition(*zip(*trs[lo:hi])), cases.GAMMA, hi - lo, 0.0, cases.MOMENTUM, 0.0, cases.CLIP,
+                         use_double_dqn=True, global_batch=gB, sync=False)
+        sums += np.asarray(out.tolist()[:2])
+        g, _ = _unclipped(policy)
+        total = g if total is None else total + g
+        if r == 0:
+            bn0 = policy.bn_buffers.cpu().numpy()
+        del policy, target
+    torch.cuda.empty_cache()
+    return total, sums[0] / gB, sums[1] / gB, bn0
+
+
+PROPERTY_CASES = [
+    # configs[3] lifting_2_pushing_2: Cin 5, one net per robot group (Cout 2 and 1), 64 transitions per GPU and net, fp32
+    ('configs3_lifting_c5o2_64perrank', (5, 2, 128, 61, 71, 'fp32', 0.1, 2), 2, 'gloo', False, 2e-4),
+    ('configs3_pushing_c5o1_64perrank', (5, 1, 128, 62, 72, 'fp32', 0.1, 2), 2, 'gloo', False, 2e-4),
+    # the same shard size through libsimq's RCCL communicator (one rank: the collectives run, the sum is the shard itself)
+    ('configs3_lifting_c5o2_64_rccl_comm', (5, 2, 64, 61, 73, 'fp32', 0.1, 2), 1, 'nccl', True, 2e-4),
+    # configs[4] lifting_4-large_empty: Cin 5, Cout 2, 128 transitions per GPU, bf16 operands
+    ('configs4_c5o2_128perrank_bf16', (5, 2, 256, 63, 74, 'bf16', 0.1, 2), 2, 'gloo', False, 2e-3),
+    ('configs4_c5o2_128_bf16_rccl_comm', (5, 2, 128, 63, 75, 'bf16', 0.1, 2), 1, 'nccl', True, 2e-3),
+]
+
+
+@pytest.mark.parametrize('name,spec,world,backend,use_comm,tol', PROPERTY_CASES, ids=[c[0] for c in PROPERTY_CASES])
+def test_dp_step_full_size_properties(tmp_path, name, spec, world, backend, use_comm, tol):
+    import simq
+    ranks = _run_ranks(tmp_path, world, backend, use_comm, spec)
+    r0 = ranks[0]
+    for r in ranks[1:]:
+        assert np.array_equal(r0['params'], r['params']) and np.array_equal(r0['momentum'], r['momentum'])
+        assert np.array_equal(r0['grad'], r['grad']) and r['loss'] == r0['loss']
+    assert np.isfinite(r0['params']).all() and np.isfinite(float(r0['loss_last']))
+    want, loss, td, bn0 = _single_process_shard_sum(simq, spec, world)
+    got = torch.as_tensor(r0['grad'])
+    err = float((got - want).norm() / want.norm())
+    print('%s: all-reduced gradient vs sum of single-process shard gradients: rel-L2 %.3g; loss %.6g vs %.6g' % (name, err, float(r0['loss']), loss))
+    assert err <= tol, err
+    assert abs(float(r0['loss']) - loss) <= 1e-5 * abs(loss) and abs(float(r0['td_error']) - td) <= 1e-5 * abs(td)
+    assert np.abs(r0['bn'] - bn0).max() <= 1e-6 * np.abs(bn0).max()               # rank 0: statistics of ITS shard only
+    # first SGD step identity on the all-reduced, clipped gradient: m = c*g + wd*p0 ; p1 = p0 - lr*m
+    cin, cout, gB, wseed = spec[0], spec[1], spec[2], spec[3]
+    p0 = _make_nets(simq, cin, cout, wseed, 'fp32', torch.device('cuda', 0))[0].flat_params.double().cpu()
+    tn = float(r0['total_norm'])
+    c = min(1.0, cases.CLIP / (tn + 1e-6))
+    m = c * torch.as_tensor(r0['grad']) + cases.WEIGHT_DECAY * p0
+    p1 = p0 - cases.LR * m
+    assert float((torch.as_tensor(r0['params1']).double() - p1).norm() / p1.norm()) < 1e-6

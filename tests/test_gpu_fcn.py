@@ -495,6 +495,61 @@ def test_onehot_backward_equals_dense_backward(simq_mod, cout):
     assert num < 1e-4, num
 
 
+def test_optimizer_state_is_interchangeable_with_the_reference_layout(simq_mod, tmp_path):
+    """train.py:204 / :331 -- optimizer.load_state_dict / optimizer.state_dict() in a checkpoint.  The reference's momentum buffers
+    are OIHW tensors; simq stores OHWI and presents every parameter / gradient / momentum buffer to torch under the reference's
+    logical [O,I,H,W] shape (a permuted view).  (1) A state dict as the reference's SGD writes it after >= 1 step (OIHW buffers,
+    here seeded random values, pickled through torch.save) is adopted element by logical index and the NEXT update is the
+    reference's sgd_step arithmetic on it; (2) a simq-written optimizer state loads into a plain torch SGD over OIHW-contiguous
+    reference-shaped parameters and steps there with identical logical buffers (Cin = 7: the stem weight [64,7,7,7] has the
+    same shape in both layouts, so a shape-based guess could not tell them apart)."""
+    import os
+    from oracle import learner as olearner
+    cin, cout, B = 7, 2, 3
+    spec = ofcn.state_spec(cin, cout)
+    ref_shapes = [tuple(s) for k, s, kind in spec if ofcn.has_gradient(kind)]
+    policy, target = make_net(simq_mod, cin, cout, 81, True), make_net(simq_mod, cin, cout, 82, False)
+    params = list(policy.parameters())
+    trainable = [p for p in params if tuple(p.shape) != (1000, 512) and tuple(p.shape) != (1000,)]
+    assert [tuple(p.shape) for p in trainable] == ref_shapes                     # parameters carry the reference's shapes
+    # (1) reference-written state: one OIHW momentum buffer per parameter that received a gradient, indexed like torch does
+    g = torch.Generator().manual_seed(5)
+    ref_bufs = [torch.randn(s, generator=g) * 1e-3 for s in ref_shapes]
+    opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    sd = opt.state_dict()
+    index_of = {id(p): i for i, p in enumerate(params)}
+    sd['state'] = {index_of[id(p)]: {'momentum_buffer': b.clone()} for p, b in zip(trainable, ref_bufs)}
+    path = os.path.join(str(tmp_path), 'opt.pth.tar')
+    torch.save({'optimizers': [sd]}, path)
+    opt.load_state_dict(torch.load(path, weights_only=False)['optimizers'][0])    # train.py:200-204
+    p_before = [p.detach().clone().cpu() for p in trainable]
+    batch = cases.make_batch(cin, cout, B, 83)
+    simq_mod.train(cases.make_cfg(B), policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    grads = [v.detach().clone().cpu() for v in policy.reference_views(policy.flat_grads)]     # clipped gradient, logical OIHW
+    want_p, want_m = [p.clone() for p in p_before], [b.clone() for b in ref_bufs]
+    olearner.sgd_step(want_p, grads, want_m, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY)     # torch.optim.SGD.step restated
+    for p, wp, wm in zip(trainable, want_p, want_m):
+        got_m = opt.state[p]['momentum_buffer']
+        assert tuple(got_m.shape) == tuple(wm.shape)
+        assert rel(got_m, wm) < 1e-6 and rel(p, wp) < 1e-6
+    # (2) simq-written state -> the reference's optimizer (plain contiguous OIHW parameters on the CPU)
+    torch.save({'optimizers': [opt.state_dict()]}, path)
+    sd2 = torch.load(path, map_location='cpu', weights_only=False)['optimizers'][0]
+    ref_params = [torch.nn.Parameter(p.detach().cpu().contiguous()) for p in params]
+    ref_opt = torch.optim.SGD(ref_params, lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    ref_opt.load_state_dict(sd2)
+    for rp, p in zip(ref_params, params):
+        if id(p) in {id(t) for t in trainable}:
+            rp.grad = torch.zeros_like(rp)
+            assert torch.equal(ref_opt.state[rp]['momentum_buffer'], opt.state[p]['momentum_buffer'].cpu())
+    ref_opt.step()                                                                # shapes agree: the reference can continue
+    # a buffer of the wrong shape is refused, not reinterpreted
+    bad = torch.optim.SGD(policy.parameters(), lr=0.01, momentum=0.9)
+    bad.state[trainable[2]]['momentum_buffer'] = torch.zeros(3, 3, device='cuda')
+    with pytest.raises(simq_mod._lib.SimqError):
+        simq_mod.train(cases.make_cfg(B), policy, target, bad, batch, olearner.apply_transform, cases.GAMMA)
+
+
 def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_dir):
     """SURVEY 8f row 4 (train.py:197-209, 309-346).  (1) a checkpoint pickled by the reference's own classes goes into the
     HBM ring and samples what the host ring samples; (2) save_policy + save_checkpoint + resume() in fresh objects continue

@@ -181,3 +181,29 @@ def test_full_size_golden_is_present_and_consistent(golden_dir):
     assert abs(tot - g['total_norm64']) <= 1e-9 * g['total_norm64']                  # global norm = norm of tensor norms
     assert float(g['ref_fp32_grad_relerr']) < 5e-3
     assert (g['num_batches_tracked'] == 4).all()
+
+
+@pytest.mark.parametrize('name', ['dp_c5o2_b8_w8', 'dp_c5o1_b8_w2'])
+def test_data_parallel_emulation_golden(name, golden_dir):
+    """Fixture G7: written after oracle.learner.dp_emulation agreed BIT FOR BIT with the reference's own FCN run replica
+    by replica (nn.DataParallel semantics, policies.py:39).  w8: eight 1-transition shards, three of them all-terminal."""
+    _, cin, cout, gB, world, wseed, dseed = [c for c in cases.DP_CASES if c[0] == name][0]
+    g = np.load('%s/%s.npz' % (golden_dir, name))
+    cfg, batch, spec = cases.make_cfg(gB), cases.make_batch(cin, cout, gB, dseed), fcn.state_spec(cin, cout)
+    st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+    total, loss, td = learner.dp_emulation(cfg, st, tg, spec, batch, world, cases.GAMMA)
+    assert abs(loss - float(g['loss'])) <= 1e-5 * abs(float(g['loss'])) and abs(td - float(g['td_error'])) <= 1e-5 * abs(float(g['td_error']))
+    assert rel(cases.bn_buffer_vector(st), g['bn_buffers_after']) < 1e-5
+    # the gradient of these tiny shards is conditioned as DESIGN section 2 describes: hold the fp32 oracle to the fp64 summary
+    # within a few times the error the reference's fp32 had on the generating host
+    off, num, den = 0, 0.0, 0.0
+    for i, k in enumerate(learner.grad_keys(spec)):
+        n = st[k].numel()
+        flat = total[off:off + n].double()
+        off += n
+        idx = torch.tensor(cases.sample_indices(n))
+        num += float(((flat[idx].numpy() - g['grad64'][i][1:]) ** 2).sum())
+        den += float((g['grad64'][i][1:] ** 2).sum())
+    assert (num / den) ** 0.5 <= max(10 * float(g['ref_fp32_grad_relerr']), 5e-3)
+    assert int(g['all_terminal_shards']) == (3 if name.endswith('w8') else 0)
+    assert float(g['shard_vs_single_replica_relerr']) > 0.5      # per-replica BN statistics are NOT SyncBN
