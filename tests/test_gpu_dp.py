@@ -131,7 +131,8 @@ def _run_ranks(tmp_path, world, backend, use_comm, spec):
 def _reference_layout(simq, cin, cout, flat):
     """flat HIP gradient (OHWI conv weights) -> {reference key: flat tensor in the reference's OIHW order}."""
     from simq import arch
-    plan = simq._lib.Plan(cin, cout)
+    from simq import _lib
+    plan = _lib.Plan(cin, cout)
     out = {}
     t = torch.as_tensor(flat)
     for name, off, shape, kind in plan.tensors:
