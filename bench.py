@@ -97,17 +97,31 @@ def cpu_baseline(batch):
                       % (batch, warm, steps, dt, os.cpu_count() or 0, avail)}
 
 
+PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summary, kernel whose bytes per launch `roofline.traffic` quotes)
+    'fp32': ('r02_pmc_traffic.json', 'igemm_conv_kernel<64, 64, true, true>'),
+    'bf16': ('r02_pmc_traffic_bf16_b128.json', None),          # None: the kernel named by DOMINANT_BF16 below
+}
+DOMINANT_BF16 = 'igemm_bf16_pp_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
+
+
 def pmc_traffic(precision):
     """HBM-side bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes) from the committed
-    rocprofv3 PMC passes over this same command (profiles/r01_pmc_traffic.json, tools/pmc_traffic.py); PMC counters cannot
+    rocprofv3 PMC passes over this same command (profiles/r02_pmc_traffic*.json, tools/pmc_traffic.py); PMC counters cannot
     be read from inside the timed process, so the value is the recorded one, or None when the file is absent."""
-    if precision != 'fp32':
+    if precision not in PMC_TRAFFIC:
         return None
-    try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        return round(t['igemm_conv_kernel<64, 64, true, true>']['bytes_per_launch'])
-    except (OSError, KeyError, ValueError):
-        return None
+    fname, kernel = PMC_TRAFFIC[precision]
+    for f in (fname, fname.replace('r02_', 'r01_')):
+        try:
+            t = json.load(open(os.path.join(ROOT, 'profiles', f)))
+        except (OSError, ValueError):
+            continue
+        if kernel is not None and kernel in t:
+            return round(t[kernel]['bytes_per_launch'])
+        cand = [(v['launches'] * v['bytes_per_launch'], v) for k, v in t.items() if k.startswith(DOMINANT_BF16) or k.startswith('igemm_bf16_dma_kernel')]
+        if kernel is None and cand:
+            return round(max(cand, key=lambda kv: kv[0])[1]['bytes_per_launch'])
+    return None
 
 
 def main():
@@ -263,53 +277,63 @@ def main():
     w = run_workload(CIN, BATCH_PER_GPU, args.precision, args.steps, args.warmup, REPLAY_ITEMS)
     value, dt, dt_m1, info, step, barrier, B, gB = (w[k] for k in ('value', 'dt', 'dt_m1', 'info', 'step', 'barrier', 'B', 'gB'))
 
-    roof = None
-    if not args.no_roofline:
-        # live per-launch timing of the GEMM-class kernels (HIP events on the launch stream) over the same K steps
+    KERNEL_NAMES = {
+        'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd F(2x2,3x3) layers: forward + dgrad of the '
+                '256- and 512-channel 3x3 convolutions, 16 GEMMs per launch, v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
+        'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
+                  'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
+        'bf16': 'large-tile LDS-DMA bf16 implicit GEMM (igemm_bf16_pp_kernel / igemm_bf16_dma_kernel, v_mfma_f32_16x16x32_bf16): forward + dgrad of '
+                'the 128..512-channel 3x3 convolutions'}
+
+    def roofline_pass(step_fn, barrier_fn, steps, precision, ms_per_step, per_gpu_rate):
+        """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
+        `steps` more steps with the two-stream overlap off, so that every bracket times one kernel alone."""
         import simq.learner as slearner
-        slearner.OVERLAP_TARGET_FORWARD = False    # serial kernels: each HIP-event bracket then times one kernel alone
+        keep = slearner.OVERLAP_TARGET_FORWARD
+        slearner.OVERLAP_TARGET_FORWARD = False
         lib.call('simq_profile_start')
-        barrier()
+        barrier_fn()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
+        for _ in range(steps):
+            step_fn()
+        barrier_fn()
         dt_inst = time.perf_counter() - t1
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
-        dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # batched transform-domain GEMM (fp32 Winograd layers)
-        wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}
-        oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # every other implicit-GEMM tile
+        slearner.OVERLAP_TARGET_FORWARD = keep
+        dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # kind 0: the dominant kernel of the precision
+        wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}       # kind 1: direct weight-gradient launches
+        oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # kind 2: every other implicit-GEMM tile
         allg = {k: dom[k] + oth[k] for k in dom}
-        # the dominant KERNEL of the fp32 workload is the batched GEMM of the Winograd layers (its EXECUTED flops are counted:
-        # 16 x 2*T*Cout*Cin per launch, 2.25x fewer than the 3x3 convolution it implements); the other precisions report all tiles
-        ig = dom if (args.precision == 'fp32' and dom['launches'] > 0) else allg
-        ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12 if ig['ms'] > 0 else 0.0
-        ach_all = allg['flops'] / (allg['ms'] * 1e-3) / 1e12 if allg['ms'] > 0 else 0.0
-        PEAK = PEAK_FP32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
-        kname = {'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd F(2x2,3x3) layers: forward + dgrad of the '
-                         '256- and 512-channel 3x3 convolutions, 16 GEMMs per launch, v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
-                 'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
-                           'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
-                 'bf16': 'igemm_bf16_kernel<NP=1> (bf16 implicit GEMM, v_mfma_f32_16x16x32_bf16)'}[args.precision]
-        roof = {
-            'bound': 'mfma', 'kernel': kname,
-            'achieved': round(ach, 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK, 4),
-            'traffic': pmc_traffic(args.precision),
-            'launches_per_step': ig['launches'] / args.steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
+        # fp32: the batched GEMM of the Winograd layers (EXECUTED flops: 16 x 2*T*Cout*Cin per launch, 2.25x fewer than the 3x3
+        # convolution it implements); bf16: the large-tile LDS-DMA kernel; when a precision has no kind-0 launches, all tiles
+        ig = dom if dom['launches'] > 0 else allg
+        tf = lambda d: d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        PEAK = PEAK_FP32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+        executed = (dom['flops'] + oth['flops'] + wg['flops']) / steps          # matrix-core flops actually issued per step
+        return {
+            'bound': 'mfma', 'kernel': KERNEL_NAMES[precision],
+            'achieved': round(tf(ig), 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(tf(ig) / PEAK, 4),
+            'traffic': pmc_traffic(precision),
+            'launches_per_step': ig['launches'] / steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
             'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
-            'kernel_ms_per_step': round(ig['ms'] / args.steps, 4),
-            'direct_conv_equivalent_tflops': round(2.25 * ach, 2) if (args.precision == 'fp32' and dom['launches'] > 0) else None,
-            'all_implicit_gemm_tiles': {'launches_per_step': allg['launches'] / args.steps, 'kernel_ms_per_step': round(allg['ms'] / args.steps, 4),
-                                        'achieved': round(ach_all, 2), 'frac': round(ach_all / PEAK, 4)},
-            'wgrad': {'launches_per_step': wg['launches'] / args.steps, 'kernel_ms_per_step': round(wg['ms'] / args.steps, 4),
-                      'achieved': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2) if wg['ms'] > 0 else 0.0,
-                      'frac': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12 / PEAK, 4) if wg['ms'] > 0 else 0.0},
-            'whole_step': {'note': 'direct-convolution flops per transition (SURVEY 8d) x measured rate / peak; the Winograd layers execute 2.25x fewer',
-                           'mfma_frac_M2': round(value / world * FLOP_M2 / (PEAK * 1e12), 4),
-                           'hbm_frac_activation_lower_bound': round(value / world * 61.9e6 / (PEAK_HBM_GBS * 1e9), 5)},
-            'ms_per_step_instrumented': round(dt_inst / args.steps * 1e3, 3),
+            'kernel_ms_per_step': round(ig['ms'] / steps, 4),
+            'direct_conv_equivalent_tflops': round(2.25 * tf(ig), 2) if (precision == 'fp32' and dom['launches'] > 0) else None,
+            # flat copies of the secondary figures (nested objects do not survive the driver's summary of the line)
+            'all_gemm_tiles_launches_per_step': allg['launches'] / steps, 'all_gemm_tiles_ms_per_step': round(allg['ms'] / steps, 4),
+            'all_gemm_tiles_achieved': round(tf(allg), 2), 'all_gemm_tiles_frac': round(tf(allg) / PEAK, 4),
+            'wgrad_launches_per_step': wg['launches'] / steps, 'wgrad_ms_per_step': round(wg['ms'] / steps, 4),
+            'wgrad_achieved': round(tf(wg), 2), 'wgrad_frac': round(tf(wg) / PEAK, 4),
+            # the whole step against the matrix-core roof: EXECUTED matrix flops per step / un-instrumented step time / peak
+            'whole_step_executed_gflop': round(executed / 1e9, 2),
+            'whole_step_executed_frac': round(executed / (ms_per_step * 1e-3) / (PEAK * 1e12), 4),
+            'whole_step_hbm_frac_activation_lower_bound': round(per_gpu_rate * (61.9e6 if precision == 'fp32' else 31.0e6) / (PEAK_HBM_GBS * 1e9), 5),
+            'ms_per_step_instrumented': round(dt_inst / steps * 1e3, 3),
         }
+
+    roof = None
+    if not args.no_roofline:
+        roof = roofline_pass(step, barrier, args.steps, args.precision, dt / args.steps * 1e3, value / world)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -317,36 +341,48 @@ def main():
 
     # BASELINE configs[2] (lifting_4-small_divider: Cin=5, batch 128, bf16 operands) on the opt-in bf16 matrix-core path,
     # reported beside the fp32 headline, never instead of it (N=1 default run only; a few seconds)
-    extras = None
+    extras, roof_bf16 = None, None
     if world == 1 and args.precision == 'fp32' and not args.no_extras and args.cin == 4 and args.batch == 32:
         try:
             e = run_workload(5, 128, 'bf16', 10, 3, 256)
-            extras = {'configs[2] lifting_4-small_divider, batch 128, bf16 operands (f32 accumulate / BN / optimiser)': {
-                'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / 10 * 1e3, 3),
-                'fwd_bwd_only_transitions_per_s': round(e['gB'] * 10 / e['dt_m1'], 1),
-                'fwd_bwd_only_ms_per_step': round(e['dt_m1'] / 10 * 1e3, 3), 'last_loss': e['info']['loss']}}
+            extras = {'workload': 'BASELINE configs[2] lifting_4-small_divider (Cin=5), minibatch 128, bf16 operands (f32 accumulate / BN / optimiser)',
+                      'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / 10 * 1e3, 3),
+                      'fwd_bwd_only_transitions_per_s': round(e['gB'] * 10 / e['dt_m1'], 1),
+                      'fwd_bwd_only_ms_per_step': round(e['dt_m1'] / 10 * 1e3, 3), 'last_loss': e['info']['loss']}
+            if not args.no_roofline:
+                roof_bf16 = roofline_pass(e['step'], e['barrier'], 10, 'bf16', e['dt'] / 10 * 1e3, e['value'])
             del e
             torch.cuda.empty_cache()
         except Exception as ex:       # the headline line must not depend on the opt-in leg
             extras = {'error': repr(ex)}
 
     if rank == 0:
+        m1 = None if args.no_m1 else round(gB * args.steps / dt_m1, 2)
         line = {
             'metric': 'Q-map transitions/sec (full train() step: 3 fwd + bwd + clip + SGD, 96x96)',
             'value': round(value, 2), 'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMA products, f32 accumulate)', 'bf16': 'bf16 (f32 accumulate / BN / optimiser)'}[args.precision], 'data': 'synthetic',
+            # BASELINE's metric text says "fwd+bwd": the literal reading (M1 of SURVEY 8d: policy forward + gather + Huber + backward only,
+            # no next-state forwards / all-reduce / clip / SGD) beside the full-step `value` (M2), never instead of it
+            'value_fwd_bwd_only': m1, 'ms_per_step_fwd_bwd_only': None if args.no_m1 else round(dt_m1 / args.steps * 1e3, 3),
             'config': {'workload': '%s (Cin=%d, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
                                    'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
                        'global_batch': gB, 'parallelism': 'dp%d' % world, 'gradient_transport': transport,
-                       'flop_per_transition': FLOP_M2,
-                       'fwd_bwd_only': None if args.no_m1 else {'value': round(gB * args.steps / dt_m1, 2), 'unit': 'transitions/s',
-                                        'ms_per_step': round(dt_m1 / args.steps * 1e3, 3), 'flop_per_transition': FLOP_M1,
-                                        'note': 'policy forward + gather + Huber + backward only (M1 of SURVEY 8d); no '
-                                                'gradient all-reduce, clip or SGD'}, 'last_loss': info['loss'], 'last_td_error': info['td_error'],
-                       'opt_in_precisions': extras},
+                       'flop_per_transition': FLOP_M2, 'flop_per_transition_fwd_bwd_only': FLOP_M1,
+                       'last_loss': info['loss'], 'last_td_error': info['td_error']},
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if extras is not None:      # BASELINE configs[2] on the opt-in bf16 path: flat `bf16_*` keys + its own roofline object
+            line['bf16_configs2'] = extras
+            line['roofline_bf16_configs2'] = roof_bf16
+            for k in ('full_step_transitions_per_s', 'fwd_bwd_only_transitions_per_s', 'ms_per_step'):
+                if k in extras:
+                    line['config']['bf16_configs2_' + k] = extras[k]
+            if roof_bf16 is not None:
+                for k in ('achieved', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step', 'whole_step_executed_frac',
+                          'wgrad_frac', 'all_gemm_tiles_frac'):
+                    line['roofline']['bf16_configs2_' + k] = roof_bf16[k]
         print(json.dumps(line))
     if comm is not None:
         comm.close()

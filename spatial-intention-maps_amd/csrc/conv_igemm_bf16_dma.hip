@@ -52,8 +52,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// WM x WN waves (WM * WN = 4); wave tile (BM / WM) x (BN / WN)
-template <int BM, int BN, int WM, int NW, int DBG = 0>
+// WM x WN waves (WM * WN = NW); wave tile (BM / WM) x (BN / WN).
+// AIP ("A in place"): the activation fragments are NOT double-buffered -- fragment i of the next k-step is loaded into its own
+// registers right behind the MFMA row that consumed it (it is needed again a whole half stage later), only the weight
+// fragments keep two sets.  That frees TM * 4 registers and is what lets the 288 x 256 tile (wave tile 144 x 64: 144 accumulator
+// registers) fit the 256-register budget of two waves per SIMD.
+template <int BM, int BN, int WM, int NW, int DBG = 0, bool AIP = false>
 __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmBfArgs p) {
     using C = DmaCfg<BM, BN, NW>;
     constexpr int WN = NW / WM;
@@ -141,12 +145,12 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
         a_off[sub] = ra * 128 + (((sub * 4 + fq) ^ sa) << 4);
         b_off[sub] = BM * 128 + rb * 128 + (((sub * 4 + fq) ^ sb) << 4);
     }
-    bf16x8 af[2][TM], bf[2][TN];
+    bf16x8 af[AIP ? 1 : 2][TM], bf[2][TN];
     auto read_frags = [&](auto set_c, int buf, int sub) {
         constexpr int SET = decltype(set_c)::value;
         const char* st = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[SET][i] = *reinterpret_cast<const bf16x8*>(st + a_off[sub] + i * 2048);
+        for (int i = 0; i < TM; ++i) af[AIP ? 0 : SET][i] = *reinterpret_cast<const bf16x8*>(st + a_off[sub] + i * 2048);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[SET][j] = *reinterpret_cast<const bf16x8*>(st + b_off[sub] + j * 2048);
     };
@@ -177,7 +181,8 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
     auto half_stage = [&](auto fs_c, auto dma_c, int rbuf, int rsub, int dbuf) {
         constexpr int FS = decltype(fs_c)::value;
         constexpr bool DMA = decltype(dma_c)::value;
-        constexpr int NITEMS = TM + TN + (DMA ? NI : 0);
+        constexpr int AS = AIP ? 0 : FS;                             // fragment set the MFMAs read their A operand from
+        constexpr int NITEMS = (AIP ? 0 : TM) + TN + (DMA ? NI : 0);
         constexpr int SLOTS = TM - 1;                               // after MFMA rows 0 .. TM-2
         constexpr int PER = (NITEMS + SLOTS - 1) / SLOTS;
         const char* st = smem + rbuf * STAGE;
@@ -185,16 +190,19 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (DBG & 16) asm volatile("" :: "v"(af[FS][i]), "v"(bf[FS][j]));
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[FS][i], bf[FS][j], acc[i][j], 0, 0, 0);
+                if constexpr (DBG & 16) asm volatile("" :: "v"(af[AS][i]), "v"(bf[FS][j]));
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[AS][i], bf[FS][j], acc[i][j], 0, 0, 0);
+            }
+            if constexpr (AIP) {                                    // refill this row's A fragment for the next k-step
+                if constexpr (!(DBG & 8)) af[0][i] = *reinterpret_cast<const bf16x8*>(st + a_off[rsub] + i * 2048);
             }
             if (i < SLOTS) {
 #pragma unroll
                 for (int q = 0; q < PER; ++q) {
                     const int it = i * PER + q;
                     if (it < TN) { if constexpr (!(DBG & 8)) bf[FS ^ 1][it] = *reinterpret_cast<const bf16x8*>(st + b_off[rsub] + it * 2048); }
-                    else if (it < TN + TM) { if constexpr (!(DBG & 8)) af[FS ^ 1][it - TN] = *reinterpret_cast<const bf16x8*>(st + a_off[rsub] + (it - TN) * 2048); }
-                    else if (it < NITEMS) { if constexpr (!(DBG & 1)) dma_item(it - TN - TM, dbuf); }
+                    else if (!AIP && it < TN + TM) { if constexpr (!(DBG & 8)) af[AIP ? 0 : (FS ^ 1)][it - TN] = *reinterpret_cast<const bf16x8*>(st + a_off[rsub] + (it - TN) * 2048); }
+                    else if (it < NITEMS) { if constexpr (!(DBG & 1)) dma_item(it - TN - (AIP ? 0 : TM), dbuf); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -238,7 +246,7 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
     else igemm_epilogue<BM, BN, TM, TN, WM, NW>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 
-template <int BM, int BN, int WM, int NW = 4, int DBG = 0>
+template <int BM, int BN, int WM, int NW = 4, int DBG = 0, bool AIP = false>
 int run(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
@@ -247,7 +255,7 @@ int run(const IgemmBfArgs& a, hipStream_t stream) {
     prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((igemm_bf16_dma_kernel<BM, BN, WM, NW, DBG>), dim3((unsigned)(tilesM * p.tilesN)), dim3(NW * 64), 0, stream, p);
+    hipLaunchKernelGGL((igemm_bf16_dma_kernel<BM, BN, WM, NW, DBG, AIP>), dim3((unsigned)(tilesM * p.tilesN)), dim3(NW * 64), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 1;
@@ -264,6 +272,7 @@ int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
         }
         return run<288, 128, 2, 8>(a, stream);
     }
+    if (bm == 288 && bn == 256) return run<288, 256, 2, 8, 0, true>(a, stream);
     if (bm == 144 && bn == 128) return run<144, 128, 1>(a, stream);
     if (bm == 288 && bn == 64) return run<288, 64, 2>(a, stream);
     if (bm == 144 && bn == 64) return run<144, 64, 1>(a, stream);

@@ -21,6 +21,9 @@ struct IgemmBfArgs {
 // 0 when the shape is not covered (the caller falls back to the register-staged kernel), < 0 on error.
 int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream);
 
+// conv_igemm_bf16_pp.hip: 288 x 256 tile, wave groups one barrier apart (ping-pong); same return convention
+int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream);
+
 // SIMQ_XCD_REMAP=0 keeps launch order
 inline int bf16_xcd_chunk(int tiles, int tilesN) {
     static const int on = (getenv("SIMQ_XCD_REMAP") && atoi(getenv("SIMQ_XCD_REMAP")) == 0) ? 0 : 1;
