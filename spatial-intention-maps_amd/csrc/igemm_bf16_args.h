@@ -24,6 +24,9 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream);
 // conv_igemm_bf16_pp.hip: 288 x 256 tile, wave groups one barrier apart (ping-pong); same return convention
 int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream);
 
+// conv_igemm_bf16_img.hip: one 24 x 24 image x 128 output channels per block, halo patch staged once per channel chunk
+int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream);
+
 // SIMQ_XCD_REMAP=0 keeps launch order
 inline int bf16_xcd_chunk(int tiles, int tilesN) {
     static const int on = (getenv("SIMQ_XCD_REMAP") && atoi(getenv("SIMQ_XCD_REMAP")) == 0) ? 0 : 1;

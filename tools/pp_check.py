@@ -36,19 +36,21 @@ def run(B, name, tile, reps=5):
     return out, s, ms, 2.0 * B * H * H * Cout * k * k * Cin
 
 
-if os.environ.get('SIMQ_BF16_PP_DBG'):          # timing ablation of the ping-pong kernel (results are wrong by construction)
+if os.environ.get('SIMQ_BF16_PP_DBG') or os.environ.get('SIMQ_BF16_IMG_DBG'):   # timing ablations (results are wrong by construction)
     for name in ('l4', 'l3'):
-        _, _, ms, fl = run(128, name, (288, 256))
-        print('DBG=%s B=128 %s 288x256 pp %.1f us' % (os.environ['SIMQ_BF16_PP_DBG'], name, ms * 1e3), flush=True)
+        tile = (288, 256) if os.environ.get('SIMQ_BF16_PP_DBG') else (576, 128)
+        _, _, ms, fl = run(128, name, tile)
+        print('DBG=%s B=128 %s %dx%d %.1f us' % (os.environ.get('SIMQ_BF16_PP_DBG') or os.environ.get('SIMQ_BF16_IMG_DBG'), name, tile[0], tile[1], ms * 1e3), flush=True)
     sys.exit(0)
 for B in [int(a) for a in sys.argv[1:]] or [128, 115]:
     for name in SHAPES:
         ref, sref, ms_ref, fl = run(B, name, (128, 128))
         dma, sdma, ms_dma, _ = run(B, name, (288, 128))
         pp, spp, ms_pp, _ = run(B, name, (288, 256))
-        err = float((pp - ref).abs().max() / ref.abs().max())
-        serr = float((spp - sref).abs().max() / sref.abs().max())
-        print('B=%d %-3s  128x128 %.1f us (%.0f TF/s) | 288x128 dma %.1f us (%.0f TF/s) | 288x256 pp %.1f us (%.0f TF/s)   max dev y %.2e stats %.2e'
-              % (B, name, ms_ref * 1e3, fl / ms_ref / 1e9, ms_dma * 1e3, fl / ms_dma / 1e9, ms_pp * 1e3, fl / ms_pp / 1e9, err, serr), flush=True)
+        im, sim, ms_im, _ = run(B, name, (576, 128))
+        err = max(float((pp - ref).abs().max() / ref.abs().max()), float((im - ref).abs().max() / ref.abs().max()))
+        serr = max(float((spp - sref).abs().max() / sref.abs().max()), float((sim - sref).abs().max() / sref.abs().max()))
+        print('B=%d %-3s  128x128 %.1f us (%.0f TF/s) | 288x128 dma %.1f us (%.0f) | 288x256 pp %.1f us (%.0f) | image-tile 576x128 %.1f us (%.0f TF/s)   max dev y %.2e stats %.2e'
+              % (B, name, ms_ref * 1e3, fl / ms_ref / 1e9, ms_dma * 1e3, fl / ms_dma / 1e9, ms_pp * 1e3, fl / ms_pp / 1e9, ms_im * 1e3, fl / ms_im / 1e9, err, serr), flush=True)
         assert err < 1e-4 and serr < 1e-6, (err, serr)
 print('pp_check OK')
