@@ -225,6 +225,65 @@ def gen_dp():
               'all-terminal shards: %d; per-shard-BN vs single replica: %.3g' % (relerr, empty_shards, float((t64 - one).norm() / one.norm())))
 
 
+def gen_bf16_calibration():
+    """Fixture G8: how far the REFERENCE moves when its own modules run in bf16 -- torch.autocast('cpu', bfloat16) over
+    the imported networks.FCN / train.train arithmetic (bf16 convolution operands and outputs, fp32 BatchNorm statistics and
+    parameters: the mixed-precision recipe the opt-in `precision='bf16'` plans follow) -- measured against the fp64 oracle on the
+    forward and train fixtures' own inputs.  The GPU tests hold the HIP bf16 path to a small multiple of THESE errors instead of an
+    asserted constant."""
+    from torch.nn.functional import smooth_l1_loss
+    out = {}
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    for name, cin, cout, B, wseed, dseed in cases.FORWARD_CASES:
+        x = torch.cat([learner.apply_transform(s) for s in synth.make_states(B, cin, dseed)])
+        for training in (False, True):
+            st64 = cases.oracle_state(cin, cout, wseed, torch.float64)
+            with torch.no_grad():
+                q64 = fcn.fcn_forward(st64, x.double(), training)
+            net = ref_net(cin, cout, wseed)
+            net.train(training)
+            with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+                q16 = net(x)
+            out['%s.%s' % (name, 'train' if training else 'eval')] = rel(q16.float().numpy(), q64.numpy())
+    for name, cin, cout, B, wseed, dseed in cases.TRAIN_CASES:
+        cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        ex64 = {}
+        i64 = learner.train_step(cfg, st64, tg64, spec, [None] * len(learner.grad_keys(spec)), batch, cases.GAMMA, cases.LR,
+                                 cases.MOMENTUM, cases.WEIGHT_DECAY, dtype=torch.float64, extras=ex64)
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        # train.py:109-132 under autocast (the reference's train() moves tensors itself; restated here so that autocast wraps the forwards)
+        state_b = torch.cat([learner.apply_transform(s) for s in batch.state])
+        act = torch.tensor(batch.action, dtype=torch.long)
+        rew = torch.tensor(batch.reward, dtype=torch.float32)
+        nf = torch.cat([learner.apply_transform(s) for s in batch.next_state if s is not None])
+        mask = torch.tensor([s is not None for s in batch.next_state], dtype=torch.bool)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            q = policy(state_b).float().view(B, -1).gather(1, act.unsqueeze(1)).squeeze(1)
+            nsv = torch.zeros(B)
+            with torch.no_grad():
+                best = policy(nf).float().view(nf.size(0), -1).max(1)[1].view(-1, 1)
+                nsv[mask] = target(nf).float().view(nf.size(0), -1).gather(1, best).view(-1)
+        y = rew + cases.GAMMA * nsv
+        loss = smooth_l1_loss(q, y)
+        loss.backward()
+        grads = {k: p.grad for k, p in policy.named_parameters() if p.grad is not None}
+        num = sum(float((grads[k[len('module.'):] if k[len('module.'):] in grads else k].double() - ex64['grads'][k]).pow(2).sum())
+                  for k in ex64['grads'] if (k in grads or k[len('module.'):] in grads))
+        den = sum(float(ex64['grads'][k].pow(2).sum()) for k in ex64['grads'])
+        out[name + '.loss'] = abs(float(loss) - i64['loss']) / abs(i64['loss'])
+        out[name + '.td_error'] = abs(float(torch.abs(q - y).mean()) - i64['td_error']) / abs(i64['td_error'])
+        out[name + '.grad'] = (num / den) ** 0.5
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'bf16_calibration.npz'), **{k: np.array(v) for k, v in out.items()})
+    for k, v in out.items():
+        print('bf16 calibration (reference under torch.autocast bf16 vs fp64)  %-28s %.4g' % (k, v))
+
+
 def gen_intention():
     """train.train_intention (train.py:143-158) run twice on the reference vs the oracle restatement, bit-exact."""
     for name, cin_full, B, wseed, dseed in cases.INTENTION_CASES:
@@ -349,6 +408,6 @@ if __name__ == '__main__':
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
             'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
-            'dp': gen_dp}
+            'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

@@ -47,6 +47,10 @@ struct ConvEpilogue {
     const float* shift = nullptr;    // [Cout]
     const float* addend = nullptr;   // [M][Cout] (may alias the output)
     int relu = 0;
+    // plain-bf16 plans keep the pre-BatchNorm convolution outputs as bf16 (statistics still come from the fp32 accumulators):
+    // y_bf16: the output pointer is a uint16_t [M][Cout] buffer; bnr_y_bf16: so are bnr_y1 / bnr_y2
+    int y_bf16 = 0, bnr_y_bf16 = 0;
+    int addend_bf16 = 0;             // `addend` points at bf16 values (a bf16 plane: eval-mode folded BatchNorm of plain-bf16 plans)
     // dgrad only: fused reduction of the NEXT BatchNorm backward (sum dz, sum dz*xhat with dz = out * (mask > 0)),
     // optionally against a second (downsample-branch) BN that shares the mask.  See igemm_epilogue.h.
     const float* bnr_mask = nullptr;
@@ -125,8 +129,9 @@ struct BnEvalTable { BnEvalDesc d[24]; int n; };
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream);
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
+// y_bf16: `y` points at bf16 values (uint16_t), see ConvEpilogue::y_bf16
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
-                    int C, hipStream_t stream, Planes pl = Planes(), Planes res_pl = Planes());
+                    int C, hipStream_t stream, Planes pl = Planes(), Planes res_pl = Planes(), int y_bf16 = 0);
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
                          hipStream_t stream, Planes pl = Planes());
@@ -135,12 +140,12 @@ int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx
                          int C, hipStream_t stream);
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean,
-                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream);
+                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0);
 // dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
                         float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes(),
-                        const uint16_t* mask16 = nullptr);
+                        const uint16_t* mask16 = nullptr, int y_bf16 = 0);
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);

@@ -105,6 +105,12 @@ __device__ __forceinline__ void st_planes(const Planes& pl, size_t i4, float4 v)
         *reinterpret_cast<ushort4*>(pl.lo + i4 * 4) = l;
     }
 }
+// a pre-BatchNorm convolution output: fp32, or bf16 behind the same pointer (plain-bf16 plans, ConvEpilogue::y_bf16)
+__device__ __forceinline__ float4 ld4y(const float* y, size_t i4, int y_bf16) {
+    if (!y_bf16) return ld4(y + i4 * 4);
+    const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(y) + i4 * 4);
+    return make_float4(from_bf16(h.x), from_bf16(h.y), from_bf16(h.z), from_bf16(h.w));
+}
 __device__ __forceinline__ float4 relu4(float4 a) {
     return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
 }
@@ -113,7 +119,7 @@ __device__ __forceinline__ float4 relu4(float4 a) {
 // res / res_pl: the residual as fp32 or (matrix-core precisions, where the fp32 copy of a block activation is not kept) as its
 // bf16 planes; out may be NULL when only the planes are consumed downstream
 __global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const float* __restrict__ res, Planes res_pl, BnRef rbn, int has_rbn,
-                                int relu, float* __restrict__ out, Planes pl, size_t total4, int C4) {
+                                int relu, float* __restrict__ out, Planes pl, size_t total4, int C4, int y_bf16) {
     // the grid stride (gridDim*blockDim) is a multiple of C4, so a thread keeps its 4 channels: coefficients once
     const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const int c = (int)(i0 % C4) * 4;
@@ -121,7 +127,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const flo
     bn_coeff4(bn, c, sc, sh);
     if (has_rbn) bn_coeff4(rbn, c, rsc, rsh);
     for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = fma4(ld4(y + i * 4), sc, sh);
+        float4 v = fma4(ld4y(y, i, y_bf16), sc, sh);
         if (res || res_pl.hi) {
             float4 r = res ? ld4(res + i * 4) : ld_planes(res_pl, i);
             if (has_rbn) r = fma4(r, rsc, rsh);
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, double* red, size_t rows,
-                                                          int C4) {
+                                                          int C4, int y_bf16) {
     __shared__ double sm[256 * 8];
     const int tid = threadIdx.x;
     const int rowlanes = 256 / C4;
@@ -238,7 +244,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
                     dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
                     dz.z = m.z > 0.f ? dz.z : 0.f; dz.w = m.w > 0.f ? dz.w : 0.f;
                 }
-                float4 yv = ld4(y + o);
+                float4 yv = ld4y(y, o / 4, y_bf16);
                 t.x += dz.x * ((yv.x - mu.x) * is.x); t.y += dz.y * ((yv.y - mu.y) * is.y);
                 t.z += dz.z * ((yv.z - mu.z) * is.z); t.w += dz.w * ((yv.w - mu.w) * is.w);
             }
@@ -268,7 +274,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
-                                    float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4) {
+                                    float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4,
+                                    int y_bf16) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -292,7 +299,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
             dz.z = (short)m.z > 0 ? dz.z : 0.f; dz.w = (short)m.w > 0 ? dz.w : 0.f;
         }
         if (dz_out) st4(dz_out + i * 4, dz);
-        float4 yv = ld4(y + i * 4), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
+        float4 yv = ld4y(y, i, y_bf16), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
         float db[4] = {(float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]};
         float dg[4] = {(float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]};
         float4 o;
@@ -421,12 +428,12 @@ int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float*
 }
 
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
-                    int C, hipStream_t stream, Planes pl, Planes res_pl) {
+                    int C, hipStream_t stream, Planes pl, Planes res_pl, int y_bf16) {
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_apply: C=%d unsupported", C);
     SIMQ_REQUIRE(out || pl.hi, "bn_apply: no output requested");
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, res_pl, rbn ? *rbn : bn,
-                       rbn ? 1 : 0, relu, out, pl, total4, C / 4);
+                       rbn ? 1 : 0, relu, out, pl, total4, C / 4, y_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -461,22 +468,22 @@ static int reduce_grid(int64_t rows, int C4) {
 }
 
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
-                         double* red, int64_t rows, int C, hipStream_t stream) {
+                         double* red, int64_t rows, int C, hipStream_t stream, int y_bf16) {
     SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "bn_bwd_reduce: C=%d unsupported", C);
     hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, g, mask, y, mean,
-                       invstd, red, (size_t)rows, C / 4);
+                       invstd, red, (size_t)rows, C / 4, y_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
-                        int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16) {
+                        int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16, int y_bf16) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
-                       gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4);
+                       gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -485,7 +492,7 @@ int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows,
     SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
     SIMQ_CHECK_HIP(hipMemsetAsync(red_scratch, 0, sizeof(double) * C, stream));
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, x, nullptr, nullptr,
-                       nullptr, nullptr, red_scratch, (size_t)rows, C / 4);
+                       nullptr, nullptr, red_scratch, (size_t)rows, C / 4, 0);
     SIMQ_CHECK_LAUNCH();
     return launch_colsum_finish(red_scratch, out, C, stream);
 }

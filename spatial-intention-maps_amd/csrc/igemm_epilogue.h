@@ -16,6 +16,9 @@
 
 namespace simq {
 
+__device__ __forceinline__ uint16_t epi_to_bf16(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float epi_from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
 struct EpiArgs {
     float* y;
     const float* bias;
@@ -24,6 +27,7 @@ struct EpiArgs {
     const float* shift;
     const float* addend;
     int relu;
+    int y_bf16, bnr_y_bf16, addend_bf16;      // ConvEpilogue: y / bnr_y1 / bnr_y2 / addend point at bf16 values
     // fused BN-backward reduction (dgrad launches only)
     const float* bnr_mask;
     const uint16_t* bnr_mask16;
@@ -34,6 +38,7 @@ struct EpiArgs {
 inline EpiArgs make_epi(float* y, const ConvEpilogue& e) {
     EpiArgs a;
     a.y = y; a.bias = e.bias; a.stats = e.stats; a.scale = e.scale; a.shift = e.shift; a.addend = e.addend; a.relu = e.relu;
+    a.y_bf16 = e.y_bf16; a.bnr_y_bf16 = e.bnr_y_bf16; a.addend_bf16 = e.addend_bf16;
     a.bnr_mask = e.bnr_mask; a.bnr_mask16 = e.bnr_mask16;
     a.bnr_y1 = e.bnr_y1; a.bnr_mean1 = e.bnr_mean1; a.bnr_invstd1 = e.bnr_invstd1; a.bnr_red1 = e.bnr_red1;
     a.bnr_y2 = e.bnr_y2; a.bnr_mean2 = e.bnr_mean2; a.bnr_invstd2 = e.bnr_invstd2; a.bnr_red2 = e.bnr_red2;
@@ -72,15 +77,20 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
                     if (p.stats) { s0[j] += v; s1[j] += v * v; }
                     v = v * sc + sh;
                     const size_t o = (size_t)m * Cout + n;
-                    if (p.addend) v += p.addend[o];
+                    if (p.addend) v += p.addend_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.addend)[o]) : p.addend[o];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
+                    if (p.y_bf16) reinterpret_cast<uint16_t*>(p.y)[o] = epi_to_bf16(v);
+                    else p.y[o] = v;
                     if (bnr) {
                         const bool pos = p.bnr_mask ? p.bnr_mask[o] > 0.f : (short)p.bnr_mask16[o] > 0;
                         const float dz = pos ? v : 0.f;
+                        const float y1 = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y1)[o]) : p.bnr_y1[o];
                         s0[j] += dz;
-                        s1[j] += dz * ((p.bnr_y1[o] - mu1) * is1);
-                        if (bnr2) { s2[j] += dz; s3[j] += dz * ((p.bnr_y2[o] - mu2) * is2); }
+                        s1[j] += dz * ((y1 - mu1) * is1);
+                        if (bnr2) {
+                            const float y2 = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y2)[o]) : p.bnr_y2[o];
+                            s2[j] += dz; s3[j] += dz * ((y2 - mu2) * is2);
+                        }
                     }
                 }
             }
@@ -177,9 +187,21 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                 if (p.stats) { s0 += v; s1 += v * v; }
                 v = v * sc + sh;
                 const size_t o = (size_t)m * Cout + n;
-                if (p.addend) v += *reinterpret_cast<const floatx4*>(p.addend + o);
+                if (p.addend) {
+                    if (p.addend_bf16) {
+                        const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(p.addend) + o);
+                        v += floatx4{epi_from_bf16(h.x), epi_from_bf16(h.y), epi_from_bf16(h.z), epi_from_bf16(h.w)};
+                    } else {
+                        v += *reinterpret_cast<const floatx4*>(p.addend + o);
+                    }
+                }
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                *reinterpret_cast<floatx4*>(p.y + o) = v;
+                if (p.y_bf16) {
+                    *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(p.y) + o) =
+                        make_ushort4(epi_to_bf16(v[0]), epi_to_bf16(v[1]), epi_to_bf16(v[2]), epi_to_bf16(v[3]));
+                } else {
+                    *reinterpret_cast<floatx4*>(p.y + o) = v;
+                }
                 if (bnr) {
                     floatx4 dz;
                     if (p.bnr_mask) {
@@ -191,11 +213,16 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                         dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
                         dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
                     }
-                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
+                    auto ldy = [&](const float* q) -> floatx4 {
+                        if (!p.bnr_y_bf16) return *reinterpret_cast<const floatx4*>(q + o);
+                        const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(q) + o);
+                        return floatx4{epi_from_bf16(h.x), epi_from_bf16(h.y), epi_from_bf16(h.z), epi_from_bf16(h.w)};
+                    };
+                    const floatx4 y1 = ldy(p.bnr_y1);
                     s0 += dz;
                     s1 += dz * ((y1 - mu1) * is1);
                     if (bnr2) {
-                        const floatx4 y2 = *reinterpret_cast<const floatx4*>(p.bnr_y2 + o);
+                        const floatx4 y2 = ldy(p.bnr_y2);
                         s2 += dz;
                         s3 += dz * ((y2 - mu2) * is2);
                     }

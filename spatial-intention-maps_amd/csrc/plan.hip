@@ -218,6 +218,10 @@ struct Ctx {
     float* aux(const BnL& b, int which) const { return f(L.aux) + b.aux_off + (int64_t)which * b.C; }   // 0 scale 1 shift 2 mean 3 invstd
     double* red(const BnL& b) const { return reinterpret_cast<double*>(ws + L.red) + b.red_off; }
     bool mc() const { return p->precision != SIMQ_PREC_FP32; }      // matrix-core bf16 / split-bf16 convolutions
+    // plain-bf16 plans keep the pre-BatchNorm outputs of the matrix-core convolutions as bf16 (half the bytes for bn_apply, the
+    // BatchNorm backward and the fused reductions; the batch statistics still come from the fp32 accumulators)
+    int ybf() const { return p->precision == SIMQ_PREC_BF16 ? 1 : 0; }
+    int ybf(const ConvL& cv) const { return (p->precision == SIMQ_PREC_BF16 && cv.wp_off >= 0) ? 1 : 0; }
     Planes planes(int64_t off, int64_t elems) const {
         Planes pl;
         if (mc() && off >= 0) {
@@ -270,6 +274,7 @@ int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
+    e.y_bf16 = c.ybf(cv);
     return conv_fwd(c, cv, x, y, g, e);
 }
 
@@ -316,6 +321,18 @@ int conv_bn_folded(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, f
     return conv_fwd(c, cv, x, out, g, e);
 }
 
+// the same for plain-bf16 plans: input, residual and output are bf16 planes (the fp32 accumulator is scaled / shifted / added / rectified
+// in fp32 and rounded once); `out` and `addend` are plane pointers
+int conv_bn_folded_planes(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, uint16_t* out, int hin, const uint16_t* addend, int relu) {
+    ConvGeom g = geom(cv, c.B, hin);
+    ConvEpilogue e;
+    if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
+    e.scale = c.aux(bn, 0); e.shift = c.aux(bn, 1);
+    e.addend = reinterpret_cast<const float*>(addend); e.addend_bf16 = 1; e.relu = relu;
+    e.y_bf16 = 1;
+    return conv_fwd(c, cv, x, reinterpret_cast<float*>(out), g, e);
+}
+
 BnEvalTable bn_eval_table(const simq_plan* p) {
     BnEvalTable t;
     t.n = 0;
@@ -347,13 +364,28 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
                             reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl));
     // eval mode, fp32 arithmetic: BatchNorm folded into the convolution epilogues (no bn_apply launches, no pre-BN
     // round trip through HBM); the matrix-core precisions keep bn_apply, which also writes their bf16 planes
-    const bool folded = mode == SIMQ_MODE_EVAL && !c.mc();
+    // ... and so do plain-bf16 plans when only the planes of the block activations are kept (conv_bn_folded_planes)
+    static const bool no_fold16 = getenv("SIMQ_NO_BF16_EVAL_FOLD") != nullptr;      // diagnostics
+    const bool folded16 = mode == SIMQ_MODE_EVAL && p->precision == SIMQ_PREC_BF16 && c.planes_only() && !no_fold16;
+    const bool folded = (mode == SIMQ_MODE_EVAL && !c.mc()) || folded16;
     if (folded) RC(launch_bn_eval_coeff(bn_eval_table(p), c.params, c.bnbuf, c.f(L.aux), c.stream));
     for (int i = 0; i < 8; ++i) {   // BasicBlock.forward, resnet.py:31-47
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
         const int64_t n = rows * b.planes;
         Act a1 = c.block_act(o.a1, o.p_a1, n), out = c.block_act(o.out, o.p_out, n);
+        if (folded16) {
+            RC(conv_bn_folded_planes(c, b.c1, b.b1, cur, a1.pl.hi, 24, nullptr, 1));
+            const uint16_t* identity = cur.pl.hi;
+            if (b.has_ds) {                                    // (the downsample branch lands in the idle pre-BN buffer, as a plane)
+                uint16_t* yd16 = reinterpret_cast<uint16_t*>(c.f(o.yd));
+                RC(conv_bn_folded_planes(c, b.ds, b.bds, cur, yd16, 24, nullptr, 0));
+                identity = yd16;
+            }
+            RC(conv_bn_folded_planes(c, b.c2, b.b2, a1, out.pl.hi, 24, identity, 1));
+            cur = out;
+            continue;
+        }
         if (folded) {
             RC(conv_bn_folded(c, b.c1, b.b1, cur, a1.f, 24, nullptr, 1));
             const float* identity = cur.f;
@@ -366,15 +398,19 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
             continue;
         }
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
-        RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.fv ? a1.f : nullptr, rows, b.planes, c.stream, a1.pl));
+        RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.fv ? a1.f : nullptr, rows, b.planes, c.stream, a1.pl,
+                           Planes(), c.ybf()));
         RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
         if (b.has_ds) {
             RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
             const BnRef rd = bnref(c, b.bds, mode, rows);
-            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), c.f(o.yd), &rd, 1, out.fv ? out.f : nullptr, rows, b.planes, c.stream, out.pl));
+            Planes ydp;                                       // bf16 pre-BN output of the downsample conv: read as a plane
+            if (c.ybf()) ydp.hi = reinterpret_cast<uint16_t*>(c.f(o.yd));
+            RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), c.ybf() ? nullptr : c.f(o.yd), &rd, 1, out.fv ? out.f : nullptr, rows,
+                               b.planes, c.stream, out.pl, ydp, c.ybf()));
         } else {
             RC(launch_bn_apply(c.f(o.y2), bnref(c, b.b2, mode, rows), cur.fv ? cur.f : nullptr, nullptr, 1, out.fv ? out.f : nullptr, rows, b.planes,
-                               c.stream, out.pl, cur.fv ? Planes() : cur.pl));
+                               c.stream, out.pl, cur.fv ? Planes() : cur.pl, c.ybf()));
         }
         cur = out;
     }
@@ -383,7 +419,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(conv_bn_folded(c, p->h1, p->hb1, cur, c.f(L.ah1), 24, nullptr, 1));
     } else {
         RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream));
+        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream, Planes(), Planes(), c.ybf()));
     }
     Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
     RC(launch_upsample2x_fwd(c.f(L.ah1), up1.f, B, 24, 24, 128, c.stream, up1.pl));
@@ -391,7 +427,8 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(conv_bn_folded(c, p->h2, p->hb2, up1, c.f(L.ah2), 48, nullptr, 1));
     } else {
         RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
-        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream));
+        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream,
+                           Planes(), Planes(), c.ybf()));
     }
     RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
     RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
@@ -402,11 +439,13 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 // `reduced`: the sums (red slot) were already accumulated by the epilogue of the dgrad launch that produced g.
 // `mask16`: the mask as a bf16 plane when its fp32 copy is not kept (then `mask` is NULL and the reduction was fused);
 // `dy.fv == false`: only the planes of dy are written
+// `y_bf16`: y is the bf16 pre-BN output of a matrix-core convolution (Ctx::ybf)
 int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
-           bool reduced = false, const uint16_t* mask16 = nullptr) {
-    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream));
+           bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1) {
+    if (y_bf16 < 0) y_bf16 = c.ybf();
+    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16));
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
-                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16);
+                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16);
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
@@ -490,6 +529,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         const BlockL& bb = p->blocks[bi];
         if (c.planes_only()) e.bnr_mask16 = c.planes(L.blk[bi].p_out, rows * bb.planes).hi;
         else e.bnr_mask = c.f(L.blk[bi].out);
+        e.bnr_y_bf16 = c.ybf();
         e.bnr_y1 = c.f(L.blk[bi].y2); e.bnr_mean1 = c.aux(bb.b2, 2); e.bnr_invstd1 = c.aux(bb.b2, 3); e.bnr_red1 = c.red(bb.b2);
         if (bb.has_ds) {
             e.bnr_y2 = c.f(L.blk[bi].yd); e.bnr_mean2 = c.aux(bb.bds, 2); e.bnr_invstd2 = c.aux(bb.bds, 3); e.bnr_red2 = c.red(bb.bds);
@@ -523,6 +563,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(conv_wgrad(c, b.c2, a1, T0, 24));
         ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
         if (!no_fuse) {
+        f1.bnr_y_bf16 = c.ybf();
         f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1));
@@ -545,7 +586,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     Act T1; T1.f = S[(gi + 2) & 3];
     Act x0; x0.f = c.f(L.x);
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream));
-    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304));
+    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, 0));   // (the stem conv is fp32)
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
     return 0;
 }

@@ -310,22 +310,31 @@ def test_target_sync_and_checkpoint_format(simq_mod, tmp_path):
 #   'bf16x3'  split-bf16 (v = hi + lo, 3 MFMA products, fp32 accumulate): ~10x the round-off of true fp32
 #             (tests/diag/diag_fwd_error.py: eval Q-map 1.7e-5 vs 2.4e-6).  Bars: Q / loss / td <= 3e-4 (train-mode BN on
 #             2-4 samples amplifies it to ~1e-4), gradients <= max(100 x reference-fp32 error, 5e-2) vs fp64.
-#   'bf16'    plain bf16 operands (BASELINE configs 3 and 5), bf16-class bars: Q-map <= 5e-2
-#             (max-normalised), loss / td-error within 15 % on these 4-8 sample batches, gradients <= 0.5.
+#   'bf16'    plain bf16 operands AND bf16 pre-BatchNorm convolution outputs (BASELINE configs 3 and 5): the mixed-precision recipe
+#             of torch.autocast.  Bars are CALIBRATED (fixture G8, tests/golden/bf16_calibration.npz: the reference's own modules
+#             under torch.autocast('cpu', bfloat16) vs the fp64 oracle on these very inputs -- eval Q-maps 1.7-4.7e-2, train-mode
+#             Q-maps 4.6-8.7e-2, loss up to 16 %, gradients 0.45-0.54 on the 4-8 sample batches): Q-map <= max(5e-2, 1.5 x
+#             calibration), loss / td-error <= max(15 %, 2 x calibration), gradients <= max(0.5, 1.2 x calibration).
 @pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-4), ('bf16', 5e-2)])
 @pytest.mark.parametrize('case', cases.FORWARD_CASES, ids=[c[0] for c in cases.FORWARD_CASES])
 def test_precision_forward(simq_mod, case, precision, tol, golden_dir):
     name, cin, cout, B, wseed, dseed = case
     g = np.load('%s/%s.npz' % (golden_dir, name))
     x_hwc = torch.from_numpy(synth.make_states(B, cin, dseed)).cuda()
+    tol_eval = tol_train = tol
+    if precision == 'bf16':
+        cal = np.load('%s/bf16_calibration.npz' % golden_dir)
+        tol_eval, tol_train = max(tol, 1.5 * float(cal[name + '.eval'])), max(tol, 1.5 * float(cal[name + '.train']))
     net = make_net(simq_mod, cin, cout, wseed, training=False, precision=precision)
     with torch.no_grad():
         q = net.forward_nhwc(x_hwc)
-    assert rel(q, g['q_eval']) < tol
+    err_eval = rel(q, g['q_eval'])
     net = make_net(simq_mod, cin, cout, wseed, training=True, precision=precision)
     with torch.no_grad():
         q = net.forward_nhwc(x_hwc)
-    assert rel(q, g['q_train']) < tol
+    err_train = rel(q, g['q_train'])
+    print('\n[%s %s] Q-map error eval %.3g (bar %.3g) train-mode %.3g (bar %.3g)' % (name, precision, err_eval, tol_eval, err_train, tol_train))
+    assert err_eval < tol_eval and err_train < tol_train
     sd = net.state_dict()
     got = np.concatenate([sd[k].cpu().double().numpy().ravel() for k in sd
                           if k.endswith('running_mean') or k.endswith('running_var')])
@@ -360,8 +369,12 @@ def test_precision_fused_train(simq_mod, case, precision, golden_dir):
         assert rel(policy._last['q_sa'], g['q_sa']) < 3e-4 and rel(policy._last['y'], g['y']) < 3e-4
         assert err <= max(100 * ref_err, 5e-2)
     else:
-        assert rel(info['loss'], g['loss'][0]) < 0.15 and rel(info['td_error'], g['td_error'][0]) < 0.15
-        assert err <= 0.5
+        cal = np.load('%s/bf16_calibration.npz' % golden_dir)
+        print('   bf16 calibration (reference under torch.autocast): loss %.3g td %.3g grad %.3g' % (
+            float(cal[name + '.loss']), float(cal[name + '.td_error']), float(cal[name + '.grad'])))
+        assert rel(info['loss'], g['loss'][0]) < max(0.15, 2 * float(cal[name + '.loss']))
+        assert rel(info['td_error'], g['td_error'][0]) < max(0.15, 2 * float(cal[name + '.td_error']))
+        assert err <= max(0.5, 1.2 * float(cal[name + '.grad']))
     info2 = simq_mod.train(cfg, policy, target, opt, batch, None, cases.GAMMA)
     assert np.isfinite(info2['loss'])
     sd = policy.state_dict()
