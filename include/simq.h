@@ -226,6 +226,12 @@ int simq_conv2d_fwd(const float* d_x, const float* d_w_ohwi, const float* d_bias
 int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                              int batch, int hin, int win, int cin, int cout,
                              double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+/* The same convolution in Winograd F(4x4,3x3) form (36 transform-domain GEMMs over a quarter of the tiles; interpolation points
+ * {0, 1, -1, 1/2, -2, inf}): the form the plan uses for forwards nothing is differentiated through (target net, double-DQN argmax
+ * forward, policy.step).  hin, win multiples of 4.  d_scratch: 36*cout*cin + 36*T4*(cin+cout) floats, T4 = batch*(hin/4)*(win/4). */
+int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
+                              int batch, int hin, int win, int cin, int cout,
+                              double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
 /* Weight gradient of the same convolution through the transform domain (dy / x transforms, 16 batched contractions over
  * the tiles, G^T dU G).  Additionally cin % 128 == 0 and cout % 128 == 0.  d_dw is overwritten.
  * the tiles, G^T dU G); uses F(4x4,3x3) when hin, win are multiples of 4 and batch*(hin/4)*(win/4) is a multiple of 16.

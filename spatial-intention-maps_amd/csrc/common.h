@@ -76,11 +76,15 @@ bool winograd_eligible(const ConvGeom& g);
 bool winograd_pays(int cin, int cout);
 int64_t winograd_scratch_floats(const ConvGeom& g);
 int launch_wino_weight(const float* w_ohwi, float* U, int cout, int cin, hipStream_t stream);
-struct WinoWeightDesc { int64_t src_off, u_off; int cout, cin, from_wt, pad_; };   // cout / cin of the convolution U serves
+struct WinoWeightDesc { int64_t src_off, u_off; int cout, cin, from_wt, pad_; };   // cout / cin of the convolution U serves; pad_ = 1: F(4x4,3x3) form (36 planes)
 struct WinoWeightTable { WinoWeightDesc d[40]; int n; };
 int launch_wino_weight_all(const float* params, const float* wt, float* ubase, const WinoWeightTable& t, hipStream_t stream);
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                          hipStream_t stream);
+// F(4x4,3x3) form for forwards nothing is differentiated through (U4: 36 planes [Cout][Cin])
+bool winograd_f4_forward(const ConvGeom& g);
+int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
+                          hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
 // conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
 int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);

@@ -35,6 +35,7 @@ struct ConvL {
     int64_t wt_off = -1;              // into the transposed-weight scratch (dgrad), -1: no dgrad
     int64_t wp_off = -1;              // into the bf16 weight-plane scratch (matrix-core precisions), -1: stays fp32
     int64_t wu_off = -1, wut_off = -1;   // Winograd-transformed weights (forward / dgrad form) in the weight cache, -1: direct conv
+    int64_t wu4_off = -1;                // F(4x4,3x3) forward form (36 planes) for the no-grad forwards
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int64_t wcount() const { return (int64_t)cout * k * k * cin; }
 };
@@ -99,6 +100,7 @@ struct Builder {
             if (winograd_eligible(g)) {
                 p->wino_du_floats = std::max(p->wino_du_floats, 36 * c.wcount() / 9);   // dU of the F(4x4,3x3) weight gradient
                 c.wu_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
+                c.wu4_off = p->wu_total; p->wu_total += 36 * c.wcount() / 9;
                 p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(g));
             }
             if (winograd_eligible(gt)) {
@@ -256,13 +258,16 @@ ConvGeom geom(const ConvL& c, int B, int hin) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e) {
+// `nograd`: nothing will be differentiated through this forward (eval / train-no-grad modes): the Winograd layers may use F(4x4,3x3)
+int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e, bool nograd = false) {
     if (c.mc() && cv.wp_off >= 0) {
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* wsp[2];
         c.wplanes(cv, false, wsp);
         return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
     }
+    if (nograd && cv.wu4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
+        return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream);
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
         return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream);
     return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream);
@@ -275,7 +280,7 @@ int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
     e.y_bf16 = c.ybf(cv);
-    return conv_fwd(c, cv, x, y, g, e);
+    return conv_fwd(c, cv, x, y, g, e, mode != SIMQ_MODE_TRAIN);
 }
 
 // how the consumer of a BatchNorm output sees the layer (coefficients are computed in the consuming kernel)
@@ -318,7 +323,7 @@ int conv_bn_folded(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, f
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     e.scale = c.aux(bn, 0); e.shift = c.aux(bn, 1);
     e.addend = addend; e.relu = relu;
-    return conv_fwd(c, cv, x, out, g, e);
+    return conv_fwd(c, cv, x, out, g, e, true);
 }
 
 // the same for plain-bf16 plans: input, residual and output are bf16 planes (the fp32 accumulator is scaled / shifted / added / rectified
@@ -725,6 +730,7 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
         t.n = 0;
         (void)for_each_mc_conv(plan, [&](const ConvL& cv) {
             if (cv.wu_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu_off, cv.cout, cv.cin, 0, 0};
+            if (cv.wu4_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu4_off, cv.cout, cv.cin, 0, 1};
             if (cv.wut_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut_off, cv.cin, cv.cout, 1, 0};
             return 0;
         });
@@ -926,6 +932,22 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
+                              int cin, int cout, double* d_stats, float* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_x && d_w && d_y && d_scratch && batch >= 1, "conv2d_fwd_winograd4: bad argument");
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
+    SIMQ_REQUIRE(winograd_eligible(g) && hin % 4 == 0 && win % 4 == 0, "conv2d_fwd_winograd4: geometry not supported (map %% 4, cin %% 16, cout %% 64)");
+    ConvEpilogue e;
+    e.bias = d_bias; e.stats = d_stats;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WinoWeightTable t;
+    t.n = 1;
+    t.d[0] = WinoWeightDesc{0, 0, cout, cin, 0, 1};
+    RC(launch_wino_weight_all(d_w, nullptr, d_scratch, t, st));
+    return launch_conv_winograd4(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)36 * cout * cin, st);
 }
 
 int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,

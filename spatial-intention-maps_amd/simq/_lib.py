@@ -95,6 +95,7 @@ _SIGS = {
     'simq_tune_winograd': (c_int, [c_int]),
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_comm_unique_id': (c_int, [c_void_p]),
     'simq_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     'simq_comm_world_size': (c_int, [c_void_p]),
