@@ -30,6 +30,9 @@ TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
 # data-parallel emulation (SURVEY 8e / fixture G7): (name, cin, cout, global batch, shards, weight seed, data seed)
 DP_CASES = [('dp_c5o2_b8_w1', 5, 2, 8, 1, 37, 50), ('dp_c5o2_b8_w2', 5, 2, 8, 2, 37, 50), ('dp_c5o2_b8_w4', 5, 2, 8, 4, 37, 50),
             ('dp_c5o2_b8_w8', 5, 2, 8, 8, 37, 50), ('dp_c5o1_b8_w2', 5, 1, 8, 2, 38, 48)]
+# gradient-parity study (err_build <= k * err_reference-fp32): many seeded batches, judged as a distribution
+GRAD_STUDY_CASES = [('gs_b8_%02d' % i, (4, 5)[i % 2], (2, 1)[(i // 2) % 2], 8, 200 + i, 300 + i) for i in range(10)] + \
+                   [('gs_b32_%02d' % i, (4, 5, 4)[i], (2, 2, 1)[i], 32, 250 + i, 350 + i) for i in range(3)]
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 

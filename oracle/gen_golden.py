@@ -225,6 +225,60 @@ def gen_dp():
               'all-terminal shards: %d; per-shard-BN vs single replica: %.3g' % (relerr, empty_shards, float((t64 - one).norm() / one.norm())))
 
 
+def gen_grad_study():
+    """Gradient-parity study: fp32 gradients of these small train-mode-BN batches are only 1e-4 .. 1e-2
+    accurate -- for the reference as much as for any other fp32 implementation -- and WHICH implementation is luckier changes from
+    batch to batch.  So the bar is a distribution: 10 seeded B=8 and 3 seeded B=32 batches; per case the reference's own fp32
+    train.train (imported, two consecutive calls) and the fp64 oracle.  Stored per case: the fp64 gradient / parameter-update
+    summaries (16 sampled elements per tensor) and the REFERENCE-fp32 error on exactly those samples -- the yardstick the GPU test
+    (tests/test_gpu_fcn.py::test_gradient_parity_distribution) holds the HIP path to (median <= 2 x, no case > 10 x)."""
+    out = {'names': np.array([c[0] for c in cases.GRAD_STUDY_CASES])}
+    for name, cin, cout, B, wseed, dseed in cases.GRAD_STUDY_CASES:
+        cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
+        gkeys = learner.grad_keys(spec)
+        # the reference itself, fp32, two steps
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+        p0 = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+        info_ref = [ref_train.train(cfg, policy, target, opt, batch, learner.apply_transform, cases.GAMMA)]
+        p1_ref = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+        info_ref.append(ref_train.train(cfg, policy, target, opt, batch, learner.apply_transform, cases.GAMMA))
+        # the oracle fp32 (bit-exact with the reference: gives access to the pre-clip gradient) and fp64
+        st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        ex32 = {}
+        i32 = learner.train_step(cfg, st, tg, spec, [None] * len(gkeys), batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, extras=ex32)
+        assert i32 == info_ref[0], (name, i32, info_ref[0])
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        mom64, ex64 = [None] * len(gkeys), {}
+        i64 = [learner.train_step(cfg, st64, tg64, spec, mom64, batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                  dtype=torch.float64, extras=ex64)]
+        p1_64 = {k: st64[k].detach().clone() for k in gkeys}
+        i64.append(learner.train_step(cfg, st64, tg64, spec, mom64, batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                      dtype=torch.float64))
+        g64s, g32s, d64s, d32s = [], [], [], []
+        for k in gkeys:
+            idx = torch.tensor(cases.sample_indices(ex64['grads'][k].numel()))
+            g64s.append(ex64['grads'][k].reshape(-1)[idx].numpy())
+            g32s.append(ex32['grads'][k].double().reshape(-1)[idx].numpy())
+            d64s.append((p1_64[k] - p0[k].double()).reshape(-1)[idx].numpy())
+            d32s.append((p1_ref[k].double() - p0[k].double()).reshape(-1)[idx].numpy())
+        g64s, g32s, d64s, d32s = (np.stack(a) for a in (g64s, g32s, d64s, d32s))
+        rl2 = lambda a, b: float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+        out[name + '.grad64'] = g64s
+        out[name + '.dparam64'] = d64s
+        out[name + '.total_norm64'] = np.array(ex64['total_norm'])
+        out[name + '.loss64'] = np.array([i['loss'] for i in i64])
+        out[name + '.td64'] = np.array([i['td_error'] for i in i64])
+        out[name + '.ref_grad_err'] = np.array(rl2(g32s, g64s))
+        out[name + '.ref_dparam_err'] = np.array(rl2(d32s, d64s))
+        out[name + '.ref_loss_err'] = np.array([abs(info_ref[j]['loss'] - i64[j]['loss']) / abs(i64[j]['loss']) for j in range(2)])
+        print('grad study %-10s ref fp32 vs fp64: sampled grad rel-L2 %.3g, sampled update rel-L2 %.3g, loss err %.2g / %.2g (step 1 / 2)'
+              % (name, out[name + '.ref_grad_err'], out[name + '.ref_dparam_err'], out[name + '.ref_loss_err'][0], out[name + '.ref_loss_err'][1]), flush=True)
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, 'grad_study.npz'), **out)
+
+
 def gen_bf16_calibration():
     """Fixture G8: how far the REFERENCE moves when its own modules run in bf16 -- torch.autocast('cpu', bfloat16) over
     the imported networks.FCN / train.train arithmetic (bf16 convolution operands and outputs, fp32 BatchNorm statistics and
@@ -408,6 +462,7 @@ if __name__ == '__main__':
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
             'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
-            'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration}
+            'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration,
+            'grad_study': gen_grad_study}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

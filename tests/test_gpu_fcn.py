@@ -508,6 +508,63 @@ def test_onehot_backward_equals_dense_backward(simq_mod, cout):
     assert num < 1e-4, num
 
 
+def test_gradient_parity_distribution(simq_mod, golden_dir):
+    """SURVEY section 0's criterion for gradients, err_build <= k * err_reference-fp32, judged as a DISTRIBUTION (fixture
+    tests/golden/grad_study.npz, written by oracle/gen_golden.py from the imported reference: 10 seeded B=8 and 3 seeded B=32 batches,
+    each with the fp64 oracle's gradient / first-update / second-step-loss and the error the REFERENCE's own fp32 train.train makes on
+    the same 16 sampled elements per tensor).  fp32 gradients of these batches are 1e-4 .. 1e-2 accurate for any implementation and
+    which one is luckier changes per batch, so: median HIP error <= 2 x median reference error, no case beyond 10 x the reference's
+    error on that case (or its median), for the pre-clip gradient and for the first parameter update (sampled elements, not
+    tensor norms); the second step's loss (which sees the first update) is held to the amplification the reference itself shows.
+    Measured (MI355X): medians 1.6e-3 (HIP) vs 2.0e-3 (reference fp32) for both gradient and update."""
+    from oracle import learner as olearner
+    g = np.load('%s/grad_study.npz' % golden_dir)
+    rows = []
+    for name, cin, cout, B, wseed, dseed in cases.GRAD_STUDY_CASES:
+        cfg, batch = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed)
+        policy, target = make_net(simq_mod, cin, cout, wseed, True), make_net(simq_mod, cin, cout, wseed + 1000, False)
+        opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+        p0 = [v.detach().clone().cpu().double() for v in policy.reference_views(policy.flat_params)]
+        info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+        tn = float(policy._simq_opt_state.total_norm.item())
+        coef = min(1.0, cases.CLIP / (tn + 1e-6))
+        grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
+        p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
+        info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+        gs, ds = [], []
+        for t, a, b in zip(grads, p0, p1):
+            idx = torch.tensor(cases.sample_indices(t.numel()))
+            gs.append(t.reshape(-1)[idx].numpy())
+            ds.append((b - a).reshape(-1)[idx].numpy())
+        rl2 = lambda a, b: float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+        rows.append(dict(name=name, grad=rl2(np.stack(gs), g[name + '.grad64']), ref_grad=float(g[name + '.ref_grad_err']),
+                         dparam=rl2(np.stack(ds), g[name + '.dparam64']), ref_dparam=float(g[name + '.ref_dparam_err']),
+                         loss1=abs(info1['loss'] - float(g[name + '.loss64'][0])) / float(g[name + '.loss64'][0]),
+                         loss2=abs(info2['loss'] - float(g[name + '.loss64'][1])) / float(g[name + '.loss64'][1]),
+                         ref_loss2=float(g[name + '.ref_loss_err'][1]),
+                         norm=abs(tn - float(g[name + '.total_norm64'])) / float(g[name + '.total_norm64'])))
+        del policy, target, opt
+    print()
+    for r in rows:
+        print('%-10s grad %.3g (ref %.3g)  update %.3g (ref %.3g)  loss step 1 %.2g  step 2 %.3g (ref %.3g)  |g| %.2g'
+              % (r['name'], r['grad'], r['ref_grad'], r['dparam'], r['ref_dparam'], r['loss1'], r['loss2'], r['ref_loss2'], r['norm']))
+    med = lambda k: float(np.median([r[k] for r in rows]))
+    print('medians: grad %.3g (ref %.3g)  update %.3g (ref %.3g)  loss step 2 %.3g (ref %.3g)'
+          % (med('grad'), med('ref_grad'), med('dparam'), med('ref_dparam'), med('loss2'), med('ref_loss2')))
+    assert all(r['loss1'] < 1e-4 for r in rows)                                    # the forward / Huber side: the 1e-4 bar
+    for k, rk in (('grad', 'ref_grad'), ('dparam', 'ref_dparam')):
+        assert med(k) <= 2.0 * med(rk), (k, med(k), med(rk))
+        for r in rows:
+            assert r[k] <= 10.0 * max(r[rk], med(rk)), (k, r)
+    # The second step's loss is the first update's error seen through the network once more: in the fixture the reference's own
+    # fp32 second-step loss is off by up to 15 x its update error (0.10 on gs_b8_03), with a heavy tail (13 samples: 2e-5 .. 1e-1).
+    # Held to: that amplification (x 2), and a median within 4 x the reference's median.
+    amp_ref = max(float(g[n + '.ref_loss_err'][1]) / float(g[n + '.ref_dparam_err']) for n, *_ in cases.GRAD_STUDY_CASES)
+    assert med('loss2') <= 4.0 * med('ref_loss2'), (med('loss2'), med('ref_loss2'))
+    for r in rows:
+        assert r['loss2'] <= 2.0 * amp_ref * r['dparam'] + 1e-4, (r, amp_ref)
+
+
 def test_optimizer_state_is_interchangeable_with_the_reference_layout(simq_mod, tmp_path):
     """train.py:204 / :331 -- optimizer.load_state_dict / optimizer.state_dict() in a checkpoint.  The reference's momentum buffers
     are OIHW tensors; simq stores OHWI and presents every parameter / gradient / momentum buffer to torch under the reference's
