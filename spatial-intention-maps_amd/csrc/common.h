@@ -83,6 +83,7 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
                          hipStream_t stream);
 // F(4x4,3x3) form for forwards nothing is differentiated through (U4: 36 planes [Cout][Cin])
 bool winograd_f4_forward(const ConvGeom& g);
+int winograd_f4_grad();
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                           hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);

@@ -35,7 +35,7 @@ struct ConvL {
     int64_t wt_off = -1;              // into the transposed-weight scratch (dgrad), -1: no dgrad
     int64_t wp_off = -1;              // into the bf16 weight-plane scratch (matrix-core precisions), -1: stays fp32
     int64_t wu_off = -1, wut_off = -1;   // Winograd-transformed weights (forward / dgrad form) in the weight cache, -1: direct conv
-    int64_t wu4_off = -1;                // F(4x4,3x3) forward form (36 planes) for the no-grad forwards
+    int64_t wu4_off = -1, wut4_off = -1; // F(4x4,3x3) forms (36 planes): forward (no-grad forwards) / dgrad (SIMQ_WINOGRAD_F4_GRAD)
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int64_t wcount() const { return (int64_t)cout * k * k * cin; }
 };
@@ -105,6 +105,7 @@ struct Builder {
             }
             if (winograd_eligible(gt)) {
                 c.wut_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
+                if (winograd_f4_grad()) { c.wut4_off = p->wu_total; p->wu_total += 36 * c.wcount() / 9; }
                 p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(gt));
             }
         }
@@ -266,7 +267,7 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
         c.wplanes(cv, false, wsp);
         return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
     }
-    if (nograd && cv.wu4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
+    if ((nograd || winograd_f4_grad() == 1) && cv.wu4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
         return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream);
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
         return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream);
@@ -480,6 +481,8 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
         c.wplanes(cv, true, wsp);
         return launch_conv_igemm_bf16(ds, wsp, c.p->np(), dx, g, e, c.stream);
     }
+    if (cv.wut4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
+        return launch_conv_winograd4(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wut4_off, dx, g, e, c.f(c.L.wino), c.stream);
     if (cv.wut_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
         return launch_conv_winograd(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wut_off, dx, g, e, c.f(c.L.wino), c.stream);
     return launch_conv_igemm(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wt) + cv.wt_off, dx, g, e, c.stream);
@@ -732,6 +735,7 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
             if (cv.wu_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu_off, cv.cout, cv.cin, 0, 0};
             if (cv.wu4_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu4_off, cv.cout, cv.cin, 0, 1};
             if (cv.wut_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut_off, cv.cin, cv.cout, 1, 0};
+            if (cv.wut4_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut4_off, cv.cin, cv.cout, 1, 1};
             return 0;
         });
         return launch_wino_weight_all(d_params, reinterpret_cast<const float*>(wc + W.wt), reinterpret_cast<float*>(wc + W.wu), t,
