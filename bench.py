@@ -101,7 +101,7 @@ PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summary, kernel whose 
     'fp32': ('r02_pmc_traffic.json', 'igemm_conv_kernel<64, 64, true, true>'),
     'bf16': ('r02_pmc_traffic_bf16_b128.json', None),          # None: the kernel named by DOMINANT_BF16 below
 }
-DOMINANT_BF16 = 'igemm_bf16_pp_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
+DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
 
 
 def pmc_traffic(precision):
@@ -278,12 +278,13 @@ def main():
     value, dt, dt_m1, info, step, barrier, B, gB = (w[k] for k in ('value', 'dt', 'dt_m1', 'info', 'step', 'barrier', 'B', 'gB'))
 
     KERNEL_NAMES = {
-        'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd F(2x2,3x3) layers: forward + dgrad of the '
-                '256- and 512-channel 3x3 convolutions, 16 GEMMs per launch, v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
+        'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd layers -- 128->256, 256- and 512-channel 3x3 '
+                'convolutions: 16 GEMMs per launch for the grad-mode forward in F(2x2,3x3), 36 for the no-grad forwards, dgrads and weight '
+                'gradients in F(4x4,3x3); v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
         'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
                   'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
-        'bf16': 'large-tile LDS-DMA bf16 implicit GEMM (igemm_bf16_pp_kernel / igemm_bf16_dma_kernel, v_mfma_f32_16x16x32_bf16): forward + dgrad of '
-                'the 128..512-channel 3x3 convolutions'}
+        'bf16': 'igemm_bf16_img_kernel (image-tile 3x3 convolution: one 24x24 map x 128 channels per block, halo patch in LDS, ping-pong wave '
+                'groups, v_mfma_f32_16x16x32_bf16) + igemm_bf16_dma_kernel: forward + dgrad of the 128..512-channel 3x3 convolutions'}
 
     def roofline_pass(step_fn, barrier_fn, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
@@ -318,7 +319,7 @@ def main():
             'launches_per_step': ig['launches'] / steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
             'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
             'kernel_ms_per_step': round(ig['ms'] / steps, 4),
-            'direct_conv_equivalent_tflops': round(2.25 * tf(ig), 2) if (precision == 'fp32' and dom['launches'] > 0) else None,
+            
             # flat copies of the secondary figures (nested objects do not survive the driver's summary of the line)
             'all_gemm_tiles_launches_per_step': allg['launches'] / steps, 'all_gemm_tiles_ms_per_step': round(allg['ms'] / steps, 4),
             'all_gemm_tiles_achieved': round(tf(allg), 2), 'all_gemm_tiles_frac': round(tf(allg) / PEAK, 4),

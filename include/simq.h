@@ -124,6 +124,29 @@ int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params
                          const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads, void* d_workspace, int phase,
                          void* stream);
 
+/* ---- optional cross-rank BatchNorm statistics ("SyncBN") ----------------------------------------------------------
+ * The reference's multi-GPU form (nn.DataParallel, policies.py:39) normalises every replica with ITS OWN batch statistics, and that is
+ * what the data-parallel step does by default.  With a simq_sync the train-mode BatchNorms of simq_forward_sync / simq_backward_sync
+ * use the statistics of the GLOBAL minibatch instead, which makes an N-rank step arithmetically the single-device step on the whole
+ * minibatch: after every convolution the [sum | sum of squares] of its BatchNorm (2*C doubles), and in the backward walk every
+ * [sum dz | sum dz*xhat], are handed to `reduce` (sum over ranks, in place, ordered on `stream`) before they are consumed -- 44 small
+ * latency-bound reductions per step.  global_batch = transitions over all ranks (row counts scale by global_batch / batch);
+ * d gamma / d beta are written as 1/world_size of the global sums, so that the flat-gradient all-reduce restores them.
+ * simq_comm_reduce_f64 is a ready-made `reduce` over a simq_comm (user = the communicator). */
+typedef int (*simq_reduce_fn)(void* user, double* d_buf, int64_t count, void* stream);
+typedef struct simq_sync { simq_reduce_fn reduce; void* user; int global_batch; int world_size; } simq_sync;
+int simq_forward_sync(const simq_plan* plan, int mode, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf,
+                      const float* d_x, float* d_q, void* d_workspace, void* stream, const simq_sync* sync);
+/* d_dq != NULL: dense upstream gradient (simq_backward_phase); d_dq == NULL: the one-hot form (simq_backward_onehot) */
+int simq_backward_sync(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                       const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
+                       void* d_workspace, int phase, void* stream, const simq_sync* sync);
+int simq_comm_reduce_f64(void* comm, double* d_buf, int64_t count, void* stream);
+/* A rank whose shard holds no input for a synchronised train-mode forward (the double-DQN forward over the non-final next states of
+ * an all-terminal shard) still has to take part in that forward's reductions: contributes zeros, in the forward's order.
+ * d_workspace: any workspace of this plan sized for `layout_batch` >= 1. */
+int simq_forward_sync_null(const simq_plan* plan, int layout_batch, void* d_workspace, void* stream, const simq_sync* sync);
+
 /* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */
 /* flat max / first-index argmax over each row of d_q [rows][n]  (train.py:121,124; policies.py:64) */
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream);
@@ -164,7 +187,8 @@ int simq_replay_gather(const float* d_ring, int64_t item_floats, const int64_t* 
  * dq may be NULL: the backward then starts from the one-hot form (simq_backward_onehot) and no dense dQ map is written. */
 typedef struct simq_train_args {
     const simq_plan* plan;
-    int batch, num_nonfinal, global_batch, use_double_dqn, first_step, reserved_;
+    int batch, num_nonfinal, global_batch, use_double_dqn, first_step;
+    int sync_bn;                 /* with `comm`: global-minibatch BatchNorm statistics (simq_sync over the communicator) */
     float gamma, lr, momentum, weight_decay, max_norm, reserved2_;
     float* params; void* wcache; float* bnbuf; float* grads; float* momentum_buf; void* ws_train; void* ws_tmp;   /* policy */
     const float* t_params; const void* t_wcache; float* t_bnbuf; void* t_ws;                                      /* target */
@@ -173,6 +197,8 @@ typedef struct simq_train_args {
     float* nsv; float* vals; int64_t* best; float* q_sa; float* y; float* td; float* out4;
     void* opt_scratch; float* total_norm;
     void* stream; void* side_stream;
+    int global_nonfinal;         /* sync_bn: non-final next states over all ranks (the double-DQN forward's global row count) */
+    int reserved3_;
     struct simq_comm* comm;      /* NULL: single process.  Otherwise the data-parallel form: `batch` is this rank's shard of a
                                   * minibatch of `global_batch` transitions; head + layer4 gradients (simq_grad_bucket_split) are
                                   * summed over the ranks while layers 3..1 + stem are still being differentiated, then the rest

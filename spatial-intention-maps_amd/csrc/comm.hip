@@ -86,6 +86,8 @@ struct simq_comm {
 namespace simq {
 
 // used by simq_train_step (plan.hip)
+int comm_wait(simq_comm* c, hipStream_t consumer);
+
 int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_t producer) {
     SIMQ_REQUIRE(c && buf && count > 0, "comm_allreduce: bad argument");
     SIMQ_REQUIRE(dtype == SIMQ_COMM_F32 || dtype == SIMQ_COMM_F64, "comm_allreduce: dtype %d (SIMQ_COMM_F32 | SIMQ_COMM_F64)", dtype);
@@ -96,6 +98,13 @@ int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_
     SIMQ_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == SIMQ_COMM_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->comm,
                                      c->stream));
     return 0;
+}
+
+int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream) {
+    simq_comm* c = static_cast<simq_comm*>(comm);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = comm_allreduce(c, buf, count, SIMQ_COMM_F64, st)) return rc;
+    return comm_wait(c, st);
 }
 
 int comm_wait(simq_comm* c, hipStream_t consumer) {
@@ -155,6 +164,8 @@ int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, v
     SIMQ_CHECK_RCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclInt8, root, comm->comm, comm->stream));
     return 0;
 }
+
+int simq_comm_reduce_f64(void* comm, double* d_buf, int64_t count, void* stream) { return simq::comm_reduce_f64(comm, d_buf, count, stream); }
 
 int simq_comm_wait(simq_comm* comm, void* consumer_stream) {
     return simq::comm_wait(comm, static_cast<hipStream_t>(consumer_stream));

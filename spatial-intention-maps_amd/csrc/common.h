@@ -150,7 +150,7 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
                         float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes(),
-                        const uint16_t* mask16 = nullptr, int y_bf16 = 0);
+                        const uint16_t* mask16 = nullptr, int y_bf16 = 0, double global_rows = 0.0, float dparam_scale = 1.f);
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);
@@ -186,6 +186,7 @@ int launch_replay_gather(const float* ring, int64_t item_floats, const int64_t* 
 
 // comm.hip: RCCL all-reduce on the communicator's own stream, ordered behind `producer` / awaited by `consumer`
 int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_t producer);
+int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream);   // simq_reduce_fn over a communicator
 int comm_wait(simq_comm* c, hipStream_t consumer);
 
 }  // namespace simq

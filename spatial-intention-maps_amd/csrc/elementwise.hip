@@ -275,15 +275,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
                                     float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4,
-                                    int y_bf16) {
+                                    int y_bf16, float inv_rows, float dparam_scale) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            dbeta[c] = (float)red[c];
-            dgamma[c] = (float)red[C + c];
+            dbeta[c] = (float)red[c] * dparam_scale;
+            dgamma[c] = (float)red[C + c] * dparam_scale;
         }
     }
-    const float inv_rows = (float)(1.0 / (double)rows);
     size_t total4 = rows * C4;
     // the grid stride is a multiple of C4 (256 % C4 == 0): a thread keeps its 4 channels
     const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) % C4) * 4;
@@ -478,12 +477,14 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
-                        int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16, int y_bf16) {
+                        int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16, int y_bf16, double global_rows,
+                        float dparam_scale) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
-                       gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16);
+                       gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16,
+                       (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

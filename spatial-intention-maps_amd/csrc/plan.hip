@@ -217,6 +217,10 @@ struct Ctx {
     hipStream_t stream;
     char* wc = nullptr;      // weight cache
     WLayout W = WLayout();
+    const simq_sync* sync = nullptr;   // cross-rank BatchNorm statistics (simq_forward_sync / simq_backward_sync)
+    // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
+    double bn_rows(int64_t rows) const { return sync ? (double)rows / (double)B * (double)sync->global_batch : (double)rows; }
+    int sync_reduce(double* buf, int64_t count) const { return sync ? sync->reduce(sync->user, buf, count, stream) : 0; }
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
     float* aux(const BnL& b, int which) const { return f(L.aux) + b.aux_off + (int64_t)which * b.C; }   // 0 scale 1 shift 2 mean 3 invstd
     double* red(const BnL& b) const { return reinterpret_cast<double*>(ws + L.red) + b.red_off; }
@@ -281,7 +285,9 @@ int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
     e.y_bf16 = c.ybf(cv);
-    return conv_fwd(c, cv, x, y, g, e, mode != SIMQ_MODE_TRAIN);
+    RC(conv_fwd(c, cv, x, y, g, e, mode != SIMQ_MODE_TRAIN));
+    if (mode != SIMQ_MODE_EVAL) RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));     // SyncBN: [sum | sum of squares] over all ranks
+    return 0;
 }
 
 // how the consumer of a BatchNorm output sees the layer (coefficients are computed in the consuming kernel)
@@ -291,7 +297,7 @@ BnRef bnref(const Ctx& c, const BnL& bn, int mode, int64_t rows) {
     r.gamma = c.params + bn.g_off; r.beta = c.params + bn.b_off;
     r.rmean = c.bnbuf + bn.buf_off; r.rvar = c.bnbuf + bn.buf_off + bn.C;
     r.save_mean = c.aux(bn, 2); r.save_invstd = c.aux(bn, 3);
-    r.rows = (double)rows; r.inv_rows = 1.0 / (double)rows; r.C = bn.C;
+    r.rows = c.bn_rows(rows); r.inv_rows = 1.0 / r.rows; r.C = bn.C;
     return r;
 }
 
@@ -450,8 +456,10 @@ int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const
            bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1) {
     if (y_bf16 < 0) y_bf16 = c.ybf();
     if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16));
+    RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));                                   // SyncBN: [sum dz | sum dz*xhat] over all ranks
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
-                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16);
+                               c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16,
+                               c.sync ? c.bn_rows(rows) : 0.0, c.sync ? 1.f / (float)c.sync->world_size : 1.f);
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
@@ -756,6 +764,56 @@ int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_para
     return forward_impl(c, mode, d_x, d_q);
 }
 
+static int check_sync(const simq_sync* sync, int batch) {
+    SIMQ_REQUIRE(!sync || (sync->reduce && sync->global_batch >= batch && sync->world_size >= 1), "simq_sync: reduce is NULL or global_batch < batch");
+    return 0;
+}
+
+int simq_forward_sync(const simq_plan* plan, int mode, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf,
+                      const float* d_x, float* d_q, void* d_workspace, void* stream, const simq_sync* sync) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_bnbuf && d_x && d_q && d_workspace, "forward: NULL argument");
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "forward: batch=%d out of range", batch);
+    SIMQ_REQUIRE(mode >= 0 && mode <= 2, "forward: bad mode %d", mode);
+    RC(check_sync(sync, batch));
+    Ctx c{plan, batch, d_params, nullptr, d_bnbuf, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    c.sync = sync;
+    return forward_impl(c, mode, d_x, d_q);
+}
+
+int simq_forward_sync_null(const simq_plan* plan, int layout_batch, void* d_workspace, void* stream, const simq_sync* sync) {
+    SIMQ_REQUIRE(plan && d_workspace && sync && sync->reduce && layout_batch >= 1, "forward_sync_null: bad argument");
+    Ctx c{plan, layout_batch, nullptr, nullptr, nullptr, static_cast<char*>(d_workspace), make_layout(plan, layout_batch), static_cast<hipStream_t>(stream)};
+    c.sync = sync;
+    SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + c.L.red, 0, plan->red_total * sizeof(double), c.stream));
+    // the order in which forward_impl's convolutions hand their statistics over: stem; per block conv1, conv2, downsample; head
+    RC(c.sync_reduce(c.red(plan->stem_bn), 2 * (int64_t)plan->stem_bn.C));
+    for (int i = 0; i < 8; ++i) {
+        const BlockL& b = plan->blocks[i];
+        RC(c.sync_reduce(c.red(b.b1), 2 * (int64_t)b.b1.C));
+        RC(c.sync_reduce(c.red(b.b2), 2 * (int64_t)b.b2.C));
+        if (b.has_ds) RC(c.sync_reduce(c.red(b.bds), 2 * (int64_t)b.bds.C));
+    }
+    RC(c.sync_reduce(c.red(plan->hb1), 2 * (int64_t)plan->hb1.C));
+    RC(c.sync_reduce(c.red(plan->hb2), 2 * (int64_t)plan->hb2.C));
+    return 0;
+}
+
+int simq_backward_sync(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                       const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
+                       void* d_workspace, int phase, void* stream, const simq_sync* sync) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_grads && d_workspace && (d_dq || (d_action && d_q_sa && d_y)), "backward_sync: NULL argument");
+    SIMQ_REQUIRE(phase >= 0 && phase <= 2, "backward: bad phase %d", phase);
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
+    RC(check_sync(sync, batch));
+    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    c.sync = sync;
+    if (d_dq) return backward_impl(c, d_dq, phase);
+    const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
+    return backward_impl(c, nullptr, phase, &oh);
+}
+
 int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                         float* d_grads, void* d_workspace, int phase, void* stream) {
     SIMQ_REQUIRE(plan && d_params && d_wcache && d_dq && d_grads && d_workspace, "backward: NULL argument");
@@ -790,6 +848,7 @@ int simq_train_step(const simq_train_args* a) {
                  a->q && a->q_tgt && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
                  "train_step: NULL buffer");
     SIMQ_REQUIRE(!a->use_double_dqn || a->num_nonfinal == 0 || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
+    SIMQ_REQUIRE(!(a->comm && a->sync_bn) || a->global_nonfinal >= a->num_nonfinal, "train_step: sync_bn needs global_nonfinal (>= num_nonfinal)");
     // single process: the reference itself fails on a minibatch without any non-final next state (torch.cat([]) at train.py:112);
     // a data-parallel SHARD may have none and still has to join the collectives
     SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= (a->comm ? 0 : 1) && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
@@ -810,7 +869,10 @@ int simq_train_step(const simq_train_args* a) {
         }
         ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1];
     }
-    RC(simq_forward(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main));          // train.py:114
+    // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
+    simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
+    const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
+    RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
     // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read.  It is
     // forked BEHIND the policy's train-mode forward so that it overlaps the policy's next-state forward: both run on the
     // ~29 non-final samples, whose tiles do not fill whole rounds of the CUs, and fill each other's tails (+1.7 % on the step
@@ -823,7 +885,11 @@ int simq_train_step(const simq_train_args* a) {
     RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side ? side : main));
     if (side) SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
     if (a->use_double_dqn) {                                                                                          // train.py:119-122
-        RC(simq_forward(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, main));
+        // (under SyncBN this forward normalises over the non-final next states of ALL ranks)
+        simq_sync sync_nf = sync_storage;
+        sync_nf.global_batch = a->global_nonfinal;
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, main,
+                             sync ? &sync_nf : nullptr));
         RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, main));
         if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
         RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
@@ -832,13 +898,17 @@ int simq_train_step(const simq_train_args* a) {
         RC(launch_q_argmax(a->q_tgt, Nn, n, nullptr, a->vals, main));
     }
     }
+    if (Nn == 0 && sync && a->use_double_dqn && a->global_nonfinal > 0) {     // all-terminal shard: zeros into the other ranks' reductions
+        simq_sync sync_nf = sync_storage;
+        sync_nf.global_batch = a->global_nonfinal;
+        RC(simq_forward_sync_null(p, 1, a->ws_tmp, main, &sync_nf));
+    }
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
-        return a->dq ? simq_backward_phase(p, B, a->params, a->wcache, a->dq, a->grads, a->ws_train, phase, main)
-                     : simq_backward_onehot(p, B, a->params, a->wcache, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main);
+        return simq_backward_sync(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync);
     };
     if (!a->comm) {
         RC(backward(0));

@@ -31,18 +31,26 @@ if not os.path.exists(LIB_PATH):
 
 _c = ctypes.CDLL(LIB_PATH)
 
+REDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)     # simq_reduce_fn
+
+
+class SyncArgs(ctypes.Structure):
+    """simq_sync of include/simq.h (cross-rank BatchNorm statistics)."""
+    _fields_ = [('reduce', REDUCE_FN), ('user', c_void_p), ('global_batch', c_int), ('world_size', c_int)]
+
+
 class TrainArgs(ctypes.Structure):
     """simq_train_args of include/simq.h (the whole TD step in one library call)."""
     _fields_ = [('plan', c_void_p),
                 ('batch', c_int), ('num_nonfinal', c_int), ('global_batch', c_int), ('use_double_dqn', c_int), ('first_step', c_int),
-                ('reserved_', c_int),
+                ('sync_bn', c_int),
                 ('gamma', c_float), ('lr', c_float), ('momentum', c_float), ('weight_decay', c_float), ('max_norm', c_float),
                 ('reserved2_', c_float)] + [(n, c_void_p) for n in (
                     'params', 'wcache', 'bnbuf', 'grads', 'momentum_buf', 'ws_train', 'ws_tmp',
                     't_params', 't_wcache', 't_bnbuf', 't_ws',
                     'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
                     'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
-                    'opt_scratch', 'total_norm', 'stream', 'side_stream', 'comm')]
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('reserved3_', c_int), ('comm', c_void_p)]
 
 
 _SIGS = {
@@ -96,6 +104,11 @@ _SIGS = {
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_forward_sync': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'simq_backward_sync': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p]),
+    'simq_comm_reduce_f64': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'simq_forward_sync_null': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_comm_unique_id': (c_int, [c_void_p]),
     'simq_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     'simq_comm_world_size': (c_int, [c_void_p]),

@@ -69,6 +69,43 @@ def max_over_ranks(value, device, group=None):
     return float(t.item())
 
 
+class SyncBN:
+    """The SyncBN option (include/simq.h simq_sync): train-mode BatchNorm over the GLOBAL minibatch instead of the
+    per-replica statistics of nn.DataParallel.  Wraps the reduction the library calls back for every BatchNorm's partial sums:
+    over torch.distributed (`group`: "nccl" == RCCL, or gloo) or over libsimq's own communicator (`comm`), whose native
+    simq_comm_reduce_f64 then runs without entering Python."""
+
+    def __init__(self, global_batch, group=None, comm=None):
+        from . import _lib
+        self.world = comm.world if comm is not None else dist.get_world_size(group)
+        self.global_batch = int(global_batch)
+        self._group, self._comm, self._ws = group, comm, None
+        self.args = _lib.SyncArgs()
+        if comm is not None:
+            fn = ctypes.cast(_lib._c.simq_comm_reduce_f64, _lib.REDUCE_FN)
+            self.args.reduce, self.args.user = fn, comm.handle
+        else:
+            self._cb = _lib.REDUCE_FN(self._reduce)          # keep the callback object alive
+            self.args.reduce, self.args.user = self._cb, None
+        self.args.global_batch, self.args.world_size = self.global_batch, self.world
+
+    def bind(self, workspace):
+        """The partial sums live inside `workspace` (a torch uint8 tensor): the callback needs it to wrap the raw pointer."""
+        self._ws = workspace
+        return ctypes.byref(self.args)
+
+    def _reduce(self, user, d_buf, count, stream):
+        try:
+            off = int(d_buf) - self._ws.data_ptr()
+            t = self._ws[off:off + 8 * int(count)].view(torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group)
+            return 0
+        except Exception:                                    # noqa: BLE001  (an exception must not cross the C boundary)
+            import traceback
+            traceback.print_exc()
+            return -5
+
+
 class Comm:
     """libsimq's RCCL communicator (simq_comm_*, include/simq.h) for the ranks of a torch.distributed process group.
 

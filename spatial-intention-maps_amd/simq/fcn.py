@@ -231,8 +231,9 @@ class FCN(torch.nn.Module):
             self.weights_dirty = False
             self._weights_stamp += 1
 
-    def _forward_raw(self, x_nhwc, mode):
-        """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96]."""
+    def _forward_raw(self, x_nhwc, mode, sync=None):
+        """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96].  sync: a simq.dist.SyncBN (global-minibatch
+        BatchNorm statistics in the train modes)."""
         if x_nhwc.dtype != torch.float32 or not x_nhwc.is_contiguous() or x_nhwc.device != self.flat_params.device:
             raise SimqError('simq.FCN: input must be a contiguous fp32 tensor on %s' % self.device_)
         B = x_nhwc.shape[0]
@@ -246,8 +247,12 @@ class FCN(torch.nn.Module):
         ws = self._workspace('train' if mode == MODE_TRAIN else 'tmp', B)
         q = torch.empty((B, self.num_output_channels, W, W), dtype=torch.float32, device=self.device_)
         self._ensure_weights()
-        lib.call('simq_forward', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.wcache), ptr(self.bn_buffers), ptr(x_nhwc),
-                 ptr(q), ptr(ws), stream_ptr(self.device_))
+        if sync is not None:
+            lib.call('simq_forward_sync', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.wcache), ptr(self.bn_buffers),
+                     ptr(x_nhwc), ptr(q), ptr(ws), stream_ptr(self.device_), sync.bind(ws))
+        else:
+            lib.call('simq_forward', self.plan.handle, mode, B, ptr(self.flat_params), ptr(self.wcache), ptr(self.bn_buffers), ptr(x_nhwc),
+                     ptr(q), ptr(ws), stream_ptr(self.device_))
         if mode != MODE_EVAL:
             for k in self.num_batches_tracked:
                 self.num_batches_tracked[k] += 1
@@ -263,12 +268,16 @@ class FCN(torch.nn.Module):
                  ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
         return self.flat_grads
 
-    def _backward_onehot(self, action, q_sa, y, grad_scale, batch, phase=0):
+    def _backward_onehot(self, action, q_sa, y, grad_scale, batch, phase=0, sync=None):
         """Backward of the TD loss from its one-hot upstream gradient dQ[b][action[b]] = clamp(q_sa - y, -1, 1) * grad_scale
-        (no dense dQ map); same phases as _backward_raw."""
+        (no dense dQ map); same phases as _backward_raw.  sync: as in _forward_raw."""
         ws = self._ws.get('train')
         if ws is None:
             raise SimqError('simq.FCN: backward without a grad-mode forward')
+        if sync is not None:
+            lib.call('simq_backward_sync', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), None, ptr(action), ptr(q_sa),
+                     ptr(y), float(grad_scale), ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_), sync.bind(ws))
+            return self.flat_grads
         lib.call('simq_backward_onehot', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(action), ptr(q_sa),
                  ptr(y), float(grad_scale), ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
         return self.flat_grads

@@ -366,7 +366,7 @@ def _hyper(optimizer):
 
 def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, momentum, weight_decay,
                grad_norm_clipping, use_double_dqn=True, opt_state=None, process_group=None, global_batch=None,
-               sync=True, comm=None):
+               sync=True, comm=None, sync_bn=False, global_nonfinal=None):
     """One TD step (train.py:108-141) entirely on the device, over the nets' flat buffers.
 
     Data-parallel: pass `global_batch` and either `comm` (simq.dist.Comm: libsimq's RCCL communicator -- the step stays ONE
@@ -374,6 +374,10 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     collectives around the two backward phases); this rank's `batch` is its slice of the minibatch, BatchNorm uses per-rank
     statistics (the reference's DataParallel semantics, policies.py:39) and the flat gradient is summed over the ranks in two
     buckets before every rank applies the identical clip + SGD.
+    sync_bn=True (data-parallel only): the SyncBN option -- the grad-mode forward / backward normalise with the statistics of the
+    GLOBAL minibatch (44 small all-reduces per step), which makes the N-rank step the single-device step on the whole minibatch
+    instead of DataParallel's per-replica BatchNorm; `global_nonfinal` = number of non-final next states in the WHOLE minibatch
+    (every rank draws the same minibatch, so each knows it) sizes the double-DQN forward's global statistics.
     Returns {'td_error','loss'} floats (sync=True, as the reference's .item() calls do) or the
     device tensor [sum_huber, sum_td] (sync=False).
     """
@@ -382,6 +386,10 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
                         % (type(policy_net).__name__, type(target_net).__name__))
     dev = policy_net.device_
     parallel = process_group is not None or comm is not None
+    if sync_bn and not parallel:
+        raise SimqError('train_step: sync_bn needs a process group or a communicator (one process has nothing to synchronise)')
+    if sync_bn and global_nonfinal is None:
+        raise SimqError('train_step: sync_bn needs global_nonfinal (non-final next states of the whole minibatch)')
     b = assemble_batch(batch, dev, allow_all_final=parallel)
     B = b.state.shape[0]
     if b.next_state.shape[0] == 0 and not parallel:
@@ -399,11 +407,13 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
 
     if (process_group is None or comm is not None) and FUSED_LIBRARY_STEP:
         return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                                 use_double_dqn, st_opt, sync, comm)
+                                 use_double_dqn, st_opt, sync, comm, sync_bn, global_nonfinal)
+    bn_sync = sdist.SyncBN(gB, group=process_group, comm=comm) if sync_bn else None
+    bn_sync_nf = sdist.SyncBN(global_nonfinal, group=process_group, comm=comm) if (sync_bn and global_nonfinal) else None
     reduce_async = (lambda t: sdist.allreduce_async(t, process_group)) if comm is None else comm.all_reduce
 
     # train.py:114 -- policy forward, train-mode BN, activations kept for backward
-    q = policy_net._forward_raw(b.state, MODE_TRAIN)
+    q = policy_net._forward_raw(b.state, MODE_TRAIN, sync=bn_sync)
     # The target-net forward (eval mode, its own parameters / workspace) depends on nothing the policy net computes: it runs
     # on a side stream, forked behind the train-mode forward so that it overlaps the policy's next-state forward (both work
     # on the ~29 non-final samples and fill each other's partially filled rounds of CUs).
@@ -418,10 +428,12 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
             q_tgt = target_net._forward_raw(b.next_state, MODE_EVAL)          # train.py:122/124 (target in eval mode)
     # train.py:116-124 -- bootstrap values of the non-final next states
     if Nn == 0:
-        pass
+        if use_double_dqn and bn_sync_nf is not None:       # all-terminal shard under SyncBN: zeros into the others' reductions
+            ws0 = policy_net._workspace('tmp', 1)
+            lib.call('simq_forward_sync_null', policy_net.plan.handle, 1, ptr(ws0), st, bn_sync_nf.bind(ws0))
     elif use_double_dqn:
         # train.py:121: the POLICY net, still in train mode (batch statistics, 2nd running-stat update)
-        q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD)
+        q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD, sync=bn_sync_nf)
         best = torch.empty(Nn, dtype=torch.int64, device=dev)
         lib.call('simq_q_argmax', ptr(q_next), Nn, n, ptr(best), None, st)
         main.wait_stream(side)
@@ -447,9 +459,9 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
         # data parallel: the all-reduce of the head + layer4 gradients (75 % of the 45 MB) is issued as soon as they are
         # final and runs on RCCL's stream while layers 3..1 + stem are still being differentiated
         split = policy_net.grad_bucket_split
-        grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=1)
+        grads = policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=1, sync=bn_sync)
         works = [reduce_async(grads[split:])]
-        policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=2)
+        policy_net._backward_onehot(b.action, q_sa, y, 1.0 / gB, B, phase=2, sync=bn_sync)
         works += [reduce_async(grads[:split]), reduce_async(out4)]
         if comm is not None:
             comm.wait()
@@ -470,7 +482,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
 
 
 def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                      use_double_dqn, st_opt, sync, comm=None):
+                      use_double_dqn, st_opt, sync, comm=None, sync_bn=False, global_nonfinal=None):
     """train_step through simq_train_step: the same launches in the same order, sequenced inside the library (with `comm`: the
     data-parallel form, gradient buckets all-reduced on the communicator's stream between the backward phases and the SGD)."""
     dev = policy_net.device_
@@ -494,6 +506,8 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     a.plan = policy_net.plan.handle
     a.batch, a.num_nonfinal, a.global_batch = B, Nn_real, gB
     a.comm = comm.handle if comm is not None else None
+    a.sync_bn = 1 if (sync_bn and comm is not None) else 0
+    a.global_nonfinal = int(global_nonfinal) if global_nonfinal is not None else Nn_real
     next_state = b.next_state if Nn_real else torch.empty((1, W, W, policy_net.num_input_channels), **f32)
     nonfinal_pos = b.nonfinal_pos if Nn_real else torch.zeros(1, dtype=torch.int32, device=dev)
     a.use_double_dqn, a.first_step = int(bool(use_double_dqn)), 0 if st_opt.initialised else 1

@@ -188,9 +188,31 @@ class DQNIntentionPolicy(DQNPolicy):
         return action
 
     def step_many(self, states, exploration_eps=None, use_ground_truth_intention=False):
-        """Several environments at once.  With ground-truth intention maps the batched DQNPolicy.step_many applies; the
-        predicted-intention path chains two networks per robot group and is served environment by environment (same results
-        and RNG order as sequential step() calls)."""
+        """Several environments at once, predicted-intention path included: per robot group ONE batched forward of
+        the intention net over the awaiting robots of all environments, one sigmoid+concat launch over the whole batch (the predicted
+        maps stay in HBM), then the batched Q-network forward + argmax of DQNPolicy.step_many.  Same results and the same
+        epsilon-greedy draw order as sequential step() calls (policies.py:119-146)."""
         if self.train and use_ground_truth_intention:
             return super().step_many(states, exploration_eps=exploration_eps)
-        return [self.step(st, exploration_eps=exploration_eps, use_ground_truth_intention=use_ground_truth_intention) for st in states]
+        W = arch.STATE_WIDTH
+        pred = [[[None for _ in g] for g in st] for st in states]
+        with torch.no_grad():
+            for i in range(self.num_robot_groups):
+                live = [(e, j) for e, st in enumerate(states) for j, s in enumerate(st[i]) if s is not None]
+                if not live:
+                    continue
+                net = self.intention_nets[i]
+                net.eval()                                                                 # policies.py:101
+                xs = [states[e][i][j] for e, j in live]
+                if self.train:                                                             # drop the ground-truth map (policies.py:124)
+                    xs = [s[:, :, :-1] for s in xs]
+                x = torch.from_numpy(np.stack([np.ascontiguousarray(s, dtype=np.float32) for s in xs])).to(self.device)
+                logit = net.forward_nhwc(x)
+                n, C = x.shape[0], x.shape[3]
+                out = torch.empty((n, W, W, C + 1), dtype=torch.float32, device=self.device)
+                lib.call('simq_sigmoid_concat', ptr(x), ptr(logit), ptr(out), None, n * W * W, C, stream_ptr(self.device))
+                for k, (e, j) in enumerate(live):
+                    pred[e][i][j] = out[k:k + 1]
+                if self.train:
+                    net.train()
+        return super().step_many(pred, exploration_eps=exploration_eps)

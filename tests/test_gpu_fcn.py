@@ -103,6 +103,42 @@ def test_forward_eval_and_train(simq_mod, case, golden_dir):
     assert all(int(sd[k]) == 1 for k in sd if k.endswith('num_batches_tracked'))
 
 
+@pytest.mark.parametrize('cin,cout,wseed,dseed', [(7, 2, 91, 92), (10, 1, 93, 94), (4, 2, 95, 96)], ids=['c7o2_spatial', 'c10o1', 'c4o2'])
+def test_forward_b8_other_channel_counts_and_f4_forwards(simq_mod, cin, cout, wseed, dseed):
+    """(1) The input-channel variants SURVEY 8d names beyond the fixtures: Cin = 7 (`-spatial`: 4 state + 3 spatial intention channels)
+    and Cin = 10 (the largest num_input_channels the reference's configs produce), Cout 2 / 1.  (2) Batch 8 is where the no-grad
+    forwards of the fp32 plan switch their wide 3x3 layers to Winograd F(4x4,3x3) (B * 36 >= 256 tiles): eval mode (target net,
+    policy.step) and train-mode-no-grad (the double-DQN argmax forward, with batch statistics and the running update) against the
+    live fp32 oracle at the 1e-4 bar, argmax included; the grad-mode forward (F(2x2,3x3)) of the same batch agrees as well."""
+    B = 8
+    x_hwc = synth.make_states(B, cin, dseed)
+    x_nchw = torch.cat([olearner.apply_transform(s) for s in x_hwc])
+    net = make_net(simq_mod, cin, cout, wseed, training=False)
+    with torch.no_grad():
+        q = net.forward_nhwc(torch.from_numpy(x_hwc).cuda())
+    st = cases.oracle_state(cin, cout, wseed)
+    with torch.no_grad():
+        q_or = ofcn.fcn_forward(st, x_nchw, False)
+    err_eval = rel(q, q_or)
+    assert q.reshape(B, -1).argmax(1).cpu().tolist() == q_or.reshape(B, -1).argmax(1).tolist()
+    net = make_net(simq_mod, cin, cout, wseed, training=True)
+    with torch.no_grad():
+        q_ng = net.forward_nhwc(torch.from_numpy(x_hwc).cuda())                   # MODE_TRAIN_NOGRAD
+    st = cases.oracle_state(cin, cout, wseed)
+    with torch.no_grad():
+        q_or_t = ofcn.fcn_forward(st, x_nchw, True)
+    err_ng = rel(q_ng, q_or_t)
+    sd = net.state_dict()
+    got = np.concatenate([sd[k].cpu().double().numpy().ravel() for k in sd if k.endswith('running_mean') or k.endswith('running_var')])
+    err_bn = rel(got, cases.bn_buffer_vector(st))
+    net2 = make_net(simq_mod, cin, cout, wseed, training=True)
+    q_g = net2.forward_nhwc(torch.from_numpy(x_hwc).cuda())                       # grad mode (autograd node): F(2x2,3x3)
+    err_g = rel(q_g, q_or_t)
+    print('\n[Cin %d Cout %d B 8] Q-map error vs the fp32 oracle: eval (F4) %.3g, train-no-grad (F4) %.3g, grad-mode (F2) %.3g, running stats %.3g'
+          % (cin, cout, err_eval, err_ng, err_g, err_bn))
+    assert err_eval < TOL and err_ng < TOL and err_g < TOL and err_bn < TOL
+
+
 def test_state_dict_roundtrip(simq_mod):
     np_sd = synth.make_state_dict(5, 2, 77)
     net = make_net(simq_mod, 5, 2, 77, training=False)

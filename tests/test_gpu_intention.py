@@ -148,6 +148,23 @@ def test_intention_policy_step_golden(simq_mod, golden_dir):
     a_gt = pol.step([[full], [None]], exploration_eps=0.0, use_ground_truth_intention=True)
     assert 0 <= a_gt[0][0] < 2 * 96 * 96
     assert all(n.training for n in pol.policy_nets + pol.intention_nets)
+    # step_many on the predicted-intention path: one batched intention forward + one batched Q forward per robot group for all
+    # environments == environment-by-environment step() (greedy), and the same epsilon-greedy draws under a seed
+    s3 = synth.make_states(5, 4, 83)
+    fulls = [np.concatenate([x, np.zeros((96, 96, 1), np.float32)], axis=2) for x in s3]
+    envs = [[[fulls[0]], [fulls[1]]], [[fulls[2]], [None]], [[None], [fulls[3]]], [[fulls[4]], [fulls[0]]]]
+    many = pol.step_many(envs, exploration_eps=0.0)
+    assert many == [pol.step(st, exploration_eps=0.0) for st in envs]
+    import random
+    random.seed(3); m1 = pol.step_many(envs, exploration_eps=0.5)
+    random.seed(3); m2 = [pol.step(st, exploration_eps=0.5) for st in envs]
+    assert m1 == m2
+    assert all(n.training for n in pol.policy_nets + pol.intention_nets)
+    pol.train = False
+    for n in pol.policy_nets + pol.intention_nets:
+        n.eval()
+    envs4 = [[[s3[0]], [s3[1]]], [[s3[2]], [s3[3]]]]
+    assert pol.step_many(envs4, exploration_eps=0.0) == [pol.step(st, exploration_eps=0.0) for st in envs4]
 
 
 def test_intention_checkpoint_roundtrip(simq_mod, tmp_path):

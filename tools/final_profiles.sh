@@ -1,24 +1,32 @@
 #!/bin/bash
-# GPU box: the measurements behind profiles/rNN_* (run from the repo root through gpurun):
-#   1. python bench.py                      -> gpurun_out/final/bench_fp32.json   (the judged line, with cpu_baseline)
-#   2. rocprofv3 --kernel-trace             -> kernel_trace.txt                   (same command, fewer steps)
-#   3. rocprofv3 --pmc SQ_* (own pass)      -> pmc_sq.txt                         (matrix-pipe busy cycles)
-#   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> pmc_traffic.txt + pmc_traffic.json
+# GPU box: the measurements behind profiles/r02_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
+#   1. python bench.py                      -> bench.json        (the judged line: fp32 configs[1] headline + bf16 configs[2] leg,
+#                                                                  both with a roofline object, cpu_baseline)
+#   per workload W in {b32 = fp32 configs[1], bf16_b128 = bf16 configs[2]}:
+#   2. rocprofv3 --kernel-trace             -> bench_W_kernel_trace.txt   (same bench.py, 7 full steps, nothing else)
+#   3. rocprofv3 --pmc SQ_* (own pass)      -> bench_W_pmc_sq.txt         (matrix-pipe busy cycles)
+#   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> bench_W_pmc_traffic.txt + pmc_traffic[_bf16_b128].json
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
-python bench.py > $O/bench_fp32.json 2> $O/bench_fp32.err
-B="python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --steps 5 --warmup 2"   # 7 full steps, nothing else
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O -o kt -- $B > $O/kt.out 2> $O/kt.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O -o ps -- $B > $O/ps.out 2> $O/ps.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O -o pf -- $B > $O/pf.out 2> $O/pf.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O -o pw -- $B > $O/pw.out 2> $O/pw.err
-cd $R
-python tools/rocprof_summary.py $(find $O -name "kt_results.db") 7 > $O/kernel_trace.txt
-python tools/rocprof_summary.py $(find $O -name "ps_results.db") 7 > $O/pmc_sq.txt
-python tools/pmc_traffic.py $(find $O -name "pf_results.db") $(find $O -name "pw_results.db") $O/pmc_traffic.json > $O/pmc_traffic.txt
-find $O -name "*.db" -size +30M -delete
-tail -c 600 $O/bench_fp32.json
+python bench.py > $O/bench.json 2> $O/bench.err
+prof() {   # name, extra bench args...
+  local name=$1; shift
+  local B="python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --steps 5 --warmup 2 $*"
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace -d $O -o kt_$name -- $B > $O/kt_$name.out 2> $O/kt_$name.err
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O -o ps_$name -- $B > $O/ps_$name.out 2> $O/ps_$name.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O -o pf_$name -- $B > $O/pf_$name.out 2> $O/pf_$name.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O -o pw_$name -- $B > $O/pw_$name.out 2> $O/pw_$name.err
+  cd $R
+  python tools/rocprof_summary.py $(find $O -name "kt_${name}_results.db") 7 > $O/bench_${name}_kernel_trace.txt
+  python tools/rocprof_summary.py $(find $O -name "ps_${name}_results.db") 7 > $O/bench_${name}_pmc_sq.txt
+  python tools/pmc_traffic.py $(find $O -name "pf_${name}_results.db") $(find $O -name "pw_${name}_results.db") $O/pmc_traffic_${name}.json > $O/bench_${name}_pmc_traffic.txt
+}
+prof b32
+prof bf16_b128 --precision bf16 --batch 128 --cin 5
+find $O -name "*.db" -delete
+find $O -type d -empty -delete
+tail -c 1500 $O/bench.json
