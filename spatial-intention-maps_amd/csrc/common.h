@@ -99,6 +99,9 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
                            const ConvEpilogue& e, hipStream_t stream);
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
                            hipStream_t stream);
+// conv_wgrad_bf16_pp.hip: 256 x 256 tiles, LDS-DMA staging, ping-pong wave groups; 1 = took the launch, 0 = shape not covered
+int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, const ConvGeom& g, unsigned x_bytes, unsigned dy_bytes,
+                           hipStream_t stream);
 // every convolution's weight transforms in one launch (see split_planes.hip)
 struct WeightPrepDesc { int64_t w_off, wt_off, wp_off; int cout, taps, cin, pad_; };
 struct WeightPrepTable { WeightPrepDesc d[24]; int n; };

@@ -291,6 +291,10 @@ int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[
     SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "conv_wgrad_bf16: tensor exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_wgrad_bf16: nplanes must be 1 or 2");
+    if (nplanes == 1) {                                  // wide 3x3 layers: 256 x 256 ping-pong tiles (conv_wgrad_bf16_pp.hip)
+        const int took = try_conv_wgrad_bf16_pp(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream);
+        if (took != 0) return took < 0 ? took : 0;
+    }
     return nplanes == 2 ? dispatch<2>(a, stream) : dispatch<1>(a, stream);
 }
 

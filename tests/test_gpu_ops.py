@@ -287,6 +287,60 @@ def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
     assert rel(dwd, wd64.grad.permute(0, 2, 3, 1)) < tol_fwd
 
 
+@pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256))],
+                         ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged'])
+def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile):
+    """The two ping-pong bf16 kernels of the 3x3 layers on the 24x24 maps -- conv_igemm_bf16_img.hip (tile "576x128": one image x 128
+    channels per block, halo patch staged once per 32-channel chunk, nine taps read shifted fragments) and conv_igemm_bf16_pp.hip
+    (288x256 implicit-GEMM tile, 4-stage LDS-DMA ring) -- against the register-staged kernel on the same bf16 operands: same
+    products, fp32 accumulation in a different K order, so outputs agree to fp32 round-off; bias + batch statistics through the
+    staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile."""
+    H, k = 24, 3
+    g = torch.Generator().manual_seed(11 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
+    st = L.stream_ptr()
+    outs = []
+    try:
+        for t in (tile, (96, 128)):
+            L.lib.call('simq_tune_force_tile', *t)
+            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1,
+                       L.ptr(scratch), L.ptr(stats), st)
+            outs.append((y, stats))
+    finally:
+        L.lib.call('simq_tune_force_tile', 0, 0)
+    (y1, s1), (y0, s0) = outs
+    assert torch.isfinite(y1).all()
+    assert rel(y1, y0) < 5e-6 and rel(s1, s0) < 1e-6
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel(y1, ref) < 3e-2                                                   # bf16-class against fp64
+
+
+@pytest.mark.parametrize('B,Cin,Cout', [(8, 256, 256), (5, 512, 256), (6, 256, 512)], ids=['l3', 'l4b_ragged', 'l4a'])
+def test_conv_bf16_wgrad_pingpong_matches_register_staged(L, B, Cin, Cout):
+    """conv_wgrad_bf16_pp.hip (256x256 tiles per tap, LDS-DMA staged rows read back by ds_read_b64_tr_b16, ping-pong wave groups,
+    pixel reduction split over blocks) against the register-staged 128x128 wgrad kernel (SIMQ-internal switch) and fp64: the same
+    bf16 products, fp32 accumulation / atomics in a different order."""
+    import os
+    H, k = 24, 3
+    g = torch.Generator().manual_seed(13 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    dy = torch.randn(B, H, H, Cout, generator=g).cuda()
+    scratch = torch.empty(2 * (x.numel() + dy.numel()) + 64, dtype=torch.int16, device='cuda')
+    st = L.stream_ptr()
+    d1 = torch.full((Cout, k, k, Cin), 7.0, device='cuda')
+    L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(x), L.ptr(dy), L.ptr(d1), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), st)
+    # reference: bf16-rounded operands, exact products, fp64 accumulation
+    xb, dyb = x.bfloat16().double(), dy.bfloat16().double()
+    ref = torch.nn.grad.conv2d_weight(xb.permute(0, 3, 1, 2), (Cout, Cin, k, k), dyb.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(d1).all()
+    assert rel(d1, ref) < 2e-5, rel(d1, ref)                                     # fp32 accumulation of exact bf16 products
+
+
 @pytest.mark.parametrize('B,H,Cin,Cout,k', [(16, 24, 128, 256, 3), (15, 24, 64, 128, 3), (16, 24, 256, 128, 1)],
                          ids=['256tiles', 'ragged_rows', '1x1'])
 def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k):
