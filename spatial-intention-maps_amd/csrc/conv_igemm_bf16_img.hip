@@ -150,9 +150,12 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_img_kernel(const IgemmB
 
     // One iteration = one K-tile (chunk, tap).  The tap loop is NOT unrolled (an unrolled body made the compiler keep per-tap
     // addresses live and spill -- and a scratch reload costs an s_waitcnt vmcnt(0), which drains the DMA queue): the tap offset is a
-    // scalar added to the 9 fragment addresses (9 VALU per load segment).  (Measured alternative: the address arithmetic of the
-    // NEXT load segment done between the MFMAs of the wave's own MFMA segment -- shorter load segments, but the MFMA segment
-    // grew by more: 311 vs 296 us on layer4 at B = 128.)
+    // scalar added to the 9 fragment addresses (9 VALU per load segment).  Measured alternatives on layer4 at B = 128 (this form:
+    // 287-296 us): the NEXT segment's address arithmetic between the MFMAs of the wave's own MFMA segment -- 311 us (the MFMA
+    // segment grows by more than the load segment shrinks); the same arithmetic behind the fragment reads / DMA issue of the load
+    // segment (in the shadow of the LDS latency) -- 308 us, and with the DMA source steps in the instructions' scalar offsets 317 us
+    // (each variant is FASTER without the DMA traffic -- 203 vs 208 us -- so what they lose is the timing of the DMA issue relative
+    // to the partner wave's MFMA segment, not instruction count); taps unrolled with immediate offsets -- the compiler spills.
     int chunk = 0, tap = 0, toff = 0, tx = 0, prev_issued = 0;
     const int nk = nk_chunks * TAPS;
     for (int kt = 0; kt < nk; ++kt) {
