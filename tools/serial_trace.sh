@@ -14,7 +14,7 @@ python tools/rocprof_summary.py $DB 7 > $O/kernel_trace.txt
 python - $DB > $O/by_grid.txt <<'P'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-for pat in ('bn_apply', 'bn_bwd_apply', 'upsample2x_fwd', 'chan_reduce', 'igemm_conv_kernel<64, 64, true>', 'igemm_conv_kernel<96, 32, true>', 'igemm_conv_kernel<32, 32, true>', 'wgrad_kernel'):
+for pat in ('bn_apply', 'bn_bwd_apply', 'upsample2x_fwd', 'chan_reduce', 'igemm_conv_kernel<64, 64, true, false>', 'igemm_conv_kernel<96, 32', 'igemm_conv_kernel<32, 32', 'igemm_conv_kernel<96, 64', 'igemm_conv_kernel<64, 32', 'igemm_conv_kernel<64, 64, false', 'wgrad_kernel', 'wino'):
     rows = c.execute("select name, grid_x/workgroup_x, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like ? group by name, grid_x order by 1, 2", ('%' + pat + '%',)).fetchall()
     for r in rows:
         print('%-60s grid %6d  calls %4d  avg %8.2f us  min %8.2f us' % (r[0].replace('simq::(anonymous namespace)::', '').replace('void ', '')[:60], r[1], r[2], r[3], r[4]))
