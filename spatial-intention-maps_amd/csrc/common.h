@@ -145,15 +145,16 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
                          hipStream_t stream, Planes pl = Planes());
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
-                         int C, hipStream_t stream);
+                         int C, hipStream_t stream, int g_bf16 = 0);
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean,
-                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0);
+                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0, int g_bf16 = 0);
 // dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
                         float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes(),
-                        const uint16_t* mask16 = nullptr, int y_bf16 = 0, double global_rows = 0.0, float dparam_scale = 1.f);
+                        const uint16_t* mask16 = nullptr, int y_bf16 = 0, double global_rows = 0.0, float dparam_scale = 1.f,
+                        int g_bf16 = 0);   // g_bf16: g (and dz_out) are bf16 behind the float pointers
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);

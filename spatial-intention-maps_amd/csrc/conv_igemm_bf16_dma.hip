@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_dma_kernel(const IgemmB
     wait_vmcnt<0>();
     __syncthreads();
 
-    if constexpr (TM % 3 == 0 && C::SMEM >= staged_epilogue_smem<BN, TN, WM, NW, 3>()) igemm_epilogue_staged<BM, BN, TM, TN, WM, NW, 3>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
+    if constexpr (TM % 3 == 0 && C::SMEM >= staged_epilogue_smem<BN, TN, WM, NW, 3>()) igemm_epilogue_staged<BM, BN, TM, TN, WM, NW, 3, true>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
     else igemm_epilogue<BM, BN, TM, TN, WM, NW>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_pp_kernel(const IgemmBf
     wait_vmcnt<0>();
     __syncthreads();
 
-    igemm_epilogue_staged<BM, BN, TM, TN, WM, NW, 3>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
+    igemm_epilogue_staged<BM, BN, TM, TN, WM, NW, 3, true>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
 }
 
 template <int DBG>

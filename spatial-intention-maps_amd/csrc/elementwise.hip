@@ -184,7 +184,7 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, floa
 // gather form of maxpool backward fused with the ReLU mask: dz at HxW from g at (H/2)x(W/2)
 __global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pooled,
                                      const uint8_t* __restrict__ idx, float* __restrict__ dz, int B, int H, int W,
-                                     int C4) {
+                                     int C4, int g_bf16) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * H * W * C4;
     // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
@@ -209,7 +209,7 @@ __global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* _
                 unsigned char s = (unsigned char)(dy * 3 + dx);
                 size_t o = ((((size_t)b * Ho + py) * Wo + px) * C4 + c4) * 4;
                 uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
-                float4 pv = ld4(pooled + o), gv = ld4(g + o);
+                float4 pv = ld4(pooled + o), gv = ld4y(g, o / 4, g_bf16);
                 if (bi.x == s && pv.x > 0.f) acc.x += gv.x;
                 if (bi.y == s && pv.y > 0.f) acc.y += gv.y;
                 if (bi.z == s && pv.z > 0.f) acc.z += gv.z;
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, double* red, size_t rows,
-                                                          int C4, int y_bf16) {
+                                                          int C4, int y_bf16, int g_bf16) {
     __shared__ double sm[256 * 8];
     const int tid = threadIdx.x;
     const int rowlanes = 256 / C4;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
         if (MODE == 0) { mu = ld4(mean + c4 * 4); is = ld4(invstd + c4 * 4); }
         for (size_t r = (size_t)blockIdx.x * rowlanes + rl; r < rows; r += (size_t)gridDim.x * rowlanes) {
             size_t o = (r * C4 + c4) * 4;
-            float4 dz = ld4(g + o);
+            float4 dz = ld4y(g, o / 4, g_bf16);
             if (MODE == 0) {
                 if (mask) {
                     float4 m = ld4(mask + o);
@@ -275,7 +275,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
                                     float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4,
-                                    int y_bf16, float inv_rows, float dparam_scale) {
+                                    int y_bf16, float inv_rows, float dparam_scale, int g_bf16) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -287,7 +287,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     // the grid stride is a multiple of C4 (256 % C4 == 0): a thread keeps its 4 channels
     const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) % C4) * 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 dz = ld4(g + i * 4);
+        float4 dz = ld4y(g, i, g_bf16);
         if (mask) {
             float4 m = ld4(mask + i * 4);
             dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
@@ -297,7 +297,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
             dz.x = (short)m.x > 0 ? dz.x : 0.f; dz.y = (short)m.y > 0 ? dz.y : 0.f;
             dz.z = (short)m.z > 0 ? dz.z : 0.f; dz.w = (short)m.w > 0 ? dz.w : 0.f;
         }
-        if (dz_out) st4(dz_out + i * 4, dz);
+        if (dz_out) {
+            if (g_bf16) *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(dz_out) + i * 4) = make_ushort4((uint16_t)(__float_as_uint(dz.x) >> 16), (uint16_t)(__float_as_uint(dz.y) >> 16), (uint16_t)(__float_as_uint(dz.z) >> 16), (uint16_t)(__float_as_uint(dz.w) >> 16));   // (exact: dz is a bf16 value or 0)
+            else st4(dz_out + i * 4, dz);
+        }
         float4 yv = ld4y(y, i, y_bf16), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
         float db[4] = {(float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]};
         float dg[4] = {(float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]};
@@ -449,11 +452,11 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 }
 
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
-                         int C, hipStream_t stream) {
+                         int C, hipStream_t stream, int g_bf16) {
     size_t total = (size_t)B * H * W * (C / 4);
     SIMQ_REQUIRE(total < 2147483648ull, "stem_pool_bwd: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, pooled, idx, dz, B, H, W,
-                       C / 4);
+                       C / 4, g_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -467,10 +470,10 @@ static int reduce_grid(int64_t rows, int C4) {
 }
 
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
-                         double* red, int64_t rows, int C, hipStream_t stream, int y_bf16) {
+                         double* red, int64_t rows, int C, hipStream_t stream, int y_bf16, int g_bf16) {
     SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "bn_bwd_reduce: C=%d unsupported", C);
     hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, g, mask, y, mean,
-                       invstd, red, (size_t)rows, C / 4, y_bf16);
+                       invstd, red, (size_t)rows, C / 4, y_bf16, g_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -478,13 +481,13 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
                         int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16, int y_bf16, double global_rows,
-                        float dparam_scale) {
+                        float dparam_scale, int g_bf16) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
                        gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16,
-                       (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale);
+                       (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale, g_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -493,7 +496,7 @@ int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows,
     SIMQ_REQUIRE(C % 4 == 0 && C / 4 <= 256, "colsum: C=%d unsupported", C);
     SIMQ_CHECK_HIP(hipMemsetAsync(red_scratch, 0, sizeof(double) * C, stream));
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(reduce_grid(rows, C / 4)), dim3(256), 0, stream, x, nullptr, nullptr,
-                       nullptr, nullptr, red_scratch, (size_t)rows, C / 4, 0);
+                       nullptr, nullptr, red_scratch, (size_t)rows, C / 4, 0, 0);
     SIMQ_CHECK_LAUNCH();
     return launch_colsum_finish(red_scratch, out, C, stream);
 }

@@ -229,6 +229,12 @@ struct Ctx {
     // BatchNorm backward and the fused reductions; the batch statistics still come from the fp32 accumulators)
     int ybf() const { return p->precision == SIMQ_PREC_BF16 ? 1 : 0; }
     int ybf(const ConvL& cv) const { return (p->precision == SIMQ_PREC_BF16 && cv.wp_off >= 0) ? 1 : 0; }
+    // ... and the activation gradients that travel between the residual blocks' kernels (dgrad epilogue -> BatchNorm backward ->
+    // next dgrad's addend) as bf16 too: the dgrad epilogues are HBM-bound (SIMQ_FP32_ACT_GRADS=1 keeps them fp32, diagnostics)
+    int gbf() const {
+        static const bool fp32g = getenv("SIMQ_FP32_ACT_GRADS") != nullptr;
+        return (p->precision == SIMQ_PREC_BF16 && !fp32g) ? 1 : 0;
+    }
     Planes planes(int64_t off, int64_t elems) const {
         Planes pl;
         if (mc() && off >= 0) {
@@ -452,14 +458,15 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 // `mask16`: the mask as a bf16 plane when its fp32 copy is not kept (then `mask` is NULL and the reduction was fused);
 // `dy.fv == false`: only the planes of dy are written
 // `y_bf16`: y is the bf16 pre-BN output of a matrix-core convolution (Ctx::ybf)
+// `g_bf16`: g (and dz_out) are bf16 behind the float pointers (Ctx::gbf: the activation gradients of plain-bf16 plans)
 int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
-           bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1) {
+           bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1, int g_bf16 = 0) {
     if (y_bf16 < 0) y_bf16 = c.ybf();
-    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16));
+    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16, g_bf16));
     RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));                                   // SyncBN: [sum dz | sum dz*xhat] over all ranks
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
                                c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16,
-                               c.sync ? c.bn_rows(rows) : 0.0, c.sync ? 1.f / (float)c.sync->world_size : 1.f);
+                               c.sync ? c.bn_rows(rows) : 0.0, c.sync ? 1.f / (float)c.sync->world_size : 1.f, g_bf16);
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
@@ -476,13 +483,15 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
 
 // dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
 // `fuse`: optional BN-backward reduction over the produced gradient (igemm_epilogue.h)
+// `g_bf16`: dx and addend are bf16 behind the float pointers (Ctx::gbf)
 int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const float* addend, int hin,
-               const ConvEpilogue& fuse = ConvEpilogue()) {
+               const ConvEpilogue& fuse = ConvEpilogue(), int g_bf16 = 0) {
     ConvGeom g;
     g.B = c.B; g.Hin = hin; g.Win = hin; g.Cin = cv.cout; g.Cout = cv.cin; g.Hout = hin; g.Wout = hin;
     g.R = cv.k; g.S = cv.k; g.stride = 1; g.pad = cv.k - 1 - cv.pad;
     ConvEpilogue e = fuse;
     e.addend = addend;
+    e.y_bf16 = g_bf16; e.addend_bf16 = g_bf16;
     if (c.mc() && cv.wp_off >= 0) {
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         const uint16_t* wsp[2];
@@ -552,7 +561,8 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         }
         return e;
     };
-    if (phase != 2) RC(conv_dgrad(c, p->h1, dyact(S[0], 0), S[1], nullptr, 24, fuse_block_out(7)));
+    const int gb = c.gbf();
+    if (phase != 2) RC(conv_dgrad(c, p->h1, dyact(S[0], 0), S[1], nullptr, 24, fuse_block_out(7), gb));
     const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
     const int i_hi = phase == 2 ? kPhaseSplitBlock - 1 : 7, i_lo = phase == 1 ? kPhaseSplitBlock : 0;
     for (int i = i_hi; i >= i_lo; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
@@ -574,24 +584,24 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         const uint16_t* m16_out = po ? c.planes(o.p_out, rows * b.planes).hi : nullptr;
         const uint16_t* m16_a1 = po ? c.planes(o.p_a1, rows * b.planes).hi : nullptr;
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
-        RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out));
-        if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out));
+        RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out, -1, gb));
+        if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out, -1, gb));
         RC(conv_wgrad(c, b.c2, a1, T0, 24));
         ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
         if (!no_fuse) {
         f1.bnr_y_bf16 = c.ybf();
         f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
-        RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1));
-        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1));
+        RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1, gb));
+        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1, -1, gb));
         RC(conv_wgrad(c, b.c1, xin, T0, 24));
         const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {
             RC(conv_wgrad(c, b.ds, xin, T1, 24));
-            RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24));
-            RC(conv_dgrad(c, b.c1, T0, G, G, 24, fin));
+            RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24, ConvEpilogue(), gb));
+            RC(conv_dgrad(c, b.c1, T0, G, G, 24, fin, gb));
         } else {
-            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24, fin));
+            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24, fin, gb));
         }
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
@@ -601,7 +611,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     float* T0 = S[(gi + 1) & 3];
     Act T1; T1.f = S[(gi + 2) & 3];
     Act x0; x0.f = c.f(L.x);
-    RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream));
+    RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf()));
     RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, 0));   // (the stem conv is fp32)
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
     return 0;
