@@ -44,6 +44,16 @@ __device__ __forceinline__ void bn_coeff4(const BnRef& b, int c, float4& sc, flo
     bn_coeff(b, c, sc.x, sh.x, m, i, md, vd); bn_coeff(b, c + 1, sc.y, sh.y, m, i, md, vd);
     bn_coeff(b, c + 2, sc.z, sh.z, m, i, md, vd); bn_coeff(b, c + 3, sc.w, sh.w, m, i, md, vd);
 }
+// scale / shift of a train- or eval-mode BatchNorm for every channel, once per block (fp64 mean / variance / rsqrt per channel:
+// per thread it cost more than the short grid-stride loops that follow).  cs: [2][kCoeffMaxC] floats of LDS
+constexpr int kCoeffMaxC = 512;
+__device__ __forceinline__ void bn_coeff_block(const BnRef& b, float* cs) {
+    for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
+        float sc, sh, m, i; double md, vd;
+        bn_coeff(b, c, sc, sh, m, i, md, vd);
+        cs[c] = sc; cs[kCoeffMaxC + c] = sh;
+    }
+}
 // once per launch (block 0): save mean / invstd for backward and update the running statistics (momentum 0.1,
 // unbiased variance, in fp64 like ATen's CPU kernel)
 __device__ __forceinline__ void bn_commit(const BnRef& b) {
@@ -124,8 +134,17 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const flo
     const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const int c = (int)(i0 % C4) * 4;
     float4 sc, sh, rsc, rsh;
-    bn_coeff4(bn, c, sc, sh);
-    if (has_rbn) bn_coeff4(rbn, c, rsc, rsh);
+    if (bn.C <= kCoeffMaxC) {
+        __shared__ float cs[4 * kCoeffMaxC];
+        bn_coeff_block(bn, cs);
+        if (has_rbn) bn_coeff_block(rbn, cs + 2 * kCoeffMaxC);
+        __syncthreads();
+        sc = ld4(cs + c); sh = ld4(cs + kCoeffMaxC + c);
+        if (has_rbn) { rsc = ld4(cs + 2 * kCoeffMaxC + c); rsh = ld4(cs + 3 * kCoeffMaxC + c); }
+    } else {
+        bn_coeff4(bn, c, sc, sh);
+        if (has_rbn) bn_coeff4(rbn, c, rsc, rsh);
+    }
     for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         float4 v = fma4(ld4y(y, i, y_bf16), sc, sh);
         if (res || res_pl.hi) {
@@ -139,6 +158,117 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, BnRef bn, const flo
     }
     bn_commit(bn);
     if (has_rbn) bn_commit(rbn);
+}
+
+// ---- all-bf16 forms (plain-bf16 plans, planes-only activations): 8 channels = one 16-byte access per thread and tensor, two
+// grid-stride iterations in flight.  With 8-byte accesses these kernels sat at ~3.2 TB/s -- too few bytes in flight per CU.
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 unpack8(uint4 r) {
+    F8 o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ uint4 pack8(const F8& a) {
+    uint4 r;
+    r.x = (uint32_t)to_bf16(a.v[0]) | ((uint32_t)to_bf16(a.v[1]) << 16); r.y = (uint32_t)to_bf16(a.v[2]) | ((uint32_t)to_bf16(a.v[3]) << 16);
+    r.z = (uint32_t)to_bf16(a.v[4]) | ((uint32_t)to_bf16(a.v[5]) << 16); r.w = (uint32_t)to_bf16(a.v[6]) | ((uint32_t)to_bf16(a.v[7]) << 16);
+    return r;
+}
+__device__ __forceinline__ uint4 ld16(const uint16_t* p, size_t i8) { return *reinterpret_cast<const uint4*>(p + i8 * 8); }
+__device__ __forceinline__ void st16(uint16_t* p, size_t i8, uint4 v) { *reinterpret_cast<uint4*>(p + i8 * 8) = v; }
+
+__global__ void __launch_bounds__(256) bn_apply16_kernel(const uint16_t* __restrict__ y, BnRef bn, const uint16_t* __restrict__ res, BnRef rbn,
+                                                         int has_rbn, int relu, uint16_t* __restrict__ out, size_t total8, int C8) {
+    const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const int c = (int)(i0 % C8) * 8;                 // (the grid stride is a multiple of C8: a thread keeps its 8 channels)
+    __shared__ float cs[4 * kCoeffMaxC];              // (the launcher bounds C)
+    bn_coeff_block(bn, cs);
+    if (has_rbn) bn_coeff_block(rbn, cs + 2 * kCoeffMaxC);
+    __syncthreads();
+    float scp[8], shp[8], rscp[8], rshp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        scp[k] = cs[c + k]; shp[k] = cs[kCoeffMaxC + c + k];
+        rscp[k] = has_rbn ? cs[2 * kCoeffMaxC + c + k] : 1.f; rshp[k] = has_rbn ? cs[3 * kCoeffMaxC + c + k] : 0.f;
+    }
+    auto one = [&](uint4 yr, uint4 rr) {
+        F8 a = unpack8(yr), r = unpack8(rr);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = fmaf(a.v[k], scp[k], shp[k]);
+            if (res) v += has_rbn ? fmaf(r.v[k], rscp[k], rshp[k]) : r.v[k];
+            a.v[k] = relu ? fmaxf(v, 0.f) : v;
+        }
+        return pack8(a);
+    };
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    size_t i = i0;
+    for (; i + stride < total8; i += 2 * stride) {
+        const uint4 y0 = ld16(y, i), y1 = ld16(y, i + stride);
+        const uint4 r0 = res ? ld16(res, i) : z, r1 = res ? ld16(res, i + stride) : z;
+        st16(out, i, one(y0, r0));
+        st16(out, i + stride, one(y1, r1));
+    }
+    if (i < total8) st16(out, i, one(ld16(y, i), res ? ld16(res, i) : z));
+    bn_commit(bn);
+    if (has_rbn) bn_commit(rbn);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ mask16,
+                                                             const uint16_t* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const double* __restrict__ red, uint16_t* __restrict__ dy,
+                                                             uint16_t* __restrict__ dz_out, float* dgamma, float* dbeta, size_t total8, int C8,
+                                                             float inv_rows, float dparam_scale) {
+    const int C = C8 * 8;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dbeta[c] = (float)red[c] * dparam_scale;
+            dgamma[c] = (float)red[C + c] * dparam_scale;
+        }
+    }
+    const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const int c = (int)(i0 % C8) * 8;
+    // the expression of bn_bwd_apply_kernel with the per-channel factors (gamma*invstd, dbeta/rows, dgamma/rows) formed once
+    float ka[8], mu[8], is[8], db[8], dg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c + k]; is[k] = invstd[c + k]; ka[k] = gamma[c + k] * is[k];
+        db[k] = (float)red[c + k] * inv_rows; dg[k] = (float)red[C + c + k] * inv_rows;
+    }
+    auto one = [&](uint4 gr, uint4 mr, uint4 yr, uint4& dzr) {
+        F8 gv = unpack8(gr), yv = unpack8(yr), o;
+        const uint32_t mw[4] = {mr.x, mr.y, mr.z, mr.w};
+        uint32_t zw[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const short m = (short)(k & 1 ? mw[k >> 1] >> 16 : mw[k >> 1] & 0xffffu);
+            const bool pos = m > 0;
+            if (!pos) zw[k >> 1] &= (k & 1) ? 0x0000ffffu : 0xffff0000u;
+            const float dz = pos ? gv.v[k] : 0.f;
+            o.v[k] = ka[k] * (dz - db[k] - (yv.v[k] - mu[k]) * is[k] * dg[k]);
+        }
+        dzr = make_uint4(zw[0], zw[1], zw[2], zw[3]);
+        return pack8(o);
+    };
+    size_t i = i0;
+    for (; i + stride < total8; i += 2 * stride) {
+        const uint4 g0 = ld16(g, i), g1 = ld16(g, i + stride);
+        const uint4 m0 = ld16(mask16, i), m1 = ld16(mask16, i + stride);
+        const uint4 y0 = ld16(y, i), y1 = ld16(y, i + stride);
+        uint4 z0, z1;
+        st16(dy, i, one(g0, m0, y0, z0));
+        st16(dy, i + stride, one(g1, m1, y1, z1));
+        if (dz_out) { st16(dz_out, i, z0); st16(dz_out, i + stride, z1); }
+    }
+    if (i < total8) {
+        uint4 z0;
+        st16(dy, i, one(ld16(g, i), ld16(mask16, i), ld16(y, i), z0));
+        if (dz_out) st16(dz_out, i, z0);
+    }
 }
 
 // stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
@@ -433,6 +563,13 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
                     int C, hipStream_t stream, Planes pl, Planes res_pl, int y_bf16) {
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_apply: C=%d unsupported", C);
     SIMQ_REQUIRE(out || pl.hi, "bn_apply: no output requested");
+    if (y_bf16 && !out && pl.hi && !pl.lo && !res && !res_pl.lo && C % 8 == 0 && 256 % (C / 8) == 0 && C <= 512) {   // all-bf16 form
+        size_t total8 = (size_t)rows * (C / 8);
+        hipLaunchKernelGGL(bn_apply16_kernel, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(y), bn, res_pl.hi,
+                           rbn ? *rbn : bn, rbn ? 1 : 0, relu, pl.hi, total8, C / 8);
+        SIMQ_CHECK_LAUNCH();
+        return 0;
+    }
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, res_pl, rbn ? *rbn : bn,
                        rbn ? 1 : 0, relu, out, pl, total4, C / 4, y_bf16);
@@ -484,6 +621,14 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
                         float dparam_scale, int g_bf16) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
+    if (g_bf16 && y_bf16 && mask16 && !mask && !dy && pl.hi && !pl.lo && C % 8 == 0 && 256 % (C / 8) == 0) {   // all-bf16 form
+        size_t total8 = (size_t)rows * (C / 8);
+        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
+                           reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
+                           total8, C / 8, (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale);
+        SIMQ_CHECK_LAUNCH();
+        return 0;
+    }
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
                        gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16,
