@@ -291,7 +291,8 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
     // of the 256 CUs -- the 512-channel layers (95 vs 132 us on layer4's 3x3, 92 vs 130 us at 29 samples); on the
     // 256/128-channel layers the register-staged 96-row tiles (3-4 blocks per CU) stay ahead, so only that case is taken.
     int bm = 0, bn = 0;
-    if (a.Cout % 128 == 0 && a.K >= 1024) {
+    static const int min_k = [] { const char* e = getenv("SIMQ_BF16_DMA_MINK"); return e ? atoi(e) : 64; }();
+    if (a.Cout % 128 == 0 && a.K >= min_k) {
         const long blocks = (long)((a.M + 287) / 288) * (a.Cout / 128);
         const long rounds = (blocks + 255) / 256;
         if (blocks >= 200 && (double)blocks / (double)(rounds * 256) >= 0.85) { bm = 288; bn = 128; }
