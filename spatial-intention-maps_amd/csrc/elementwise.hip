@@ -483,7 +483,7 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
         o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
         o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
         o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
-        st4(out + i * 4, o);
+        if (out) st4(out + i * 4, o);
         st_planes(pl, i, o);
     }
 }

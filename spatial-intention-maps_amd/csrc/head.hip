@@ -3,6 +3,11 @@
 // bandwidth-bound per-pixel dot product, not a GEMM: 8 lanes share a pixel (one float4 of
 // the 32 input channels each), x is read once with 16-B loads and the Q-map is written
 // NCHW because the reference's flat action index is CHW-ordered (envs.py:858).
+//
+// The forward pass applies it BEFORE the second bilinear x2 (networks.py:25-26 in the other order): both maps are linear and
+// the bilinear weights of a pixel sum to 1, so conv3(upsample(a)) + bias == upsample(conv3(a)) + bias up to fp32 rounding
+// -- and the 96x96x32 upsampled activation (151 MB at B = 128: one write, one read, every forward) never exists.  The
+// one-hot backward re-interpolates the one pixel per transition it needs; only the dense-dQ backward materialises it.
 #include "common.h"
 
 namespace simq {
@@ -29,7 +34,7 @@ __global__ void __launch_bounds__(256) head_conv3_fwd_kernel(const float* __rest
             float s = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
 #pragma unroll
             for (int o = L / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            if (sub == 0) q[((size_t)b * Cout + co) * HW + p] = s + bias[co];
+            if (sub == 0) q[((size_t)b * Cout + co) * HW + p] = s + (bias ? bias[co] : 0.f);
         }
     }
 }
@@ -101,7 +106,7 @@ __device__ __forceinline__ void lerp2x(int o, int in_size, float scale, int& i0,
     l0 = 1.f - l1;
 }
 
-__global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __restrict__ up2, const float* __restrict__ w3,
+__global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __restrict__ ah2, const float* __restrict__ w3,
                                                              const int64_t* __restrict__ action, const float* __restrict__ q_sa,
                                                              const float* __restrict__ y, float grad_scale, float* ds1, float* dw3,
                                                              float* db3, int Cout) {
@@ -113,14 +118,18 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
     const int oy = p / W2, ox = p - oy * W2;
     const float d = q_sa[b] - y[b];
     const float g = fminf(fmaxf(d, -1.f), 1.f) * grad_scale;
-    unsafeAtomicAdd(dw3 + co * CIN + ci, g * up2[((size_t)b * W2 * W2 + p) * CIN + ci]);
-    if (ci == 0) unsafeAtomicAdd(db3 + co, g);
-    const float dx = g * w3[co * CIN + ci];
     const float s = (float)(W1 - 1) / (float)(W2 - 1);
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     lerp2x(oy, W1, s, y0, y1, ly0, ly1);
     lerp2x(ox, W1, s, x0, x1, lx0, lx1);
+    // the upsampled activation at this pixel (same expression as upsample2x_fwd_kernel)
+    const float* src = ah2 + (size_t)b * W1 * W1 * CIN + ci;
+    const float up = ly0 * (lx0 * src[(y0 * W1 + x0) * CIN] + lx1 * src[(y0 * W1 + x1) * CIN]) +
+                     ly1 * (lx0 * src[(y1 * W1 + x0) * CIN] + lx1 * src[(y1 * W1 + x1) * CIN]);
+    unsafeAtomicAdd(dw3 + co * CIN + ci, g * up);
+    if (ci == 0) unsafeAtomicAdd(db3 + co, g);
+    const float dx = g * w3[co * CIN + ci];
     float* base = ds1 + (size_t)b * W1 * W1 * CIN + ci;      // this thread owns channel ci of sample b: plain read-modify-write
     base[(y0 * W1 + x0) * CIN] += ly0 * lx0 * dx;
     base[(y0 * W1 + x1) * CIN] += ly0 * lx1 * dx;
@@ -128,13 +137,52 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
     base[(y1 * W1 + x1) * CIN] += ly1 * lx1 * dx;
 }
 
+// q[b][co] (96x96, NCHW) = bilinear x2 (align_corners=True) of z[b][co] (48x48) + bias[co]: 4 outputs along x per thread
+__global__ void __launch_bounds__(256) head_upsample_q_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                              float* __restrict__ q, int planes, int Cout, int vec) {
+    constexpr int W2 = 96, W1 = 48;
+    const float s = (float)(W1 - 1) / (float)(W2 - 1);
+    const unsigned total = (unsigned)planes * W2 * (W2 / 4);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned x4 = i % (W2 / 4), r = i / (W2 / 4);
+        const unsigned oy = r % W2, pl = r / W2;
+        const float bv = bias[pl % (unsigned)Cout];
+        int y0, y1; float ly0, ly1;
+        lerp2x((int)oy, W1, s, y0, y1, ly0, ly1);
+        const float* r0 = z + (size_t)pl * W1 * W1 + y0 * W1;
+        const float* r1 = z + (size_t)pl * W1 * W1 + y1 * W1;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int x0, x1; float lx0, lx1;
+            lerp2x((int)x4 * 4 + e, W1, s, x0, x1, lx0, lx1);
+            o[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]) + bv;
+        }
+        float* dst = q + ((size_t)pl * W2 + oy) * W2 + x4 * 4;
+        if (vec) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+    }
+}
+
 }  // namespace
 
-int launch_head_onehot_bwd(const float* up2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
+int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, int Cout, hipStream_t stream) {
+    SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_upsample_q: Cout=%d unsupported", Cout);
+    SIMQ_REQUIRE((size_t)B * Cout * 9216 < 2147483648ull, "head_upsample_q: too many pixels for 32-bit indexing");
+    const unsigned total = (unsigned)B * Cout * 96 * 24;
+    unsigned blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(head_upsample_q_kernel, dim3(blocks), dim3(256), 0, stream, z, bias, q, B * Cout, Cout,
+                       (reinterpret_cast<uintptr_t>(q) & 15) == 0 ? 1 : 0);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
                            float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream) {
     SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_onehot_bwd: Cout=%d unsupported", Cout);
     SIMQ_CHECK_HIP(hipMemsetAsync(ds1, 0, sizeof(float) * (size_t)B * 48 * 48 * 32, stream));
-    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, up2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout);
+    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

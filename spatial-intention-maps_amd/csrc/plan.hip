@@ -440,7 +440,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream, Planes(), Planes(), c.ybf()));
     }
     Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
-    RC(launch_upsample2x_fwd(c.f(L.ah1), up1.f, B, 24, 24, 128, c.stream, up1.pl));
+    RC(launch_upsample2x_fwd(c.f(L.ah1), c.planes_only() ? nullptr : up1.f, B, 24, 24, 128, c.stream, up1.pl));   // (conv2 reads the planes)
     if (folded) {
         RC(conv_bn_folded(c, p->h2, p->hb2, up1, c.f(L.ah2), 48, nullptr, 1));
     } else {
@@ -448,8 +448,9 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream,
                            Planes(), Planes(), c.ybf()));
     }
-    RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));
-    RC(launch_head_conv3_fwd(c.f(L.up2), c.params + p->h3.w_off, c.params + p->h3.b_off, d_q, B, 9216, 32, p->cout, c.stream));
+    // conv3 before the second upsample (they commute, head.hip): z = conv3(ah2) without bias at 48x48, q = upsample(z) + bias
+    RC(launch_head_conv3_fwd(c.f(L.ah2), c.params + p->h3.w_off, nullptr, c.f(L.up2), B, 2304, 32, p->cout, c.stream));
+    RC(launch_head_upsample_q(c.f(L.up2), c.params + p->h3.b_off, d_q, B, p->cout, c.stream));
     return 0;
 }
 
@@ -529,9 +530,10 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     // ---- head (networks.py:18-26 reversed) ----
     if (phase != 2) {
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
-        RC(launch_head_onehot_bwd(c.f(L.up2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
+        RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
                                   c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream));
     } else {
+        RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));   // (the forward pass does not keep it)
         RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
