@@ -68,6 +68,8 @@ void tune_tail_split(int on);           // conv_igemm.hip: balanced last round o
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream);
 // conv_igemm.hip: `batch` independent row-major GEMMs y_g = x_g * w_g^T in one launch
+// ping-pong LDS-DMA form (gemm_f32_pp.hip): 1 = launch taken, 0 = shape not covered, < 0 error
+int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
 // conv_winograd.hip: Winograd F(2x2,3x3) for the wide 3x3 layers; U = transformed weights [16][Cout][Cin]
 bool winograd_enabled();

@@ -582,6 +582,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 // launch (grid.y = batch): the transform-domain contractions of conv_winograd.hip.  K % 16 == 0, N % 64 == 0.
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream) {
     SIMQ_REQUIRE(M > 0 && K % BK == 0 && N % 64 == 0 && batch >= 1, "gemm_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
+    if (int rc = try_gemm_batched_pp(x, w, y, M, N, K, batch, stream)) return rc < 0 ? rc : 0;     // gemm_f32_pp.hip (N % 128 == 0)
     IgemmArgs a;
     a.x = x; a.w = w;
     ConvEpilogue e;

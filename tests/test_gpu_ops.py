@@ -489,3 +489,15 @@ def test_conv_winograd_rejects_unsupported_geometry(L):
         L.lib.call('simq_conv2d_fwd_winograd', L.ptr(x), L.ptr(w), None, L.ptr(y), 1, 23, 23, 64, 64, None, L.ptr(scratch), L.stream_ptr())
     with pytest.raises(Exception, match='geometry not supported'):
         L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(y), L.ptr(w), 1, 24, 24, 64, 64, L.ptr(scratch), L.stream_ptr())
+
+
+def test_f32_pingpong_gemm_serves_winograd_layers():
+    """gemm_f32_pp.hip (LDS-DMA ping-pong form of the batched transform-domain GEMM; off by default, SIMQ_F32_PP=2 routes every
+    eligible contraction through it -- the switch is read once per process, hence the child process): the Winograd forward / wgrad
+    tests of this file must hold with it, to their unchanged bars."""
+    import os, subprocess, sys
+    env = dict(os.environ, SIMQ_F32_PP='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k', 'winograd and not pingpong'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert ' passed' in r.stdout
