@@ -67,8 +67,27 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
         float mu1 = 0.f, is1 = 0.f, mu2 = 0.f, is2 = 0.f;
         if (bnr) { mu1 = p.bnr_mean1[n]; is1 = p.bnr_invstd1[n]; }
         if (bnr2) { mu2 = p.bnr_mean2[n]; is2 = p.bnr_invstd2[n]; }
+        // the global loads of four rows first (addend, ReLU mask, pre-BN outputs: up to 4 per element), then their arithmetic and
+        // stores in the original order: element by element the loop is latency-bound (the store of one element may alias the
+        // loads of the next, so the compiler keeps them in program order -- one HBM round trip per element and wave).  Four rows
+        // at a time keeps the 96-register kernels (5 blocks per CU) free of spills; all TM * 4 at once did not.
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float adv[4], y1v[4], y2v[4];
+            bool posv[4];
+            if (p.addend || bnr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / WM) + i * 16 + 4 * fq + r;
+                    const size_t o = (size_t)(m < M ? m : M - 1) * Cout + n;
+                    adv[r] = !p.addend ? 0.f : p.addend_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.addend)[o]) : p.addend[o];
+                    if (bnr) {
+                        posv[r] = p.bnr_mask ? p.bnr_mask[o] > 0.f : (short)p.bnr_mask16[o] > 0;
+                        y1v[r] = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y1)[o]) : p.bnr_y1[o];
+                        if (bnr2) y2v[r] = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y2)[o]) : p.bnr_y2[o];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * (BM / WM) + i * 16 + 4 * fq + r;
@@ -77,20 +96,15 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
                     if (p.stats) { s0[j] += v; s1[j] += v * v; }
                     v = v * sc + sh;
                     const size_t o = (size_t)m * Cout + n;
-                    if (p.addend) v += p.addend_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.addend)[o]) : p.addend[o];
+                    if (p.addend) v += adv[r];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.y_bf16) reinterpret_cast<uint16_t*>(p.y)[o] = epi_to_bf16(v);
                     else p.y[o] = v;
                     if (bnr) {
-                        const bool pos = p.bnr_mask ? p.bnr_mask[o] > 0.f : (short)p.bnr_mask16[o] > 0;
-                        const float dz = pos ? v : 0.f;
-                        const float y1 = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y1)[o]) : p.bnr_y1[o];
+                        const float dz = posv[r] ? v : 0.f;
                         s0[j] += dz;
-                        s1[j] += dz * ((y1 - mu1) * is1);
-                        if (bnr2) {
-                            const float y2 = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y2)[o]) : p.bnr_y2[o];
-                            s2[j] += dz; s3[j] += dz * ((y2 - mu2) * is2);
-                        }
+                        s1[j] += dz * ((y1v[r] - mu1) * is1);
+                        if (bnr2) { s2[j] += dz; s3[j] += dz * ((y2v[r] - mu2) * is2); }
                     }
                 }
             }
