@@ -284,7 +284,8 @@ def main():
         'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
                   'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
         'bf16': 'igemm_bf16_img_kernel (image-tile 3x3 convolution: one 24x24 map x 128 channels per block, halo patch in LDS, ping-pong wave '
-                'groups, v_mfma_f32_16x16x32_bf16) + igemm_bf16_dma_kernel: forward + dgrad of the 128..512-channel 3x3 convolutions'}
+                'groups, v_mfma_f32_16x16x32_bf16): forward + dgrad of the 256- and 512-channel 3x3 convolutions; the 288-row LDS-DMA kernels of '
+                'the other layers are counted under all_gemm_tiles)'}
 
     def roofline_pass(step_fn, barrier_fn, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over

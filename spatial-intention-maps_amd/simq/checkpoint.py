@@ -9,9 +9,14 @@ Reference behaviour mirrored:
 
 The replay rings are stored in the reference's own host layout (a ReplayBuffer whose .buffer is a list of Transition
 records holding float32 HWC ndarrays, None for terminal next states); an observation shared by two transitions is ONE
-ndarray object, so the pickle holds it once -- the same aliasing the collector produces (train.py:61-66).  A checkpoint
-written by the reference pickles `train.ReplayBuffer` / `train.Transition`; load_checkpoint resolves those names to this
-package's classes, so such a file loads without the reference on the path.
+ndarray object, so the pickle holds it once -- the same aliasing the collector produces (train.py:61-66).
+
+Class names in the pickle, both directions: the reference's scripts run as `__main__` (`python train.py`), so THEIR files name the
+ring classes `__main__.ReplayBuffer` / `__main__.Transition` (`train.*` / `train_multiprocess.*` when imported as modules);
+load_checkpoint resolves all of those to this package's classes, so such a file loads without the reference on the path.
+save_checkpoint writes the rings under `__main__.ReplayBuffer` / `__main__.Transition` too (reference_names=True, the default):
+the reference's own `torch.load` (train.py:200) then rebuilds them as ITS classes -- same attributes (capacity, buffer, position;
+state, action, reward, next_state) -- without this package being importable.  reference_names=False keeps `simq.learner.*`.
 """
 import glob
 import os
@@ -24,7 +29,8 @@ from ._lib import SimqError
 from . import learner as _learner
 
 _REFERENCE_CLASSES = {('train', 'ReplayBuffer'): 'ReplayBuffer', ('train', 'Transition'): 'Transition',
-                      ('train_multiprocess', 'ReplayBuffer'): 'ReplayBuffer', ('train_multiprocess', 'Transition'): 'Transition'}
+                      ('train_multiprocess', 'ReplayBuffer'): 'ReplayBuffer', ('train_multiprocess', 'Transition'): 'Transition',
+                      ('__main__', 'ReplayBuffer'): 'ReplayBuffer', ('__main__', 'Transition'): 'Transition'}
 
 
 class _Unpickler(pickle.Unpickler):
@@ -35,8 +41,21 @@ class _Unpickler(pickle.Unpickler):
         return super().find_class(module, name)
 
 
+class _ReferenceNamesPickler(pickle._Pickler):
+    """Writes this package's ReplayBuffer / Transition CLASSES as the globals `__main__.ReplayBuffer` / `__main__.Transition`
+    (the names in a file written by `python train.py`); everything else as usual.  (The pure-Python pickler: the C one has no
+    hook for how a class reference is written.  Observations are bulk `bytes`, which it writes through unchanged.)"""
+
+    def save_global(self, obj, name=None):
+        alias = {_learner.ReplayBuffer: b'ReplayBuffer', _learner.Transition: b'Transition'}.get(obj) if isinstance(obj, type) else None
+        if alias is None:
+            return super().save_global(obj, name)
+        self.write(pickle.GLOBAL + b'__main__\n' + alias + b'\n')
+        self.memoize(obj)
+
+
 class _PickleModule:
-    """What torch.load wants from `pickle_module`: the pickle namespace with our Unpickler."""
+    """What torch.load / torch.save want from `pickle_module`: the pickle namespace with our Unpickler (and plain Pickler)."""
     __name__ = 'pickle'
     Unpickler = _Unpickler
     Pickler = pickle.Pickler
@@ -127,9 +146,15 @@ def save_policy(checkpoint_dir, timestep, policy_nets, intention_nets=None):
     return path
 
 
+class _ReferenceNamesPickleModule(_PickleModule):
+    Pickler = _ReferenceNamesPickler
+
+
 def save_checkpoint(checkpoint_dir, timestep, episode, optimizers, replay_buffers, optimizers_intention=None,
-                    remove_old=True):
-    """train.py:324-345: optimizer state + replay rings; older checkpoint_* files in the directory are removed."""
+                    remove_old=True, reference_names=True):
+    """train.py:324-345: optimizer state + replay rings; older checkpoint_* files in the directory are removed.
+    reference_names: the ring classes are written as `__main__.ReplayBuffer` / `__main__.Transition`, i.e. exactly what the
+    reference's scripts write and can read back (module docstring)."""
     os.makedirs(str(checkpoint_dir), exist_ok=True)
     path = os.path.join(str(checkpoint_dir), 'checkpoint_{:08d}.pth.tar'.format(timestep))
     out = {'timestep': timestep, 'episode': episode,
@@ -137,7 +162,10 @@ def save_checkpoint(checkpoint_dir, timestep, episode, optimizers, replay_buffer
            'replay_buffers': [to_host_ring(b) for b in replay_buffers]}
     if optimizers_intention is not None:
         out['optimizers_intention'] = [o.state_dict() for o in optimizers_intention]
-    torch.save(out, path)
+    if reference_names:
+        torch.save(out, path, pickle_module=_ReferenceNamesPickleModule)
+    else:
+        torch.save(out, path)
     if remove_old:
         for old in glob.glob(os.path.join(str(checkpoint_dir), 'checkpoint_*.pth.tar')):
             if os.path.abspath(old) != os.path.abspath(path):

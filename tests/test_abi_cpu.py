@@ -153,6 +153,53 @@ def test_reference_written_checkpoint_loads_without_the_reference(golden_dir):
     assert buf.position == 2 and len(buf) == 3
 
 
+def test_checkpoint_written_here_loads_in_a_reference_style_main_script(tmp_path):
+    """save_checkpoint names the ring classes `__main__.ReplayBuffer` / `__main__.Transition` -- what `python train.py` itself
+    writes (train.py:26-45 define them in the script, train.py:324-334 pickle them) -- so a process that defines those two classes
+    in its main script and calls plain torch.load (train.py:200) gets ITS classes back, without this package on the path.  The
+    child script below stands in for the reference's: a ring class with capacity / buffer / position and the 4-field Transition.
+    Our own loader reads the same file back into simq's classes."""
+    import subprocess, sys, textwrap
+    import torch
+    import simq
+    from simq import learner
+    from oracle import cases
+    ring = learner.ReplayBuffer(3)
+    for (s, a, r, ns) in cases.checkpoint_transitions():
+        ring.push(s, a, r, ns)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(3))], lr=0.1, momentum=0.9)
+    path = simq.save_checkpoint(tmp_path, 7, 2, [opt], [ring])
+    import zipfile
+    with zipfile.ZipFile(path) as z:                                          # torch.save's zip container: the pickle is data.pkl
+        raw = b''.join(z.read(n) for n in z.namelist() if n.endswith('data.pkl'))
+    assert b'__main__' in raw and b'simq' not in raw
+    child = textwrap.dedent("""
+        import sys
+        from collections import namedtuple
+        import numpy as np, torch
+        assert not any(m == 'simq' or m.startswith('simq.') for m in sys.modules)
+        Transition = namedtuple('Transition', ('state', 'action', 'reward', 'next_state'))
+        class ReplayBuffer:
+            def __init__(self, capacity):
+                self.capacity, self.buffer, self.position = capacity, [], 0
+        ck = torch.load(sys.argv[1], weights_only=False)
+        buf = ck['replay_buffers'][0]
+        assert type(buf) is ReplayBuffer and all(type(t) is Transition for t in buf.buffer), type(buf)
+        assert (ck['timestep'], ck['episode'], buf.capacity, buf.position, len(buf.buffer)) == (7, 2, 3, 1, 3)
+        assert buf.buffer[1].next_state is buf.buffer[2].state and buf.buffer[0].state.dtype == np.float32
+        print('OK', float(sum(t.state.sum() for t in buf.buffer)))
+    """)
+    r = subprocess.run([sys.executable, '-c', child, path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k != 'PYTHONPATH'}, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.startswith('OK'), r.stdout[-2000:]
+    back = simq.load_checkpoint(path)['replay_buffers'][0]
+    assert type(back) is learner.ReplayBuffer and all(type(t) is learner.Transition for t in back.buffer)
+    assert abs(float(r.stdout.split()[1]) - float(sum(t.state.sum() for t in back.buffer))) < 1e-3
+    # reference_names=False keeps this package's names (only simq.load_checkpoint / an importable simq can read those)
+    path2 = simq.save_checkpoint(tmp_path / 'own', 8, 2, [opt], [ring], reference_names=False)
+    assert type(simq.load_checkpoint(path2)['replay_buffers'][0]) is learner.ReplayBuffer
+
+
 def test_winograd_transform_matrices_are_an_exact_restatement_of_the_convolution():
     """The matrices conv_winograd.hip hard-codes (F(2x2,3x3): B^T, G, A^T and the transposes its weight gradient uses), in
     fp64 numpy: Y = A^T[(G g G^T) . (B^T d B)]A is the 3x3 correlation of a 4x4 patch, and dMt = A dY A^T, dU = dMt . V,
