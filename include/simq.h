@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 200            /* 0.2.0 */
+#define SIMQ_VERSION 201            /* 0.2.1 */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -258,6 +258,12 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const floa
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                               int batch, int hin, int win, int cin, int cout,
                               double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+/* The encoder's first convolution (reference resnet.py:94: 7x7, stride 2, pad 3, cin -> 64, no bias) on the bf16 matrix cores with
+ * the operands gathered straight from the fp32 NHWC input -- the form plain-bf16 plans use (stem_conv_bf16.hip).  7 * cin <= 63,
+ * win a multiple of 32, hin even.  d_y: bf16 [batch][hin/2][win/2][64] (pre-BatchNorm, rounded once from the fp32 accumulators);
+ * d_stats: NULL or [2*64] zeroed (sum | sum of squares of the UNROUNDED outputs); d_scratch: 58 368 bytes (bf16 weight layout). */
+int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w_ohwi, uint16_t* d_y, int batch, int hin, int win, int cin,
+                              double* d_stats, void* d_scratch, void* stream);
 /* Weight gradient of the same convolution through the transform domain (dy / x transforms, 16 batched contractions over
  * the tiles, G^T dU G).  Additionally cin % 128 == 0 and cout % 128 == 0.  d_dw is overwritten.
  * the tiles, G^T dU G); uses F(4x4,3x3) when hin, win are multiples of 4 and batch*(hin/4)*(win/4) is a multiple of 16.

@@ -144,8 +144,13 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
                     int C, hipStream_t stream, Planes pl = Planes(), Planes res_pl = Planes(), int y_bf16 = 0);
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
-                         hipStream_t stream, Planes pl = Planes());
+                         hipStream_t stream, Planes pl = Planes(), int y_bf16 = 0);
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
+// first convolution on the bf16 matrix cores, operands gathered straight from the fp32 NHWC input (stem_conv_bf16.hip)
+int stem_conv_bf16_wbytes();
+bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
+int launch_stem_weight_prep(const float* w, uint16_t* w16, int C, hipStream_t stream);
+int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, double* stats, int B, int H, int W, int C, hipStream_t stream);
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
                          int C, hipStream_t stream, int g_bf16 = 0);
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat

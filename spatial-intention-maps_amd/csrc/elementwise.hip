@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
 
 // stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
 __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, float* __restrict__ pooled,
-                                     uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4) {
+                                     uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4, int y_bf16) {
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * Ho * Wo * C4;
     // the grid stride (gridDim * 256) is a multiple of C4, so a thread keeps its 4 channels: BN coefficients once
@@ -296,7 +296,7 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, floa
             for (int dx = 0; dx < 3; ++dx) {
                 int ix = 2 * px - 1 + dx;
                 if (ix < 0 || ix >= W) continue;
-                float4 v = relu4(fma4(ld4(y + (((size_t)b * H + iy) * W + ix) * C4 * 4 + c4 * 4), sc, sh));
+                float4 v = relu4(fma4(ld4y(y, (((size_t)b * H + iy) * W + ix) * C4 + c4, y_bf16), sc, sh));
                 unsigned char s = (unsigned char)(dy * 3 + dx);
                 if (v.x > best.x) { best.x = v.x; bi.x = s; }
                 if (v.y > best.y) { best.y = v.y; bi.y = s; }
@@ -578,12 +578,12 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
 }
 
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
-                         hipStream_t stream, Planes pl) {
+                         hipStream_t stream, Planes pl, int y_bf16) {
     SIMQ_REQUIRE(C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && 256 % (C / 4) == 0, "stem_pool: bad shape");
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     SIMQ_REQUIRE(total < 2147483648ull, "stem_pool: tensor too large for 32-bit indexing");
     hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, y, bn, pooled, idx, pl, B, H,
-                       W, C / 4);
+                       W, C / 4, y_bf16);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -182,10 +182,10 @@ Layout make_layout(const simq_plan* p, int B) {
 // Weight cache (caller-owned, one per parameter set): derived copies of the convolution weights that only change when
 // the parameters do -- fp32: flipped/transposed weights for dgrad; matrix-core precisions: bf16 planes of the weights
 // and of their flipped/transposed form.  Filled by simq_weights_prepare.
-struct WLayout { int64_t wt, wpl, wtpl, wu, total; };
+struct WLayout { int64_t wt = -1, wpl = -1, wtpl = -1, wu = -1, stem16 = -1, total = 0; };
 WLayout make_wlayout(const simq_plan* p) {
     WLayout W;
-    W.wt = W.wpl = W.wtpl = W.wu = -1;
+    W.wt = W.wpl = W.wtpl = W.wu = W.stem16 = -1;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
     if (p->precision == SIMQ_PREC_FP32) {
@@ -195,6 +195,11 @@ WLayout make_wlayout(const simq_plan* p) {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
         W.wpl = take(p->wp_total * h);
         W.wtpl = take(p->wp_total * h);
+        // plain-bf16 plans: the first convolution's weights in the layout of stem_conv_bf16.hip (SIMQ_NO_STEM16=1: fp32 kernel)
+        static const bool no_stem16 = getenv("SIMQ_NO_STEM16") != nullptr;
+        if (p->precision == SIMQ_PREC_BF16 && !no_stem16 &&
+            stem_conv_bf16_eligible(96, 96, p->stem.cin, p->stem.cout, p->stem.k, p->stem.stride, p->stem.pad))
+            W.stem16 = take(stem_conv_bf16_wbytes());
     }
     W.total = off;
     return W;
@@ -376,10 +381,17 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const int64_t rows = (int64_t)B * 576;
     // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97); always the fp32 kernel (Cin is 3..10)
     Act x0; x0.f = c.f(L.x);
-    RC(conv_bn(c, p->stem, p->stem_bn, mode, x0, c.f(L.y0), 96));
+    const int stem16 = c.W.stem16 >= 0 ? 1 : 0;      // plain-bf16 plans: bf16 matrix cores, bf16 pre-BN output (stem_conv_bf16.hip)
+    if (stem16) {
+        RC(launch_stem_conv_bf16(x0.f, reinterpret_cast<const uint16_t*>(c.wc + c.W.stem16), reinterpret_cast<uint16_t*>(c.f(L.y0)),
+                                 mode != SIMQ_MODE_EVAL ? c.red(p->stem_bn) : nullptr, B, 96, 96, p->cin, c.stream));
+        if (mode != SIMQ_MODE_EVAL) RC(c.sync_reduce(c.red(p->stem_bn), 2 * (int64_t)p->stem_bn.C));
+    } else {
+        RC(conv_bn(c, p->stem, p->stem_bn, mode, x0, c.f(L.y0), 96));
+    }
     Act cur = c.act(L.pooled, L.p_pooled, rows * 64);
     RC(launch_stem_pool_fwd(c.f(L.y0), bnref(c, p->stem_bn, mode, (int64_t)B * 2304), cur.f,
-                            reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl));
+                            reinterpret_cast<uint8_t*>(c.ws + L.idx), B, 48, 48, 64, c.stream, cur.pl, stem16));
     // eval mode, fp32 arithmetic: BatchNorm folded into the convolution epilogues (no bn_apply launches, no pre-BN
     // round trip through HBM); the matrix-core precisions keep bn_apply, which also writes their bf16 planes
     // ... and so do plain-bf16 plans when only the planes of the block activations are kept (conv_bn_folded_planes)
@@ -614,7 +626,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     Act T1; T1.f = S[(gi + 2) & 3];
     Act x0; x0.f = c.f(L.x);
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf()));
-    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, 0));   // (the stem conv is fp32)
+    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, c.W.stem16 >= 0 ? 1 : 0));   // (pre-BN output: fp32, or bf16 from stem_conv_bf16)
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
     return 0;
 }
@@ -761,9 +773,12 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
         return launch_wino_weight_all(d_params, reinterpret_cast<const float*>(wc + W.wt), reinterpret_cast<float*>(wc + W.wu), t,
                                       static_cast<hipStream_t>(stream));
     }
-    return launch_weight_prep_all(d_params, weight_table(plan), nullptr, reinterpret_cast<uint16_t*>(wc + W.wpl),
-                                  reinterpret_cast<uint16_t*>(wc + W.wtpl), plan->np(), plan->wp_total,
-                                  static_cast<hipStream_t>(stream));
+    RC(launch_weight_prep_all(d_params, weight_table(plan), nullptr, reinterpret_cast<uint16_t*>(wc + W.wpl),
+                              reinterpret_cast<uint16_t*>(wc + W.wtpl), plan->np(), plan->wp_total, static_cast<hipStream_t>(stream)));
+    if (W.stem16 >= 0)
+        RC(launch_stem_weight_prep(d_params + plan->stem.w_off, reinterpret_cast<uint16_t*>(wc + W.stem16), plan->stem.cin,
+                                   static_cast<hipStream_t>(stream)));
+    return 0;
 }
 
 int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf,
@@ -1018,6 +1033,15 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w, uint16_t* d_y, int batch, int hin, int win, int cin, double* d_stats,
+                              void* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_x && d_w && d_y && d_scratch && batch >= 1, "conv2d_fwd_stem_bf16: bad argument");
+    SIMQ_REQUIRE(stem_conv_bf16_eligible(hin, win, cin, 64, 7, 2, 3), "conv2d_fwd_stem_bf16: geometry not supported (7 * cin <= 63, win %% 32 == 0)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RC(launch_stem_weight_prep(d_w, static_cast<uint16_t*>(d_scratch), cin, st));
+    return launch_stem_conv_bf16(d_x, static_cast<const uint16_t*>(d_scratch), d_y, d_stats, batch, hin, win, cin, st);
 }
 
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,

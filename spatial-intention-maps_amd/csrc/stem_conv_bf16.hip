@@ -1,0 +1,223 @@
+// First convolution of the encoder (reference resnet.py:94: conv 7x7, stride 2, pad 3, Cin = 3..9 -> 64, no bias) on the bf16 matrix
+// cores, for plain-bf16 plans.  The implicit-GEMM kernels need Cin % 32 == 0; with 3..9 input channels the fp32 kernel gathers its
+// operands one float at a time (169 us at B = 128: 55 TF/s).  What this kernel uses instead:
+//
+//   * In NHWC the 7 taps x Cin channels of one filter ROW are 7*Cin CONTIGUOUS floats of x (35 at Cin = 5), starting at pixel
+//     (2 oy + ky - 3, 2 ox - 3).  A row of the im2col matrix is therefore 7 contiguous runs, and the contraction becomes, per filter
+//     row ky, K = 64 (7*Cin real values, zero weights behind them): two v_mfma_f32_16x16x32_bf16 k-steps.
+//   * The A fragment of that MFMA is 8 consecutive k per lane = 8 consecutive floats of x: every lane loads its fragment STRAIGHT from
+//     global memory (two dword-aligned global_load_dwordx4), masks the elements that fall outside the image row (left / right padding;
+//     rows above / below the image are skipped per tile), converts to bf16 and feeds the matrix core.  No LDS for activations, no
+//     packed copy of x.  k-groups that lie entirely behind the 7*Cin real values are not loaded (their weights are zero).
+//   * The weights (64 x 7 x 64 bf16, rows padded to 456 elements: conflict-free ds_read_b128) sit in LDS for the lifetime of a block;
+//     blocks are persistent (grid-stride over 32-pixel wave tiles), so the weights are staged and the BatchNorm batch statistics of the
+//     block (fp32 per lane -> fp64 per block) are pushed with atomics ONCE per block.
+//   * Output: the pre-BatchNorm map as bf16 (like every other matrix-core convolution of a plain-bf16 plan; statistics from the fp32
+//     accumulators).
+#include <cstdint>
+
+#include "common.h"
+
+namespace simq {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte load the compiler may not assume aligned
+
+constexpr int COUT = 64, R = 7, KROW = 64;            // K per filter row (7 * Cin <= 63 real)
+constexpr int WROW = R * KROW + 8;                     // LDS row of one output channel: 456 bf16 = 228 dwords (36 mod 64: conflict-free)
+constexpr int SMEM_W = COUT * WROW * 2;                // 58 368 B
+
+struct StemArgs {
+    const float* x; const uint16_t* w16; uint16_t* y; double* stats;
+    int B, H, W, C, Ho, Wo;
+    unsigned x_bytes;
+};
+
+constexpr int NWAVE = 8;                               // waves per block (they share the LDS copy of the weights)
+
+__global__ void __launch_bounds__(NWAVE * 64, 2) stem_conv_bf16_kernel(const StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    double* red = reinterpret_cast<double*>(smem + SMEM_W);          // [NWAVE][64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // weights -> LDS (the prepared layout is already [cout][WROW])
+    for (int i = tid; i < COUT * WROW / 8; i += NWAVE * 64)
+        reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.w16)[i];
+    __syncthreads();
+
+    const long total = (long)p.B * p.H * p.W * p.C;                  // floats in x
+    const int fi = lane & 15, kg = lane >> 4;
+    const int rowf = p.W * p.C;                                      // floats per image row
+    const int kreal = R * p.C;                                       // real k per filter row
+    const int tiles_per_row = p.Wo / 16;
+    const int ntiles = p.B * p.Ho * tiles_per_row;                   // 16-pixel tiles
+    const int npairs = (ntiles + 1) / 2;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint16_t* wfrag = wl + fi * WROW + kg * 8;                  // + j * 16 * WROW + ky * KROW + s * 32
+
+    for (int pair = blockIdx.x * NWAVE + wave; pair < npairs; pair += gridDim.x * NWAVE) {
+        floatx4 acc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // per tile: output row, image; per lane: pointer to the first float of its k-group at filter row 0 (may lie outside the tensor:
+        // rows above / below the image are skipped before it is used), and for both k-steps how many leading / trailing elements of
+        // its 8-float fragment fall outside the image row (left / right padding) -- none of this depends on the filter row
+        int oy[2], b[2];
+        const float* prow[2];
+        int e_lo[2];
+        bool live[2];
+        unsigned long long border[2][2];                             // lanes whose fragment needs masking, per tile and k-step (ballot)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tile = pair * 2 + t;
+            live[t] = tile < ntiles;
+            const int tt = live[t] ? tile : 0;
+            const int ox0 = (tt % tiles_per_row) * 16;
+            const int r = tt / tiles_per_row;
+            oy[t] = r % p.Ho; b[t] = r / p.Ho;
+            e_lo[t] = (2 * (ox0 + fi) - 3) * p.C + kg * 8;
+            prow[t] = p.x + ((long)(b[t] * p.H + 2 * oy[t] - 3) * rowf + e_lo[t]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int e = e_lo[t] + s * 32;
+                border[t][s] = __builtin_amdgcn_ballot_w64((e < 0 || e + 8 > rowf) && s * 32 + kg * 8 < kreal);
+            }
+        }
+        // fragment (t, s) of filter row ky as 8 floats: straight from global memory, padding masked
+        auto load_frag = [&](int t, int s, int ky, float (&v)[8]) {
+            const int k0 = s * 32 + kg * 8;                           // this lane's first k inside the filter row
+            const int iy = 2 * oy[t] + ky - 3;
+            const bool rowok = live[t] && (unsigned)iy < (unsigned)p.H;               // wave-uniform per tile
+            // the first row of the first image and the last row of the last: a fragment may reach outside the tensor
+            const bool tensor_edge = (b[t] == 0 && iy == 0) || (b[t] == p.B - 1 && iy == p.H - 1);   // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            if (rowok && k0 < kreal) {
+                const float* src = prow[t] + (ky * rowf + s * 32);
+                if (!tensor_edge) {
+                    // dword-aligned 16-byte loads: the window starts at (2 ox - 3) * C floats, 16-byte aligned only for C % 4 == 0
+                    // (buffer loads need natural alignment; global loads do not)
+                    const floatx4_a4 lo = *reinterpret_cast<const floatx4_a4*>(src), hi = *reinterpret_cast<const floatx4_a4*>(src + 4);
+                    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                } else {
+                    const long g0 = src - p.x;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (g0 + q >= 0 && g0 + q < total) ? src[q] : 0.f;
+                }
+                if (border[t][s]) {                                    // wave-uniform: some lane touches the left / right padding
+                    const int e = e_lo[t] + s * 32;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = ((unsigned)(e + q) < (unsigned)rowf) ? v[q] : 0.f;
+                }
+            }
+        };
+        // (measured at B = 128: 8 waves per block 43 us, 4 waves 60 us -- the loop is a chain of load latencies, occupancy hides them;
+        // requesting row ky + 1 before the MFMAs of row ky costs 50 registers and one resident wave per SIMD: 57 us; fully unrolled
+        // it spills: 93 us)
+#pragma unroll 1
+        for (int ky = 0; ky < R; ++ky) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v[8];
+                    load_frag(t, s, ky, v);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) af[t][q] = (__bf16)v[q];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wfrag + j * 16 * WROW + ky * KROW + s * 32);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+        // ---- store (bf16) + statistics: lane holds column fi of N-tile j, rows 4 kg + r of tile t
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!live[t]) continue;
+            const size_t m0 = (size_t)(pair * 2 + t) * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[t][j][r];
+                    s0[j] += v; s1[j] += v * v;
+                    p.y[(m0 + 4 * kg + r) * COUT + j * 16 + fi] = __builtin_bit_cast(uint16_t, (__bf16)v);
+                }
+        }
+    }
+    if (!p.stats) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = s0[j], c = s1[j];
+        a += __shfl_xor(a, 16); c += __shfl_xor(c, 16);
+        a += __shfl_xor(a, 32); c += __shfl_xor(c, 32);
+        if (kg == 0) { red[(wave * COUT + j * 16 + fi) * 2] = (double)a; red[(wave * COUT + j * 16 + fi) * 2 + 1] = (double)c; }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+        double a = 0.0, c = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { a += red[(w * COUT + tid) * 2]; c += red[(w * COUT + tid) * 2 + 1]; }
+        unsafeAtomicAdd(p.stats + tid, a);
+        unsafeAtomicAdd(p.stats + COUT + tid, c);
+    }
+}
+
+// w [64][7][7][C] fp32 (OHWI) -> w16 [64][WROW] bf16: element ky * 64 + kx * C + c, zeros elsewhere
+__global__ void stem_weight_prep_kernel(const float* __restrict__ w, uint16_t* __restrict__ w16, int C) {
+    const int total = COUT * WROW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i / WROW, e = i - o * WROW;
+        const int ky = e / KROW, n = e - ky * KROW;
+        float v = 0.f;
+        if (ky < R && n < R * C) v = w[((size_t)o * R + ky) * R * C + n];
+        w16[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+}
+
+}  // namespace
+
+int stem_conv_bf16_wbytes() { return COUT * WROW * 2; }
+
+bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad) {
+    return cout == COUT && k == R && stride == 2 && pad == 3 && C >= 1 && R * C <= KROW - 1 && H % 2 == 0 && W % 32 == 0;
+}
+
+int launch_stem_weight_prep(const float* w, uint16_t* w16, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(stem_weight_prep_kernel, dim3(32), dim3(256), 0, stream, w, w16, C);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+// y: bf16 [B][H/2][W/2][64];  stats: NULL or [2 * 64] doubles (accumulated into)
+int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, double* stats, int B, int H, int W, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(stem_conv_bf16_eligible(H, W, C, COUT, R, 2, 3), "stem_conv_bf16: shape %dx%dx%d not covered", H, W, C);
+    const double xb = 4.0 * B * H * W * C;
+    SIMQ_REQUIRE(xb < 4294967000.0, "stem_conv_bf16: input exceeds the 4 GiB buffer-addressing limit");
+    StemArgs p;
+    p.x = x; p.w16 = w16; p.y = y; p.stats = stats;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = H / 2; p.Wo = W / 2;
+    p.x_bytes = (unsigned)xb;
+    const int npairs = (B * p.Ho * (p.Wo / 16) + 1) / 2;
+    int blocks = (npairs + NWAVE - 1) / NWAVE;
+    if (blocks > 512) blocks = 512;                                   // two persistent blocks per CU
+    static bool attr_set = false;
+    const int smem = SMEM_W + NWAVE * COUT * 2 * (int)sizeof(double);
+    if (!attr_set) {
+        SIMQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(blocks), dim3(NWAVE * 64), smem, stream, p);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace simq

@@ -256,7 +256,7 @@ def test_reference_style_main_loop_on_synthetic_env(simq_mod, tmp_path, intentio
     if intention:
         for a, b in zip(policy.intention_nets, resumed.intention_nets):
             assert torch.equal(a.flat_params, b.flat_params)
-    ck = torch.load(checkpoint_path, weights_only=False)
+    ck = simq_mod.load_checkpoint(checkpoint_path)       # (the rings are pickled under the reference scripts' `__main__.*` names)
     opt = torch.optim.SGD(resumed.policy_nets[0].parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     opt.load_state_dict(ck['optimizers'][0])
     assert len(opt.state) > 0

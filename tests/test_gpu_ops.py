@@ -491,6 +491,34 @@ def test_conv_winograd_rejects_unsupported_geometry(L):
         L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(y), L.ptr(w), 1, 24, 24, 64, 64, L.ptr(scratch), L.stream_ptr())
 
 
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1'])
+def test_stem_conv_bf16_matches_a_bf16_operand_convolution(L, B, C):
+    """stem_conv_bf16.hip (reference resnet.py:94: conv 7x7 s2 p3 -> 64, the form plain-bf16 plans run): fragments gathered straight from
+    the fp32 NHWC input (7*C contiguous floats per filter row, left / right / top / bottom padding by masks), bf16 operands, fp32
+    accumulation.  Against an fp64 convolution of the bf16-ROUNDED input and weights the only error left is the accumulation order and
+    the final bf16 rounding of the stored output (2^-9 relative); the batch statistics come from the unrounded accumulators.  The
+    input carries a large value at every image corner and edge so that a wrong padding mask cannot hide."""
+    g = torch.Generator().manual_seed(41 + 7 * C + B)
+    x = torch.randn(B, 96, 96, C, generator=g)
+    x[:, 0, :, :] += 3.0; x[:, -1, :, :] -= 3.0; x[:, :, 0, :] += 5.0; x[:, :, -1, :] -= 5.0
+    w = torch.randn(64, 7, 7, C, generator=g) * (2.0 / (49 * C)) ** 0.5
+    xd, wd = x.cuda(), w.cuda()
+    y = torch.full((B, 48, 48, 64), float('nan'), dtype=torch.bfloat16, device='cuda')
+    stats = torch.zeros(128, dtype=torch.float64, device='cuda')
+    scratch = torch.empty(58368, dtype=torch.uint8, device='cuda')
+    L.lib.call('simq_conv2d_fwd_stem_bf16', L.ptr(xd), L.ptr(wd), L.ptr(y), B, 96, 96, C, L.ptr(stats), L.ptr(scratch), L.stream_ptr())
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), None, stride=2, padding=3).permute(0, 2, 3, 1)
+    got = y.double().cpu()
+    assert torch.isfinite(got).all()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    print('\nstem bf16 C=%d B=%d: max error vs fp64 conv of the rounded operands %.3g of the output range' % (C, B, err))
+    assert err < 2.0 ** -8                                                   # one bf16 rounding of the output (+ fp32 accumulation)
+    sref = torch.cat([ref.reshape(-1, 64).sum(0), (ref * ref).reshape(-1, 64).sum(0)])
+    assert rel(stats.cpu(), sref) < 1e-5                                     # statistics: from the fp32 accumulators
+
+
 def test_f32_pingpong_gemm_serves_winograd_layers():
     """gemm_f32_pp.hip (LDS-DMA ping-pong form of the batched transform-domain GEMM; off by default, SIMQ_F32_PP=2 routes every
     eligible contraction through it -- the switch is read once per process, hence the child process): the Winograd forward / wgrad
