@@ -264,6 +264,11 @@ int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const flo
  * d_stats: NULL or [2*64] zeroed (sum | sum of squares of the UNROUNDED outputs); d_scratch: 58 368 bytes (bf16 weight layout). */
 int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w_ohwi, uint16_t* d_y, int batch, int hin, int win, int cin,
                               double* d_stats, void* d_scratch, void* stream);
+/* Weight gradient of that convolution from the bf16 plane of dy (bf16 [batch][hin/2][win/2][64]): both operands staged transposed in
+ * LDS, contraction over pixels on the bf16 matrix cores, per-block partial sums added in a fixed order (deterministic).
+ * d_dw: [64][7][7][cin] fp32, overwritten.  d_scratch: min(512, ceil(batch * hin/2 * win/32 / 16)) * 64 * 49 * cin floats. */
+int simq_conv2d_wgrad_stem_bf16(const float* d_x, const uint16_t* d_dy, float* d_dw, int batch, int hin, int win, int cin,
+                                float* d_scratch, void* stream);
 /* Weight gradient of the same convolution through the transform domain (dy / x transforms, 16 batched contractions over
  * the tiles, G^T dU G).  Additionally cin % 128 == 0 and cout % 128 == 0.  d_dw is overwritten.
  * the tiles, G^T dU G); uses F(4x4,3x3) when hin, win are multiples of 4 and batch*(hin/4)*(win/4) is a multiple of 16.

@@ -151,6 +151,8 @@ int stem_conv_bf16_wbytes();
 bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
 int launch_stem_weight_prep(const float* w, uint16_t* w16, int C, hipStream_t stream);
 int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, double* stats, int B, int H, int W, int C, hipStream_t stream);
+int stem_wgrad_bf16_slabs(int B, int H, int W);      // partial-sum slabs (64 * 49 * C floats each) the weight gradient needs as scratch
+int launch_stem_wgrad_bf16(const float* x, const uint16_t* dy, float* dw, float* partial, int B, int H, int W, int C, hipStream_t stream);
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
                          int C, hipStream_t stream, int g_bf16 = 0);
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat

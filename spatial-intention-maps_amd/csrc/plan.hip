@@ -624,9 +624,13 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     float* G = S[gi];
     float* T0 = S[(gi + 1) & 3];
     Act T1; T1.f = S[(gi + 2) & 3];
+    const bool stem16 = c.W.stem16 >= 0;             // plain-bf16 plans: dy as a bf16 plane only, weight gradient on the bf16 matrix cores
+    if (stem16) { T1 = dyact(S[(gi + 2) & 3], 1); T1.fv = false; }
     Act x0; x0.f = c.f(L.x);
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf()));
     RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, c.W.stem16 >= 0 ? 1 : 0));   // (pre-BN output: fp32, or bf16 from stem_conv_bf16)
+    if (stem16)                                      // (T0 = dz is dead behind bn_bwd: it holds the partial-sum slabs)
+        return launch_stem_wgrad_bf16(x0.f, T1.pl.hi, c.grads + p->stem.w_off, T0, B, 96, 96, p->cin, c.stream);
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
     return 0;
 }
@@ -1042,6 +1046,13 @@ int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w, uint16_t* d_y,
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_stem_weight_prep(d_w, static_cast<uint16_t*>(d_scratch), cin, st));
     return launch_stem_conv_bf16(d_x, static_cast<const uint16_t*>(d_scratch), d_y, d_stats, batch, hin, win, cin, st);
+}
+
+int simq_conv2d_wgrad_stem_bf16(const float* d_x, const uint16_t* d_dy, float* d_dw, int batch, int hin, int win, int cin, float* d_scratch,
+                                void* stream) {
+    SIMQ_REQUIRE(d_x && d_dy && d_dw && d_scratch && batch >= 1, "conv2d_wgrad_stem_bf16: bad argument");
+    SIMQ_REQUIRE(stem_conv_bf16_eligible(hin, win, cin, 64, 7, 2, 3), "conv2d_wgrad_stem_bf16: geometry not supported (7 * cin <= 63, win %% 32 == 0)");
+    return launch_stem_wgrad_bf16(d_x, d_dy, d_dw, d_scratch, batch, hin, win, cin, static_cast<hipStream_t>(stream));
 }
 
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,

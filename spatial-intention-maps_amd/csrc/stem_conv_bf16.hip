@@ -183,7 +183,161 @@ __global__ void stem_weight_prep_kernel(const float* __restrict__ w, uint16_t* _
     }
 }
 
+// ---- weight gradient of the same convolution -------------------------------------------------------------------------------------
+//   dW[o][ky][n] = sum over output pixels of dy[pix][o] * xrow_ky[pix][n],   n = kx * C + c < 7 C
+// The contraction runs over PIXELS, so the MFMA operands need 8 consecutive pixels per lane -- strided in both tensors.  Per chunk of
+// 32 output pixels a block therefore stages both operands TRANSPOSED in LDS: dyT [64 o][32 pix] from the bf16 plane of dy, and for each
+// filter row XT_ky [64 n][32 pix], filled by the forward kernel's fragment gather (8 consecutive floats of x per (pixel, k-group),
+// padding masked, converted) with the 8 values scattered to 8 LDS rows.  After one barrier wave ky contracts its filter row:
+// 4 + 4 ds_read_b128 fragments, 16 MFMAs (64 x 64 outputs over k = 32 pixels).  Blocks are persistent; every block leaves its 64 x 7 x 7C
+// partial sums in a scratch slab and a second launch adds the slabs in a fixed order (deterministic; atomics over 15 680 addresses
+// from 512 blocks would be neither that nor fast).
+constexpr int TROW = 40;                               // LDS row: 32 pixels + 8 pad (80 B: conflict-free ds_read_b128 over 16 rows)
+constexpr int WG_SMEM = (COUT + R * KROW) * TROW * 2;  // dyT + 7 x XT = 40 960 B
+constexpr int WG_WAVES = 8;
+
+struct StemWgradArgs {
+    const float* x; const uint16_t* dy; float* partial;
+    int B, H, W, C, Ho, Wo;
+};
+
+__global__ void __launch_bounds__(WG_WAVES * 64, 2) stem_wgrad_bf16_kernel(const StemWgradArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[WG_SMEM / 2];
+    uint16_t* dyT = lds;                                // [64][TROW]
+    uint16_t* XT = lds + COUT * TROW;                   // [7][64][TROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rowf = p.W * p.C, kreal = R * p.C;
+    const int ngrp = (kreal + 7) / 8;                   // k-groups of a filter row that hold real values
+    const long total = (long)p.B * p.H * p.W * p.C;
+    const int tiles_per_row = p.Wo / 16;
+    const int ntiles = p.B * p.Ho * tiles_per_row;
+    const int nchunks = (ntiles + 1) / 2;
+    const int fi = lane & 15, kg = lane >> 4;
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // ---- stage dyT: 32 pixels x 64 channels; lane -> (pixel, 8-channel group), 16-byte load, 8 scattered 2-byte stores
+        if (tid < 256) {
+            const int pix = tid >> 3, cg = tid & 7;
+            const int tile = chunk * 2 + (pix >> 4);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tile < ntiles) v = *reinterpret_cast<const uint4*>(p.dy + ((size_t)tile * 16 + (pix & 15)) * COUT + cg * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dyT[(cg * 8 + q) * TROW + pix] = (uint16_t)(q & 1 ? w[q >> 1] >> 16 : w[q >> 1] & 0xffffu);
+        }
+        // ---- stage XT: slots (ky, tile, pixel, k-group); only the k-groups with real values (the others feed discarded columns)
+        for (int f = tid; f < R * 2 * 16 * 8; f += WG_WAVES * 64) {
+            const int grp = f & 7, i = (f >> 3) & 15, t = (f >> 7) & 1, ky = f >> 8;
+            if (grp >= ngrp) continue;
+            const int tile = chunk * 2 + t;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (tile < ntiles) {
+                const int ox0 = (tile % tiles_per_row) * 16;
+                const int r = tile / tiles_per_row;
+                const int oy = r % p.Ho, b = r / p.Ho;
+                const int iy = 2 * oy + ky - 3;
+                if ((unsigned)iy < (unsigned)p.H) {
+                    const int e = (2 * (ox0 + i) - 3) * p.C + grp * 8;                 // first float of the fragment inside the image row
+                    const long g0 = (long)(b * p.H + iy) * rowf + e;
+                    if (g0 >= 0 && g0 + 8 <= total) {
+                        const floatx4_a4 lo = *reinterpret_cast<const floatx4_a4*>(p.x + g0), hi = *reinterpret_cast<const floatx4_a4*>(p.x + g0 + 4);
+                        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = (g0 + q >= 0 && g0 + q < total) ? p.x[g0 + q] : 0.f;
+                    }
+                    if (e < 0 || e + 8 > rowf) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = ((unsigned)(e + q) < (unsigned)rowf) ? v[q] : 0.f;   // left / right padding
+                    }
+                }
+            }
+            uint16_t* dst = XT + (ky * KROW + grp * 8) * TROW + t * 16 + i;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q * TROW] = __builtin_bit_cast(uint16_t, (__bf16)v[q]);
+        }
+        __syncthreads();
+        // ---- wave ky: out[o][n] += sum over the 32 pixels of dyT[o][pix] * XT_ky[n][pix]
+        if (wave < R) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                af[j] = *reinterpret_cast<const bf16x8*>(dyT + (j * 16 + fi) * TROW + kg * 8);
+                bf[j] = *reinterpret_cast<const bf16x8*>(XT + (wave * KROW + j * 16 + fi) * TROW + kg * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- this block's partial sums: slab [64 o][7 ky][7 C]; lane holds out[o = i * 16 + 4 kg + r][n = j * 16 + fi]
+    if (wave < R) {
+        float* slab = p.partial + (size_t)blockIdx.x * COUT * R * kreal;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = i * 16 + 4 * kg + r, n = j * 16 + fi;
+                    if (n < kreal) slab[((size_t)o * R + wave) * kreal + n] = acc[i][j][r];
+                }
+    }
+}
+
+// dw[e] = sum over the slabs (overwrites dw): 64 outputs x 4 slab lanes per block -- lane q adds slabs q, q + 4, ... (four loads in
+// flight), the four partial sums are combined in lane order: a fixed summation tree, the same bits on every run
+__global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n, int slabs) {
+    __shared__ float sm[256];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n) {
+        int s = q;
+        for (; s + 12 < slabs; s += 16) {
+            a0 += partial[(size_t)s * n + e]; a1 += partial[(size_t)(s + 4) * n + e];
+            a2 += partial[(size_t)(s + 8) * n + e]; a3 += partial[(size_t)(s + 12) * n + e];
+        }
+        for (; s < slabs; s += 4) a0 += partial[(size_t)s * n + e];
+    }
+    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && e < n) dw[e] = (sm[threadIdx.x] + sm[threadIdx.x + 64]) + (sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+}
+
 }  // namespace
+
+// slabs the weight-gradient launch will use for this batch (the caller provides slabs * 64 * 49 * C floats of scratch)
+int stem_wgrad_bf16_slabs(int B, int H, int W) {
+    const int nchunks = (B * (H / 2) * (W / 32) + 1) / 2;
+    int blocks = (nchunks + 7) / 8;                                   // >= 8 chunks per block
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+// dy: bf16 [B][H/2][W/2][64];  dw: [64][7][7][C] fp32 (overwritten);  partial: stem_wgrad_bf16_slabs() * 64 * 49 * C floats
+int launch_stem_wgrad_bf16(const float* x, const uint16_t* dy, float* dw, float* partial, int B, int H, int W, int C, hipStream_t stream) {
+    SIMQ_REQUIRE(stem_conv_bf16_eligible(H, W, C, COUT, R, 2, 3), "stem_wgrad_bf16: shape %dx%dx%d not covered", H, W, C);
+    SIMQ_REQUIRE(4.0 * B * H * W * C < 4294967000.0, "stem_wgrad_bf16: input too large");
+    StemWgradArgs p;
+    p.x = x; p.dy = dy; p.partial = partial;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = H / 2; p.Wo = W / 2;
+    const int slabs = stem_wgrad_bf16_slabs(B, H, W);
+    hipLaunchKernelGGL(stem_wgrad_bf16_kernel, dim3(slabs), dim3(WG_WAVES * 64), 0, stream, p);
+    SIMQ_CHECK_LAUNCH();
+    const int n = COUT * R * R * C;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, partial, dw, n, slabs);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
 
 int stem_conv_bf16_wbytes() { return COUT * WROW * 2; }
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """GPU: repeated train() steps on ONE fixed minibatch (target net fixed), fp32 vs bf16 plans from the same initial weights -- does the
-TD loss fall the same way?   usage: overfit_check.py [steps] [B]   (PRECS=fp32,bf16,bf16x3)
+TD loss fall the same way?   usage: tests/diag/overfit_check.py [steps] [B]   (PRECS=fp32,bf16,bf16x3)
 Finding (round 2): the problem is chaotic -- momentum 0.9, double-DQN argmax flips, TD errors of O(1) per transition.  90 steps at B = 16:
 HIP fp32 ends at 0.33, the reference's own fp32 modules on the CPU at 3.5 (mean of the last 20 steps 4.5), the reference under
 torch.autocast(bf16) at 7.1, HIP bf16x3 at 1.4, HIP bf16 between 1.6 and 18 from run to run (atomics order).  Trajectories separate
 after ~10 steps whatever the arithmetic, so this is a smoke check for finiteness, not a parity measure; tests/golden G8 is."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import numpy as np, torch
 import simq

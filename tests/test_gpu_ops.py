@@ -519,6 +519,36 @@ def test_stem_conv_bf16_matches_a_bf16_operand_convolution(L, B, C):
     assert rel(stats.cpu(), sref) < 1e-5                                     # statistics: from the fp32 accumulators
 
 
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (1, 9), (5, 1), (19, 5)], ids=['cin4', 'cin5', 'cin9', 'cin1', 'cin5_b19'])
+def test_stem_wgrad_bf16_matches_a_bf16_operand_weight_gradient(L, B, C):
+    """Weight gradient of the first convolution on the bf16 matrix cores (stem_conv_bf16.hip: dy plane and the gathered row fragments
+    of x staged TRANSPOSED in LDS, contraction over pixels, per-block slabs added in a fixed order): against the fp64 weight gradient
+    of the bf16-ROUNDED operands only the fp32 accumulation order is left (1e-5 of the gradient's range); two runs are bit-identical
+    (no atomics).  Large values on the image borders expose a wrong padding mask."""
+    g = torch.Generator().manual_seed(43 + 7 * C + B)
+    x = torch.randn(B, 96, 96, C, generator=g)
+    x[:, 0, :, :] += 3.0; x[:, -1, :, :] -= 3.0; x[:, :, 0, :] += 5.0; x[:, :, -1, :] -= 5.0
+    dy = torch.randn(B, 48, 48, 64, generator=g).bfloat16()
+    xd, dyd = x.cuda(), dy.cuda()
+    dw = torch.full((64, 7, 7, C), float('nan'), device='cuda')
+    scratch = torch.empty(512 * 64 * 49 * C, device='cuda')
+    call = lambda out: L.lib.call('simq_conv2d_wgrad_stem_bf16', L.ptr(xd), L.ptr(dyd), L.ptr(out), B, 96, 96, C, L.ptr(scratch), L.stream_ptr())
+    call(dw)
+    dw2 = torch.empty_like(dw)
+    call(dw2)
+    assert torch.equal(dw, dw2)
+    xr = x.bfloat16().double().permute(0, 3, 1, 2).requires_grad_(False)
+    w = torch.zeros(64, C, 7, 7, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xr, w, None, stride=2, padding=3)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1)
+    got = dw.double().cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print('\nstem wgrad bf16 C=%d B=%d: max error vs fp64 gradient of the rounded operands %.3g of the range' % (C, B, err))
+    assert err < 1e-4
+
+
 def test_f32_pingpong_gemm_serves_winograd_layers():
     """gemm_f32_pp.hip (LDS-DMA ping-pong form of the batched transform-domain GEMM; off by default, SIMQ_F32_PP=2 routes every
     eligible contraction through it -- the switch is read once per process, hence the child process): the Winograd forward / wgrad
