@@ -179,7 +179,9 @@ int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, flo
 // q (NCHW 96x96) = bilinear x2 of z (NCHW 48x48) + bias: the commuted last layer (head.hip)
 int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, int Cout, hipStream_t stream);
 int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
-                           float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream);
+                           float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream,
+                           const float* ypre = nullptr, int ypre_bf16 = 0, const float* mean = nullptr, const float* invstd = nullptr,
+                           double* red = nullptr);   // red: fused BN-backward sums of the BatchNorm in front (hb2)
 int launch_head_conv3_bwd(const float* x, const float* w, const float* dq, float* dx, float* dw, float* dbias,
                           int B, int HW, int Cin, int Cout, hipStream_t stream);
 

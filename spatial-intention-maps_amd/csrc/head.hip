@@ -109,7 +109,8 @@ __device__ __forceinline__ void lerp2x(int o, int in_size, float scale, int& i0,
 __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __restrict__ ah2, const float* __restrict__ w3,
                                                              const int64_t* __restrict__ action, const float* __restrict__ q_sa,
                                                              const float* __restrict__ y, float grad_scale, float* ds1, float* dw3,
-                                                             float* db3, int Cout) {
+                                                             float* db3, int Cout, const float* __restrict__ ypre, int ypre_bf16,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, double* red) {
     constexpr int W2 = 96, W1 = 48, CIN = 32;
     const int b = blockIdx.x, ci = threadIdx.x;
     const int64_t a = action[b];
@@ -135,6 +136,26 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
     base[(y0 * W1 + x1) * CIN] += ly0 * lx1 * dx;
     base[(y1 * W1 + x0) * CIN] += ly1 * lx0 * dx;
     base[(y1 * W1 + x1) * CIN] += ly1 * lx1 * dx;
+    // The gradient of this sample is zero outside these <= 4 pixels, so the BatchNorm-backward sums of the layer in front (sum dz,
+    // sum dz * xhat with dz = ds1 * [a > 0]) are complete after a look at them -- no pass over the 48x48x32 map (red == NULL: not fused)
+    if (!red) return;
+    const float mu = mean[ci], is = invstd[ci];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a == 1 && y1 == y0) continue;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && x1 == x0) continue;
+            const size_t o = ((size_t)b * W1 * W1 + (a ? y1 : y0) * W1 + (e ? x1 : x0)) * CIN + ci;
+            const float dz = ah2[o] > 0.f ? ds1[o] : 0.f;
+            const float yv = ypre_bf16 ? __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(ypre)[o] << 16) : ypre[o];
+            s0 += dz;
+            s1 += dz * ((yv - mu) * is);
+        }
+    }
+    unsafeAtomicAdd(red + ci, (double)s0);
+    unsafeAtomicAdd(red + CIN + ci, (double)s1);
 }
 
 // q[b][co] (96x96, NCHW) = bilinear x2 (align_corners=True) of z[b][co] (48x48) + bias[co]: 4 outputs along x per thread
@@ -179,10 +200,12 @@ int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, i
 }
 
 int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
-                           float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream) {
+                           float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream,
+                           const float* ypre, int ypre_bf16, const float* mean, const float* invstd, double* red) {
     SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_onehot_bwd: Cout=%d unsupported", Cout);
     SIMQ_CHECK_HIP(hipMemsetAsync(ds1, 0, sizeof(float) * (size_t)B * 48 * 48 * 32, stream));
-    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout);
+    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout,
+                       ypre, ypre_bf16, mean, invstd, red);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

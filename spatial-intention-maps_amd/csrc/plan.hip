@@ -540,17 +540,19 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
+    static const bool no_fuse_head = getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // (diagnostics: separate reduction kernels)
     if (phase != 2) {
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
         RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
-                                  c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream));
+                                  c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream,
+                                  c.f(L.yh2), c.ybf(), c.aux(p->hb2, 2), c.aux(p->hb2, 3), no_fuse_head ? nullptr : c.red(p->hb2)));
     } else {
         RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));   // (the forward pass does not keep it)
         RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
     Act dyh = dyact(S[0], 0);
-    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dyh, nullptr, (int64_t)B * 2304));
+    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dyh, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head));
     RC(launch_colsum(S[0], cs, c.grads + p->h2.b_off, (int64_t)B * 2304, 32, c.stream));
     RC(conv_wgrad(c, p->h2, c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128), dyh, 48));
     RC(conv_dgrad(c, p->h2, dyh, S[1], nullptr, 48));
