@@ -167,8 +167,11 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);
-int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
-int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream);
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes(),
+                          double* stats = nullptr, int relu = 0, int replicas = 1);   // stats: `replicas` copies of [sum | sum of squares] of the
+                                                                                      // outputs, accumulated into (block b -> copy b % replicas)
+int launch_stats_fold(const double* rep, double* out, int n, int replicas, hipStream_t stream);   // out[i] = sum_r rep[r][i]
+int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
 int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t stream);
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipStream_t stream);

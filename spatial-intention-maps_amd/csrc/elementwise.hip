@@ -444,6 +444,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     }
 }
 
+// out[i] = sum over the replicas of rep[r][i]   (n = 2 * C entries)
+__global__ void stats_fold_kernel(const double* __restrict__ rep, double* __restrict__ out, int n, int replicas) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int r = 0; r < replicas; ++r) a += rep[(size_t)r * n + i];
+    out[i] = a;
+}
+
 __global__ void colsum_finish_kernel(const double* __restrict__ red, float* out, int C) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) out[c] = (float)red[c];
@@ -462,8 +471,12 @@ __device__ __forceinline__ Lerp lerp_coord(int o, int in_size, float scale) {
     return r;
 }
 
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, Planes pl, int B, int H, int W,
-                                      int C4) {
+// red != NULL: also accumulates the per-channel sum / sum of squares of the outputs (the train-mode BatchNorm statistics of a layer
+// whose convolution ran BEFORE the upsample, plan.hip head); relu: rectify the outputs
+__global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, Planes pl, int B, int H, int W,
+                                      int C4, double* red, int relu, int replicas) {
+    __shared__ double sm[4 * 16 * 8];                 // [wave][channel group <= 16][8]
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
     size_t total = (size_t)B * Ho * Wo * C4;
@@ -483,14 +496,38 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ in, float* __res
         o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
         o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
         o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        if (relu) o = relu4(o);
         if (out) st4(out + i * 4, o);
         st_planes(pl, i, o);
+        if (red) { s0 = add4(s0, o); s1.x += o.x * o.x; s1.y += o.y * o.y; s1.z += o.z * o.z; s1.w += o.w * o.w; }
+    }
+    if (!red) return;
+    // (the grid stride is a multiple of C4 -- the launcher checks 64 % C4 == 0 --, so a thread kept its 4 channels.)  Lanes l, l + C4,
+    // l + 2 C4 ... of a wave hold the same channels: butterfly over them in fp64, one LDS slot per wave and channel group, then C4
+    // threads push the block's sums.  (The first version summed 256 fp64 partials per channel group serially in LDS: 57 us per launch.)
+    double v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    for (int off = C4; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += __shfl_xor(v[k], off);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lane < C4)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm[(wave * C4 + lane) * 8 + k] = v[k];
+    __syncthreads();
+    if (tid < C4) {
+        const int C = C4 * 4;
+        red += (size_t)(blockIdx.x % (unsigned)replicas) * 2 * C;     // (same-address atomics of blocks that finish together serialise)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(red + tid * 4 + k, sm[tid * 8 + k] + sm[(C4 + tid) * 8 + k] + sm[(2 * C4 + tid) * 8 + k] + sm[(3 * C4 + tid) * 8 + k]);
+            unsafeAtomicAdd(red + C + tid * 4 + k, sm[tid * 8 + 4 + k] + sm[(C4 + tid) * 8 + 4 + k] + sm[(2 * C4 + tid) * 8 + 4 + k] + sm[(3 * C4 + tid) * 8 + 4 + k]);
+        }
     }
 }
 
 // transpose of the above as a gather: din[iy][ix] = sum over outputs that interpolate from (iy, ix)
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int H, int W,
-                                      int C4) {
+                                      int C4, Planes pl) {
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
     size_t total = (size_t)B * H * W * C4;
@@ -520,6 +557,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __r
             }
         }
         st4(din + i * 4, acc);
+        st_planes(pl, i, acc);
     }
 }
 
@@ -646,26 +684,35 @@ int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows,
     return launch_colsum_finish(red_scratch, out, C, stream);
 }
 
+int launch_stats_fold(const double* rep, double* out, int n, int replicas, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, rep, out, n, replicas);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream) {
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, red, out, C);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl) {
+int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl, double* stats, int relu,
+                          int replicas) {
     SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
+    SIMQ_REQUIRE(!stats || (C / 4 <= 16 && 64 % (C / 4) == 0 && !relu), "upsample2x_fwd: fused statistics need C/4 in {1,2,4,8,16} (C=%d) and no ReLU", C);
     size_t total = (size_t)B * 4 * H * W * (C / 4);
     SIMQ_REQUIRE(total < 2147483648ull, "upsample2x_fwd: tensor too large for 32-bit indexing");
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, out, pl, B, H, W, C / 4);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total, 256, stats ? 1024 : 2048)), dim3(256), 0, stream, in, out, pl, B, H, W, C / 4, stats, relu,
+                       replicas > 0 ? replicas : 1);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream) {
+int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream, Planes pl) {
     SIMQ_REQUIRE(C % 4 == 0, "upsample: C=%d must be a multiple of 4", C);
     size_t total = (size_t)B * H * W * (C / 4);
     SIMQ_REQUIRE(total < 2147483648ull, "upsample2x_bwd: tensor too large for 32-bit indexing");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dout, din, B, H, W, C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dout, din, B, H, W, C / 4, pl);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -29,6 +29,11 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Same-address fp64 atomics from blocks that finish TOGETHER serialise at ~90 ns each in L2 (1024 blocks -> 92 us, measured on the
+// upsample launch that accumulates BatchNorm 2's statistics); convolution epilogues are spread over their launch and do not see this.
+// Elementwise launches therefore add into one of kStatReplicas copies (block index mod kStatReplicas) which a tiny launch folds.
+constexpr int kStatReplicas = 16;
+
 struct ConvL {
     std::string name;
     int64_t w_off = -1, b_off = -1;   // into the flat parameter buffer
@@ -72,6 +77,8 @@ struct simq_plan {
     std::vector<TensorInfo> tensors;
     std::vector<BnL*> bns;
     int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0, wu_total = 0;
+    int64_t hb2_rep_off = -1;         // kStatReplicas x [2*32] doubles inside the reduction region (zeroed with it): head BatchNorm 2's
+                                      // statistics arrive from an elementwise launch whose blocks all finish together (forward_impl)
     int64_t wino_scratch_per_sample = 0;   // floats of V | Mt scratch per transition (max over the Winograd layers)
     int64_t wino_du_floats = 0;            // transform-domain weight gradient of the largest Winograd layer
 };
@@ -123,6 +130,7 @@ struct Builder {
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+
 // Workspace layout for a given batch (byte offsets, 256-B aligned).
 struct Layout {
     int64_t x, y0, pooled, idx;
@@ -152,7 +160,7 @@ Layout make_layout(const simq_plan* p, int B) {
         L.blk[i].out = take(n);
     }
     L.yh1 = take((int64_t)B * 576 * 128 * f); L.ah1 = take((int64_t)B * 576 * 128 * f);
-    L.up1 = take((int64_t)B * 2304 * 128 * f);
+    L.up1 = take((int64_t)B * 576 * 32 * f);          // conv2's 24x24 output (conv2 runs before the first upsample)
     L.yh2 = take((int64_t)B * 2304 * 32 * f); L.ah2 = take((int64_t)B * 2304 * 32 * f);
     L.up2 = take((int64_t)B * 9216 * 32 * f);
     L.aux = take(p->aux_total * f);
@@ -170,7 +178,7 @@ Layout make_layout(const simq_plan* p, int B) {
             L.blk[i].p_a1 = take(n);
             L.blk[i].p_out = take(n);
         }
-        L.p_up1 = take((int64_t)B * 2304 * 128 * h);
+        L.p_up1 = take((int64_t)B * 576 * 128 * h);      // planes of the head activation a1 (conv2's operand)
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
@@ -444,21 +452,39 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         }
         cur = out;
     }
-    // head, networks.py:18-26
-    if (folded) {
-        RC(conv_bn_folded(c, p->h1, p->hb1, cur, c.f(L.ah1), 24, nullptr, 1));
+    // head, networks.py:18-26.  conv2 (1x1, 128 -> 32) runs BEFORE the first bilinear upsample: both are linear and the bilinear
+    // weights of a pixel sum to 1, so conv2(upsample(a)) + b == upsample(conv2(a) + b) up to fp32 rounding -- a quarter of the pixels
+    // for the convolution, a quarter of the channels for the upsample, and the 48x48x128 activation never exists.  BatchNorm 2 still
+    // sees the 48x48x32 map: its batch statistics are accumulated by the upsample launch that produces it.
+    const Planes a1pl = c.planes(L.p_up1, rows * 128);               // bf16 planes of a1 (matrix-core precisions): conv2's operand
+    Act a1; a1.f = c.f(L.ah1); a1.pl = a1pl;
+    float* z2 = c.f(L.up1);                                          // conv2 output at 24x24 (fp32, B*576*32 floats)
+    const int64_t rows2 = (int64_t)B * 2304;
+    if (folded16) {
+        RC(conv_bn_folded_planes(c, p->h1, p->hb1, cur, a1pl.hi, 24, nullptr, 1));
+    } else if (folded) {
+        RC(conv_bn_folded(c, p->h1, p->hb1, cur, a1.f, 24, nullptr, 1));
     } else {
         RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, c.f(L.ah1), rows, 128, c.stream, Planes(), Planes(), c.ybf()));
+        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
     }
-    Act up1 = c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128);
-    RC(launch_upsample2x_fwd(c.f(L.ah1), c.planes_only() ? nullptr : up1.f, B, 24, 24, 128, c.stream, up1.pl));   // (conv2 reads the planes)
+    {
+        ConvGeom g2 = geom(p->h2, c.B, 24);
+        ConvEpilogue e2;
+        if (p->h2.b_off >= 0) e2.bias = c.params + p->h2.b_off;
+        if (folded) { e2.scale = c.aux(p->hb2, 0); e2.shift = c.aux(p->hb2, 1); }     // eval: the affine map commutes with the upsample too
+        RC(conv_fwd(c, p->h2, a1, z2, g2, e2, mode != SIMQ_MODE_TRAIN));
+    }
     if (folded) {
-        RC(conv_bn_folded(c, p->h2, p->hb2, up1, c.f(L.ah2), 48, nullptr, 1));
+        RC(launch_upsample2x_fwd(z2, c.f(L.ah2), B, 24, 24, 32, c.stream, Planes(), nullptr, 1));          // ... the ReLU does not
     } else {
-        RC(conv_bn(c, p->h2, p->hb2, mode, up1, c.f(L.yh2), 48));
-        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, (int64_t)B * 2304), nullptr, nullptr, 1, c.f(L.ah2), (int64_t)B * 2304, 32, c.stream,
-                           Planes(), Planes(), c.ybf()));
+        double* rep = reinterpret_cast<double*>(c.ws + L.red) + p->hb2_rep_off;
+        RC(launch_upsample2x_fwd(z2, c.f(L.yh2), B, 24, 24, 32, c.stream, Planes(), mode != SIMQ_MODE_EVAL ? rep : nullptr, 0, kStatReplicas));
+        if (mode != SIMQ_MODE_EVAL) {
+            RC(launch_stats_fold(rep, c.red(p->hb2), 2 * p->hb2.C, kStatReplicas, c.stream));
+            RC(c.sync_reduce(c.red(p->hb2), 2 * (int64_t)p->hb2.C));
+        }
+        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, rows2), nullptr, nullptr, 1, c.f(L.ah2), rows2, 32, c.stream, Planes(), Planes(), 0));
     }
     // conv3 before the second upsample (they commute, head.hip): z = conv3(ah2) without bias at 48x48, q = upsample(z) + bias
     RC(launch_head_conv3_fwd(c.f(L.ah2), c.params + p->h3.w_off, nullptr, c.f(L.up2), B, 2304, 32, p->cout, c.stream));
@@ -545,18 +571,23 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
         RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
                                   c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream,
-                                  c.f(L.yh2), c.ybf(), c.aux(p->hb2, 2), c.aux(p->hb2, 3), no_fuse_head ? nullptr : c.red(p->hb2)));
+                                  c.f(L.yh2), 0, c.aux(p->hb2, 2), c.aux(p->hb2, 3), no_fuse_head ? nullptr : c.red(p->hb2)));
     } else {
         RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));   // (the forward pass does not keep it)
         RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
     Act dyh = dyact(S[0], 0);
-    RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dyh, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head));
-    RC(launch_colsum(S[0], cs, c.grads + p->h2.b_off, (int64_t)B * 2304, 32, c.stream));
-    RC(conv_wgrad(c, p->h2, c.act(L.up1, L.p_up1, (int64_t)B * 2304 * 128), dyh, 48));
-    RC(conv_dgrad(c, p->h2, dyh, S[1], nullptr, 48));
-    RC(launch_upsample2x_bwd(S[1], S[2], B, 24, 24, 128, c.stream));
+    {   // BatchNorm 2 at 48x48; conv2 and everything behind it at 24x24 (the forward pass's order, transposed)
+        Act dy2; dy2.f = S[0];                                       // (fp32 only: its consumer is the bilinear transpose)
+        RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
+        Act t2 = dyact(S[1], 1);                                     // U^T dy: gradient w.r.t. conv2's 24x24 output
+        RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
+        RC(launch_colsum(t2.f, cs, c.grads + p->h2.b_off, rows, 32, c.stream));      // (the bilinear weights of a pixel sum to 1)
+        Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
+        RC(conv_wgrad(c, p->h2, a1, t2, 24));
+        RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24));             // gradient w.r.t. a1
+    }
     RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
@@ -686,6 +717,7 @@ int simq_plan_create_ex(int cin, int cout, int precision, simq_plan** out) {
     bd.bn(p->hb1, "bn1", 128);
     bd.conv(p->h2, "conv2", 128, 32, 1, 1, 0, true, true);
     bd.bn(p->hb2, "bn2", 32);
+    p->hb2_rep_off = p->red_total; p->red_total += kStatReplicas * 2 * 32;
     bd.conv(p->h3, "conv3", 32, cout, 1, 1, 0, true, false);
     for (const TensorInfo& t : p->tensors)
         if (t.kind == SIMQ_KIND_CONV_W && (t.off % 4) != 0) {
