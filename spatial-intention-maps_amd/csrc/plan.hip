@@ -383,12 +383,14 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
     const int B = c.B;
-    SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+    // the input is kept only where a backward pass will read it again (the stem's weight gradient); the other forwards convolve d_x in place
+    if (mode == SIMQ_MODE_TRAIN)
+        SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
     if (mode != SIMQ_MODE_EVAL)
         SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
     const int64_t rows = (int64_t)B * 576;
     // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97); always the fp32 kernel (Cin is 3..10)
-    Act x0; x0.f = c.f(L.x);
+    Act x0; x0.f = mode == SIMQ_MODE_TRAIN ? c.f(L.x) : const_cast<float*>(d_x);
     const int stem16 = c.W.stem16 >= 0 ? 1 : 0;      // plain-bf16 plans: bf16 matrix cores, bf16 pre-BN output (stem_conv_bf16.hip)
     if (stem16) {
         RC(launch_stem_conv_bf16(x0.f, reinterpret_cast<const uint16_t*>(c.wc + c.W.stem16), reinterpret_cast<uint16_t*>(c.f(L.y0)),

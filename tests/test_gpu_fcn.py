@@ -708,7 +708,9 @@ def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_d
         ['checkpoint_00000002.pth.tar', 'policy_00000001.pth.tar', 'policy_00000002.pth.tar']   # train.py:341-345
     target.load_state_dict(policy.state_dict())                 # what a resumed run starts from (train.py:212-214)
     rstate = random.getstate()
-    cont = [simq_mod.train(cfg, policy, target, opt, ring.sample(B), None, 0.75) for _ in range(2)]
+    cont = [simq_mod.train(cfg, policy, target, opt, ring.sample(B), None, 0.75)]
+    p_cont1 = policy.flat_params.clone()
+    cont.append(simq_mod.train(cfg, policy, target, opt, ring.sample(B), None, 0.75))
 
     policy2, target2 = simq_mod.FCN(cin, cout), simq_mod.FCN(cin, cout)
     policy2.load_state_dict(torch.load(ppath, map_location=dev)['state_dicts'][0])
@@ -721,13 +723,18 @@ def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_d
     assert rings[0].position == ring.position and len(rings[0]) == len(ring)
     assert rings[0].observations_resident == ring.observations_resident
     random.setstate(rstate)
-    again = [simq_mod.train(cfg, policy2, target2, opt2, rings[0].sample(B), None, 0.75) for _ in range(2)]
-    for a, b in zip(again, cont):
-        assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss']) and abs(a['td_error'] - b['td_error']) <= 1e-3 * abs(b['td_error'])
-    assert rel(policy2.flat_params, policy.flat_params) < 1e-3
-    # momentum = the last gradients: run-to-run noise of the atomically accumulated BN statistics, amplified by the
-    # conditioning described in this file's header (two identical runs differ by ~1e-3 here)
-    assert rel(policy2._simq_opt_state.momentum, policy._simq_opt_state.momentum) < 1e-2
+    again = [simq_mod.train(cfg, policy2, target2, opt2, rings[0].sample(B), None, 0.75)]
+    # the first resumed step sees bit-identical parameters, optimizer state and minibatch: only the summation order of the atomically
+    # accumulated BN statistics / weight gradients differs (1e-6 on the loss, 1e-5 on the parameters)
+    assert abs(again[0]['loss'] - cont[0]['loss']) <= 1e-4 * abs(cont[0]['loss'])
+    assert abs(again[0]['td_error'] - cont[0]['td_error']) <= 1e-4 * abs(cont[0]['td_error'])
+    assert rel(policy2.flat_params, p_cont1) < 1e-4
+    # the second step sees that noise through the network once more (this file's header: a double-DQN argmax of one of the 6
+    # transitions may even flip): same minibatch, loss of the same size, parameters and momentum (= the last gradients) close
+    again.append(simq_mod.train(cfg, policy2, target2, opt2, rings[0].sample(B), None, 0.75))
+    assert np.isfinite(again[1]['loss']) and abs(again[1]['loss'] - cont[1]['loss']) <= 0.2 * abs(cont[1]['loss'])
+    assert rel(policy2.flat_params, policy.flat_params) < 1e-2
+    assert rel(policy2._simq_opt_state.momentum, policy._simq_opt_state.momentum) < 0.5
 
 
 def test_winograd_layers_equal_direct_convolution_network(simq_mod):
