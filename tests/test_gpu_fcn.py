@@ -837,7 +837,8 @@ def test_bf16_backward_agrees_across_its_storage_switches(tmp_path):
               % (name, L[name], rel(G[name], G['default']), rel(G[name], G['fp32_both'])))
         assert np.isfinite(G[name]).all()
     # same forward (planes only / fp32 copies kept): identical loss, and the backward differs only by where a gradient is rounded
-    assert L['default'] == L['fp32_grads'] and L['fp32_act'] == L['fp32_both'] == L['no_fuse']
+    same = lambda a, b: abs(a - b) <= 1e-6 * abs(b)                 # (fp64 atomics: the summation order of the BN statistics may differ)
+    assert same(L['default'], L['fp32_grads']) and same(L['fp32_act'], L['fp32_both']) and same(L['no_fuse'], L['fp32_both'])
     assert rel(G['default'], G['fp32_grads']) < 3e-2
     assert rel(G['fp32_act'], G['fp32_both']) < 3e-2
     assert rel(G['no_fuse'], G['fp32_act']) < 3e-2            # separate reduction launches sum the STORED (bf16) gradient, the fused
