@@ -297,6 +297,11 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
         const long rounds = (blocks + 255) / 256;
         if (blocks >= 200 && (double)blocks / (double)(rounds * 256) >= 0.85) { bm = 288; bn = 128; }
     }
+    // 64 output channels (layer1 at large batches): the 144 x 64 four-wave tile, two blocks per CU (512 blocks at B = 128).  These
+    // launches are bound by their epilogue traffic and by the operand volume staged per flop; against the register-staged 96 x 64 tile
+    // +1.0 % on the bf16 configs[2] step, +1.4 % forward + backward (the 288 x 64 tile: neutral).  SIMQ_BF16_DMA_N64=0: off.
+    static const int n64 = [] { const char* e = getenv("SIMQ_BF16_DMA_N64"); return e ? atoi(e) : 1; }();
+    if (!bm && n64 && a.Cout == 64 && a.K >= min_k && a.M >= 144 * 400) { bm = n64 == 2 ? 288 : 144; bn = 64; }
     return bm ? dispatch(bm, bn, a, stream) : 0;
 }
 

@@ -287,14 +287,16 @@ def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
     assert rel(dwd, wd64.grad.permute(0, 2, 3, 1)) < tol_fwd
 
 
-@pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256))],
-                         ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged'])
+@pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256)),
+                                             (7, 64, 64, (144, 64))],
+                         ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged', 'dma_144x64_layer1'])
 def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile):
     """The two ping-pong bf16 kernels of the 3x3 layers on the 24x24 maps -- conv_igemm_bf16_img.hip (tile "576x128": one image x 128
     channels per block, halo patch staged once per 32-channel chunk, nine taps read shifted fragments) and conv_igemm_bf16_pp.hip
     (288x256 implicit-GEMM tile, 4-stage LDS-DMA ring) -- against the register-staged kernel on the same bf16 operands: same
     products, fp32 accumulation in a different K order, so outputs agree to fp32 round-off; bias + batch statistics through the
-    staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile."""
+    staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile.  Last case: the 144 x 64
+    LDS-DMA tile large-batch plans use for the 64-channel layer1 (conv_igemm_bf16_dma.hip)."""
     H, k = 24, 3
     g = torch.Generator().manual_seed(11 + Cin + Cout + B)
     x = torch.randn(B, H, H, Cin, generator=g).cuda()
@@ -304,7 +306,7 @@ def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile)
     st = L.stream_ptr()
     outs = []
     try:
-        for t in (tile, (96, 128)):
+        for t in (tile, (96, 128) if Cout % 128 == 0 else (96, 64)):       # (the second: a register-staged tile)
             L.lib.call('simq_tune_force_tile', *t)
             y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
             stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
