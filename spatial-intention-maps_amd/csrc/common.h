@@ -79,7 +79,8 @@ bool winograd_pays(int cin, int cout);
 int64_t winograd_scratch_floats(const ConvGeom& g);
 int launch_wino_weight(const float* w_ohwi, float* U, int cout, int cin, hipStream_t stream);
 struct WinoWeightDesc { int64_t src_off, u_off; int cout, cin, from_wt, pad_; };   // cout / cin of the convolution U serves; pad_ = 1: F(4x4,3x3) form (36 planes)
-struct WinoWeightTable { WinoWeightDesc d[40]; int n; };
+constexpr int kWinoWeightTableCap = 72;   // 18 convolutions x 4 forms (every 3x3 layer, should SIMQ_WINOGRAD_MIN admit them all)
+struct WinoWeightTable { WinoWeightDesc d[kWinoWeightTableCap]; int n; };
 int launch_wino_weight_all(const float* params, const float* wt, float* ubase, const WinoWeightTable& t, hipStream_t stream);
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                          hipStream_t stream);

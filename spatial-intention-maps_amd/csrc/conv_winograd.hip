@@ -682,10 +682,12 @@ bool winograd_eligible(const ConvGeom& g) {
 }
 
 // Layers the transform pays for: enough multiply-adds per transformed element (tools/winograd_probe.py); SIMQ_WINOGRAD_MIN
-// overrides the Cin * Cout threshold.
+// overrides the Cin * Cout threshold.  Round 1 (F(2x2,3x3) only) drew the line at 128 * 256; with the F(4x4,3x3) forms of the
+// no-grad forwards and dgrads the 128 -> 128 layers of layer2 pay as well: 3131 -> 3175 tr/s on configs[1] (forward + backward alone
+// unchanged: the gain is in the two no-grad forwards); 64 -> 64 (layer1) does not (3155, forward + backward -0.7 %).
 bool winograd_pays(int cin, int cout) {
     static long min_cc = -1;
-    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 128L * 256; }
+    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 128L * 128; }
     return (long)cin * cout >= min_cc;
 }
 

@@ -803,13 +803,14 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
         if (W.wu < 0) return 0;
         WinoWeightTable t;                             // Winograd layers: U = G w G^T of the weight and of its dgrad form
         t.n = 0;
-        (void)for_each_mc_conv(plan, [&](const ConvL& cv) {
+        RC(for_each_mc_conv(plan, [&](const ConvL& cv) {
+            SIMQ_REQUIRE(t.n + 4 <= kWinoWeightTableCap, "weights_prepare: more Winograd layers than the transform table holds");
             if (cv.wu_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu_off, cv.cout, cv.cin, 0, 0};
             if (cv.wu4_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.w_off, cv.wu4_off, cv.cout, cv.cin, 0, 1};
             if (cv.wut_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut_off, cv.cin, cv.cout, 1, 0};
             if (cv.wut4_off >= 0) t.d[t.n++] = WinoWeightDesc{cv.wt_off, cv.wut4_off, cv.cin, cv.cout, 1, 1};
             return 0;
-        });
+        }));
         return launch_wino_weight_all(d_params, reinterpret_cast<const float*>(wc + W.wt), reinterpret_cast<float*>(wc + W.wu), t,
                                       static_cast<hipStream_t>(stream));
     }

@@ -408,8 +408,8 @@ def test_conv_fp32_balanced_last_round(L, B, H):
     assert rel(y1, ref) < 1e-4
 
 
-@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 12, 128, 256), (2, 8, 64, 64)],
-                         ids=['l4', 'l4a', 'l3a_small_map', 'narrow'])
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 12, 128, 256), (2, 8, 64, 64), (7, 24, 128, 128)],
+                         ids=['l4', 'l4a', 'l3a_small_map', 'narrow', 'l2'])
 def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
     """conv_winograd.hip (input transform, 16 batched transform-domain GEMMs, output transform + epilogue) against the
     implicit-GEMM kernel and an fp64 convolution: outputs within 1e-5 of the output range (the transforms only add and
@@ -433,8 +433,9 @@ def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
     assert rel(s1, sref) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 24, 128, 256), (6, 12, 256, 256), (29, 24, 256, 256)],
-                         ids=['l4', 'l4a', 'l3a', 'l3_small_map', 'l3_b29'])
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 24, 128, 256), (6, 12, 256, 256), (29, 24, 256, 256),
+                                          (9, 24, 128, 128)],
+                         ids=['l4', 'l4a', 'l3a', 'l3_small_map', 'l3_b29', 'l2'])
 def test_conv_winograd4_forward_matches_direct(L, B, H, Cin, Cout):
     """The F(4x4,3x3) form of the no-grad forwards (conv_winograd.hip: 6x6 input transform at stride 4, 36 batched transform-domain
     GEMMs, 4x4 output transform + forward epilogue; interpolation points {0, 1, -1, 1/2, -2, inf}) against the implicit-GEMM kernel and
@@ -461,8 +462,9 @@ def test_conv_winograd4_forward_matches_direct(L, B, H, Cin, Cout):
     assert rel(s1, sref) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (6, 12, 256, 256), (8, 24, 512, 512), (4, 24, 256, 256)],
-                         ids=['l4', 'l4a', 'l3_small_map', 'l4_f4', 'l3_f4'])
+@pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (6, 12, 256, 256), (8, 24, 512, 512), (4, 24, 256, 256),
+                                          (8, 24, 128, 128), (5, 24, 128, 128)],
+                         ids=['l4', 'l4a', 'l3_small_map', 'l4_f4', 'l3_f4', 'l2_f4', 'l2'])
 def test_conv_winograd_wgrad_matches_direct(L, B, H, Cin, Cout):
     """Transform-domain weight gradient (dy / x transforms, batched contractions over the tiles, G^T dU G) against the
     direct wgrad kernel and fp64.  Tile counts that allow it ('*_f4': batch * 36 a multiple of 16) take the F(4x4,3x3) form,
