@@ -588,9 +588,14 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(launch_colsum(t2.f, cs, c.grads + p->h2.b_off, rows, 32, c.stream));      // (the bilinear weights of a pixel sum to 1)
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         RC(conv_wgrad(c, p->h2, a1, t2, 24));
-        RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24));             // gradient w.r.t. a1
+        ConvEpilogue fh;                                             // ... whose epilogue also leaves BatchNorm 1's backward sums
+        if (!no_fuse_head) {
+            fh.bnr_mask = c.f(L.ah1); fh.bnr_y1 = c.f(L.yh1); fh.bnr_y_bf16 = c.ybf();
+            fh.bnr_mean1 = c.aux(p->hb1, 2); fh.bnr_invstd1 = c.aux(p->hb1, 3); fh.bnr_red1 = c.red(p->hb1);
+        }
+        RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24, fh));         // gradient w.r.t. a1
     }
-    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows));
+    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, !no_fuse_head));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
     }
