@@ -155,7 +155,8 @@ int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, doub
 int stem_wgrad_bf16_slabs(int B, int H, int W);      // partial-sum slabs (64 * 49 * C floats each) the weight gradient needs as scratch
 int launch_stem_wgrad_bf16(const float* x, const uint16_t* dy, float* dw, float* partial, int B, int H, int W, int C, hipStream_t stream);
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
-                         int C, hipStream_t stream, int g_bf16 = 0);
+                         int C, hipStream_t stream, int g_bf16 = 0, const float* y = nullptr, const float* mean = nullptr,
+                         const float* invstd = nullptr, double* red = nullptr, int y_bf16 = 0, int replicas = 1);   // red: fused BN-backward sums
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean,
                          const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0, int g_bf16 = 0);

@@ -311,12 +311,21 @@ __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, floa
     bn_commit(bn);
 }
 
-// gather form of maxpool backward fused with the ReLU mask: dz at HxW from g at (H/2)x(W/2)
-__global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pooled,
+// gather form of maxpool backward fused with the ReLU mask: dz at HxW from g at (H/2)x(W/2).
+// red != NULL: also accumulates the BatchNorm-backward sums of the layer in front (sum dz | sum dz * xhat, xhat from the saved pre-BN
+// output y / mean / invstd) into one of `replicas` copies of a [2*C] slot (block index mod replicas; launch_stats_fold adds them up):
+// dz is complete here, so the separate reduction pass over it is not needed
+__global__ void __launch_bounds__(256) stem_pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pooled,
                                      const uint8_t* __restrict__ idx, float* __restrict__ dz, int B, int H, int W,
-                                     int C4, int g_bf16) {
+                                     int C4, int g_bf16, const float* __restrict__ y, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, double* red, int y_bf16, int replicas) {
+    __shared__ double sm[4 * 16 * 8];                  // [wave][channel group <= 16][8]
     const int Ho = H / 2, Wo = W / 2;
     size_t total = (size_t)B * H * W * C4;
+    // the grid stride (gridDim * 256) is a multiple of C4, so a thread keeps its 4 channels
+    const int cfix = (int)((blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)C4);
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, s0 = mu, s1 = mu;
+    if (red) { mu = ld4(mean + cfix * 4); is = ld4(invstd + cfix * 4); }
     // 32-bit index arithmetic (the launchers bound the element count): 64-bit div / mod cost ~10x as many instructions
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
         int c4 = (int)(i % (unsigned)C4);
@@ -347,6 +356,32 @@ __global__ void stem_pool_bwd_kernel(const float* __restrict__ g, const float* _
             }
         }
         st4(dz + i * 4, acc);
+        if (red) {
+            const float4 yv = ld4y(y, i, y_bf16);
+            s0 = add4(s0, acc);
+            s1.x += acc.x * ((yv.x - mu.x) * is.x); s1.y += acc.y * ((yv.y - mu.y) * is.y);
+            s1.z += acc.z * ((yv.z - mu.z) * is.z); s1.w += acc.w * ((yv.w - mu.w) * is.w);
+        }
+    }
+    if (!red) return;
+    // lanes l, l + C4, ... of a wave hold the same channels: fp64 butterfly, one LDS slot per wave and channel group, C4 threads push
+    double v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    for (int off = C4; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += __shfl_xor(v[k], off);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lane < C4)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sm[(wave * C4 + lane) * 8 + k] = v[k];
+    __syncthreads();
+    if (tid < C4) {
+        const int C = C4 * 4;
+        red += (size_t)(blockIdx.x % (unsigned)replicas) * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(red + tid * 4 + k, sm[tid * 8 + k] + sm[(C4 + tid) * 8 + k] + sm[(2 * C4 + tid) * 8 + k] + sm[(3 * C4 + tid) * 8 + k]);
+            unsafeAtomicAdd(red + C + tid * 4 + k, sm[tid * 8 + 4 + k] + sm[(C4 + tid) * 8 + 4 + k] + sm[(2 * C4 + tid) * 8 + 4 + k] + sm[(3 * C4 + tid) * 8 + 4 + k]);
+        }
     }
 }
 
@@ -627,11 +662,14 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 }
 
 int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx, float* dz, int B, int H, int W,
-                         int C, hipStream_t stream, int g_bf16) {
+                         int C, hipStream_t stream, int g_bf16, const float* y, const float* mean, const float* invstd, double* red,
+                         int y_bf16, int replicas) {
     size_t total = (size_t)B * H * W * (C / 4);
     SIMQ_REQUIRE(total < 2147483648ull, "stem_pool_bwd: tensor too large for 32-bit indexing");
-    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, pooled, idx, dz, B, H, W,
-                       C / 4, g_bf16);
+    SIMQ_REQUIRE(!red || (y && mean && invstd && C % 4 == 0 && C / 4 <= 16 && 64 % (C / 4) == 0 && replicas >= 1),
+                 "stem_pool_bwd: fused reduction needs y / mean / invstd and C/4 in {1,2,4,8,16}");
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(grid_for(total, 256, red ? 1024 : 2048)), dim3(256), 0, stream, g, pooled, idx, dz, B, H, W,
+                       C / 4, g_bf16, y, mean, invstd, red, y_bf16, replicas > 0 ? replicas : 1);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -77,6 +77,7 @@ struct simq_plan {
     std::vector<TensorInfo> tensors;
     std::vector<BnL*> bns;
     int64_t nparams = 0, nbnbuf = 0, wt_total = 0, wp_total = 0, aux_total = 0, red_total = 0, wu_total = 0;
+    int64_t stem_rep_off = -1;        // ... and the stem BatchNorm's backward sums (from the pooling-backward launch)
     int64_t hb2_rep_off = -1;         // kStatReplicas x [2*32] doubles inside the reduction region (zeroed with it): head BatchNorm 2's
                                       // statistics arrive from an elementwise launch whose blocks all finish together (forward_impl)
     int64_t wino_scratch_per_sample = 0;   // floats of V | Mt scratch per transition (max over the Winograd layers)
@@ -667,8 +668,13 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     const bool stem16 = c.W.stem16 >= 0;             // plain-bf16 plans: dy as a bf16 plane only, weight gradient on the bf16 matrix cores
     if (stem16) { T1 = dyact(S[(gi + 2) & 3], 1); T1.fv = false; }
     Act x0; x0.f = c.f(L.x);
-    RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf()));
-    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, false, nullptr, c.W.stem16 >= 0 ? 1 : 0));   // (pre-BN output: fp32, or bf16 from stem_conv_bf16)
+    const int y0_bf16 = c.W.stem16 >= 0 ? 1 : 0;     // pre-BN output: fp32, or bf16 from stem_conv_bf16
+    static const bool no_stem_fuse = getenv("SIMQ_NO_STEM_FUSE") != nullptr || getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // diagnostics
+    double* srep = reinterpret_cast<double*>(c.ws + L.red) + p->stem_rep_off;
+    RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf(),
+                            c.f(L.y0), c.aux(p->stem_bn, 2), c.aux(p->stem_bn, 3), no_stem_fuse ? nullptr : srep, y0_bf16, kStatReplicas));
+    if (!no_stem_fuse) RC(launch_stats_fold(srep, c.red(p->stem_bn), 2 * p->stem_bn.C, kStatReplicas, c.stream));
+    RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, !no_stem_fuse, nullptr, y0_bf16));   // (pre-BN output: fp32, or bf16 from stem_conv_bf16)
     if (stem16)                                      // (T0 = dz is dead behind bn_bwd: it holds the partial-sum slabs)
         return launch_stem_wgrad_bf16(x0.f, T1.pl.hi, c.grads + p->stem.w_off, T0, B, 96, 96, p->cin, c.stream);
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
@@ -725,6 +731,7 @@ int simq_plan_create_ex(int cin, int cout, int precision, simq_plan** out) {
     bd.conv(p->h2, "conv2", 128, 32, 1, 1, 0, true, true);
     bd.bn(p->hb2, "bn2", 32);
     p->hb2_rep_off = p->red_total; p->red_total += kStatReplicas * 2 * 32;
+    p->stem_rep_off = p->red_total; p->red_total += kStatReplicas * 2 * 64;
     bd.conv(p->h3, "conv3", 32, cout, 1, 1, 0, true, false);
     for (const TensorInfo& t : p->tensors)
         if (t.kind == SIMQ_KIND_CONV_W && (t.off % 4) != 0) {
