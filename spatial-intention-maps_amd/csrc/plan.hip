@@ -581,6 +581,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
     Act dyh = dyact(S[0], 0);
+    bool hb1_fused = false;
     {   // BatchNorm 2 at 48x48; conv2 and everything behind it at 24x24 (the forward pass's order, transposed)
         Act dy2; dy2.f = S[0];                                       // (fp32 only: its consumer is the bilinear transpose)
         RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
@@ -590,13 +591,17 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         RC(conv_wgrad(c, p->h2, a1, t2, 24));
         ConvEpilogue fh;                                             // ... whose epilogue also leaves BatchNorm 1's backward sums
-        if (!no_fuse_head) {
+        // (fp32 plans: 35 us of reduction pass saved.  The matrix-core plans keep the pass: their K = 32 dgrad runs the register-staged
+        // kernel, whose scalar epilogue makes the fused form 108 us against 30 + 61 us at B = 128.)
+        const bool fuse_hb1 = !no_fuse_head && !c.mc();
+        if (fuse_hb1) {
             fh.bnr_mask = c.f(L.ah1); fh.bnr_y1 = c.f(L.yh1); fh.bnr_y_bf16 = c.ybf();
             fh.bnr_mean1 = c.aux(p->hb1, 2); fh.bnr_invstd1 = c.aux(p->hb1, 3); fh.bnr_red1 = c.red(p->hb1);
         }
         RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24, fh));         // gradient w.r.t. a1
+        hb1_fused = fuse_hb1;
     }
-    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, !no_fuse_head));
+    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused));
     RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
     }
