@@ -159,7 +159,7 @@ int launch_stem_pool_bwd(const float* g, const float* pooled, const uint8_t* idx
                          const float* invstd = nullptr, double* red = nullptr, int y_bf16 = 0, int replicas = 1);   // red: fused BN-backward sums
 // BN backward.  dz = g * (mask>0) (mask may be NULL).  reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat
 int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, const float* mean,
-                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0, int g_bf16 = 0);
+                         const float* invstd, double* red, int64_t rows, int C, hipStream_t stream, int y_bf16 = 0, int g_bf16 = 0, int replicas = 1);
 // dy = gamma*invstd*(dz - dbeta/rows - xhat*dgamma/rows); also writes dgamma/dbeta (block 0) and dz (optional)
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean,
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
@@ -168,6 +168,7 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
                         int g_bf16 = 0);   // g_bf16: g (and dz_out) are bf16 behind the float pointers
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
+int launch_colsum_rep(const float* x, double* red_scratch, float* out, int64_t rows, int C, int replicas, hipStream_t stream);   // scratch: replicas * C doubles
 int launch_colsum_finish(const double* red, float* out, int C, hipStream_t stream);
 int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes(),
                           double* stats = nullptr, int relu = 0, int replicas = 1);   // stats: `replicas` copies of [sum | sum of squares] of the

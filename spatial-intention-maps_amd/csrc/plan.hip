@@ -166,7 +166,8 @@ Layout make_layout(const simq_plan* p, int B) {
     L.up2 = take((int64_t)B * 9216 * 32 * f);
     L.aux = take(p->aux_total * f);
     L.red = take(p->red_total * (int64_t)sizeof(double));
-    L.colsum = take(512 * sizeof(double));
+    L.colsum = take(kStatReplicas * 2 * 128 * sizeof(double));   // replicated scratch slots: bias-gradient column sums of the head
+                                                                 // convolutions, non-fused BatchNorm-backward sums (C <= 128)
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
     for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
     L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = -1;
@@ -504,7 +505,16 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
            bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1, int g_bf16 = 0) {
     if (y_bf16 < 0) y_bf16 = c.ybf();
-    if (!reduced) RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16, g_bf16));
+    if (!reduced) {
+        if (bn.C <= 128) {                                   // (blocks finish together: replicated slots)
+            double* rep = reinterpret_cast<double*>(c.ws + c.L.colsum);
+            SIMQ_CHECK_HIP(hipMemsetAsync(rep, 0, sizeof(double) * kStatReplicas * 2 * bn.C, c.stream));
+            RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), rep, rows, bn.C, c.stream, y_bf16, g_bf16, kStatReplicas));
+            RC(launch_stats_fold(rep, c.red(bn), 2 * bn.C, kStatReplicas, c.stream));
+        } else {
+            RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.red(bn), rows, bn.C, c.stream, y_bf16, g_bf16));
+        }
+    }
     RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));                                   // SyncBN: [sum dz | sum dz*xhat] over all ranks
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
                                c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16,
@@ -587,7 +597,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
         Act t2 = dyact(S[1], 1);                                     // U^T dy: gradient w.r.t. conv2's 24x24 output
         RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
-        RC(launch_colsum(t2.f, cs, c.grads + p->h2.b_off, rows, 32, c.stream));      // (the bilinear weights of a pixel sum to 1)
+        RC(launch_colsum_rep(t2.f, cs, c.grads + p->h2.b_off, rows, 32, kStatReplicas, c.stream));   // (the bilinear weights of a pixel sum to 1)
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         RC(conv_wgrad(c, p->h2, a1, t2, 24));
         ConvEpilogue fh;                                             // ... whose epilogue also leaves BatchNorm 1's backward sums
@@ -602,7 +612,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         hb1_fused = fuse_hb1;
     }
     RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused));
-    RC(launch_colsum(S[0], cs, c.grads + p->h1.b_off, rows, 128, c.stream));
+    RC(launch_colsum_rep(S[0], cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
     }
     // every dgrad that completes the gradient of a block output (or of a block's inner activation) also
