@@ -426,7 +426,8 @@ __global__ void __launch_bounds__(256) chan_reduce_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] += sm[(l * C4 + tid) * 8 + k];
         const int C = C4 * 4;
-        // all blocks finish together and same-address atomics serialise (~90 ns each: 288 blocks spent 26 of their 35 us queueing):
+        // all blocks finish together and their fp64 atomics into the same few cache lines serialise (~6 ns per atomic and line: 288
+        // blocks x 16 addresses per line spent 26 of their 35 us queueing):
         // block b adds into copy b % replicas of the slot, the finishing launch adds the copies
         red += (size_t)(blockIdx.x % (unsigned)replicas) * (MODE == 0 ? 2 * C : C);
 #pragma unroll

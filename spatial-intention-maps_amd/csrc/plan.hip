@@ -29,9 +29,11 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Same-address fp64 atomics from blocks that finish TOGETHER serialise at ~90 ns each in L2 (1024 blocks -> 92 us, measured on the
-// upsample launch that accumulates BatchNorm 2's statistics); convolution epilogues are spread over their launch and do not see this.
-// Elementwise launches therefore add into one of kStatReplicas copies (block index mod kStatReplicas) which a tiny launch folds.
+// fp64 atomics of blocks that finish TOGETHER serialise per cache line (~6 ns each: a block adds its 2*C sums into 2*C/16 lines, so
+// 1024 blocks x 64 sums into 4 lines took 92 us on the upsample launch that accumulates BatchNorm 2's statistics; one atomic per block
+// into one address, as in the gradient-norm kernel, costs only ~10 us per 1024 blocks).  Convolution epilogues are spread over their
+// launch and do not see this.  Elementwise / reduction launches therefore add into one of kStatReplicas copies (block index mod
+// kStatReplicas) which a tiny launch folds.
 constexpr int kStatReplicas = 16;
 
 struct ConvL {
