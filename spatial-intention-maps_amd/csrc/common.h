@@ -144,6 +144,8 @@ int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float*
 int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnRef* rbn, int relu, float* out, int64_t rows,
                     int C, hipStream_t stream, Planes pl = Planes(), Planes res_pl = Planes(), int y_bf16 = 0);
 // stem: pooled = maxpool3x3s2p1( relu(y*scale+shift) ), idx = first-max window position (0..8)
+// a = relu(bn(y)) (32 channels; a may be NULL) and z = conv3(a) without bias, NCHW [B][Cout][HW], in one pass (elementwise.hip)
+int launch_head_bn_relu_conv3(const float* y, const BnRef& bn, const float* w3, float* a, float* z, int B, int HW, int Cout, hipStream_t stream);
 int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t* idx, int B, int H, int W, int C,
                          hipStream_t stream, Planes pl = Planes(), int y_bf16 = 0);
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)

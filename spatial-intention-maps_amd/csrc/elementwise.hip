@@ -271,6 +271,39 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     }
 }
 
+// Head: a = relu(bn(y)) over the 32-channel map (BatchNorm 2, networks.py:24) and, in the same pass, z = conv3(a) WITHOUT bias
+// (1x1, 32 -> Cout <= 4; its bias is added behind the second upsample, head.hip) -- the activation is not read back for the last layer,
+// and forwards nothing is differentiated through (a == NULL) do not write it at all.  8 lanes share a pixel (one float4 of the 32
+// channels each); z is NCHW [B][Cout][HW].
+__global__ void __launch_bounds__(256) head_bn_relu_conv3_kernel(const float* __restrict__ y, BnRef bn, const float* __restrict__ w3,
+                                                                  float* __restrict__ a, float* __restrict__ z, int B, int HW, int Cout) {
+    constexpr int CIN = 32, L = CIN / 4, MAXC = 4;
+    __shared__ float cs[2 * kCoeffMaxC];
+    bn_coeff_block(bn, cs);
+    __syncthreads();
+    const int sub = threadIdx.x % L;
+    const float4 sc = ld4(cs + sub * 4), sh = ld4(cs + kCoeffMaxC + sub * 4);
+    float4 wv[MAXC];
+#pragma unroll
+    for (int co = 0; co < MAXC; ++co) wv[co] = co < Cout ? ld4(w3 + co * CIN + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned total = (unsigned)B * (unsigned)HW, ppb = 256 / L;
+    for (unsigned pix = blockIdx.x * ppb + threadIdx.x / L; pix < total; pix += gridDim.x * ppb) {
+        const float4 v = relu4(fma4(ld4(y + (size_t)pix * CIN + sub * 4), sc, sh));
+        if (a) st4(a + (size_t)pix * CIN + sub * 4, v);
+        const unsigned b = pix / (unsigned)HW, p = pix - b * (unsigned)HW;
+#pragma unroll
+        for (int co = 0; co < MAXC; ++co) {
+            if (co < Cout) {
+                float s = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
+#pragma unroll
+                for (int o = L / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+                if (sub == 0) z[((size_t)b * Cout + co) * HW + p] = s;
+            }
+        }
+    }
+    bn_commit(bn);
+}
+
 // stem: pooled = maxpool3x3 s2 p1 over relu(bn(y)); idx = first maximal window slot (dy*3+dx), scan order
 __global__ void stem_pool_fwd_kernel(const float* __restrict__ y, BnRef bn, float* __restrict__ pooled,
                                      uint8_t* __restrict__ idx, Planes pl, int B, int H, int W, int C4, int y_bf16) {
@@ -653,6 +686,16 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, y, bn, res, res_pl, rbn ? *rbn : bn,
                        rbn ? 1 : 0, relu, out, pl, total4, C / 4, y_bf16);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_head_bn_relu_conv3(const float* y, const BnRef& bn, const float* w3, float* a, float* z, int B, int HW, int Cout, hipStream_t stream) {
+    SIMQ_REQUIRE(bn.C == 32 && Cout >= 1 && Cout <= 4, "head_bn_relu_conv3: C=%d Cout=%d unsupported", bn.C, Cout);
+    SIMQ_REQUIRE((size_t)B * HW < 2147483648ull, "head_bn_relu_conv3: too many pixels for 32-bit indexing");
+    size_t blocks = ((size_t)B * HW + 31) / 32;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(head_bn_relu_conv3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, bn, w3, a, z, B, HW, Cout);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -490,10 +490,13 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
             RC(launch_stats_fold(rep, c.red(p->hb2), 2 * p->hb2.C, kStatReplicas, c.stream));
             RC(c.sync_reduce(c.red(p->hb2), 2 * (int64_t)p->hb2.C));
         }
-        RC(launch_bn_apply(c.f(L.yh2), bnref(c, p->hb2, mode, rows2), nullptr, nullptr, 1, c.f(L.ah2), rows2, 32, c.stream, Planes(), Planes(), 0));
+        // BatchNorm 2 + ReLU + conv3 in one pass (conv3 before the second upsample: they commute, head.hip); the activation itself is
+        // only kept where a backward pass will read it (ReLU mask, conv3's weight gradient)
+        RC(launch_head_bn_relu_conv3(c.f(L.yh2), bnref(c, p->hb2, mode, rows2), c.params + p->h3.w_off,
+                                     mode == SIMQ_MODE_TRAIN ? c.f(L.ah2) : nullptr, c.f(L.up2), B, 2304, p->cout, c.stream));
     }
-    // conv3 before the second upsample (they commute, head.hip): z = conv3(ah2) without bias at 48x48, q = upsample(z) + bias
-    RC(launch_head_conv3_fwd(c.f(L.ah2), c.params + p->h3.w_off, nullptr, c.f(L.up2), B, 2304, 32, p->cout, c.stream));
+    // folded forwards: z = conv3(ah2) without bias at 48x48; everywhere: q = upsample(z) + bias
+    if (folded) RC(launch_head_conv3_fwd(c.f(L.ah2), c.params + p->h3.w_off, nullptr, c.f(L.up2), B, 2304, 32, p->cout, c.stream));
     RC(launch_head_upsample_q(c.f(L.up2), c.params + p->h3.b_off, d_q, B, p->cout, c.stream));
     return 0;
 }
