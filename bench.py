@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Q-map transitions/sec of the spatial-action-map DQN training step on MI355X.
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on):
-  lifting_1-small_empty: Cin=4 -> Cout=2, minibatch 32 per GPU, fp32, double DQN,
-  lr 0.01 / momentum 0.9 / wd 1e-4 / clip 100, synthetic replay (seeded).
-A "step" is ONE full reference train() call (train.py:108-141) on one sampled minibatch:
-  replay index sampling + HBM gather, policy forward (train-mode BN), double-DQN next-state
-  forwards (policy train-mode no-grad + target eval), TD target + Huber, backward, global-norm
-  clip, momentum SGD, and the two scalar read-backs the reference does (.item()).
-  That is metric definition M2 of SURVEY 8d (65.0 GFLOP/transition); nothing is skipped.
-N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL), weak scaling (32
-transitions per GPU), per-rank BatchNorm statistics (the reference's DataParallel semantics),
-ONE all-reduce of the flat 45 MB gradient buffer per step.
+A "step" is ONE pass of the reference's training loop body (train.py:252-258) over the robot groups of the workload: for
+every group, one minibatch draw (train.py:256) and one full train() call (train.py:108-141) -- replay index sampling + HBM
+gather, policy forward (train-mode BN), double-DQN next-state forwards (policy train-mode no-grad + target eval), TD target
++ Huber, backward, [gradient all-reduce], global-norm clip, momentum SGD and the two scalar read-backs the reference does
+(.item()).  That is M2 of SURVEY 8d (65.0 GFLOP/transition); nothing is skipped.  M1 -- the literal "fwd+bwd" of
+BASELINE.json's metric text: policy forward + gather + Huber + backward only -- is timed beside it (`value_fwd_bwd_only`).
+
+Workloads = BASELINE.json's configs (`--workload`, default `auto` = by GPU count):
+  configs1   lifting_1-small_empty:           Cin 4 -> Cout 2,                 global minibatch   32, fp32   (auto: N=1, N=2 sharded)
+  configs2   lifting_4-small_divider:         Cin 5 -> Cout 2,                 global minibatch  128, bf16   (N=1: reported beside configs1)
+  configs3   lifting_2_pushing_2-large_empty: two nets, Cin 5 -> Cout 2 and 1, global minibatch  256 PER NET, fp32  (auto: N=4)
+  configs4   lifting_4-large_empty:           Cin 5 -> Cout 2,                 global minibatch 1024, bf16   (auto: N=8)
+  weak32     configs1's net at 32 transitions PER GPU (weak scaling; auto for every other N, and timed as a second leg of
+             every N>1 run so that a like-for-like 1 -> N curve exists next to the config-faithful `value`)
+The global minibatch is sharded over the ranks (contiguous slices of the commonly drawn indices, DataParallel's scatter,
+policies.py:39): per-rank BatchNorm statistics, gradient all-reduce in two buckets overlapped with the backward walk.
+
+N GPUs: one process per GPU.  Started under torch.distributed.run (the driver's form) the ranks are taken from the
+environment; started bare (`python bench.py --gpus N`) the script launches its own N ranks through torch.distributed.run
+on 127.0.0.1 and exits with their status.
 
 Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline` objects.
 """
@@ -20,6 +29,8 @@ import ctypes
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,16 +43,26 @@ for _p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
 # launcher exported, default to the supported mode otherwise -- must be in the environment before the HIP runtime starts
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-CIN, COUT, BATCH_PER_GPU = 4, 2, 32
 GAMMA, LR, MOMENTUM, WD, CLIP = 0.75, 0.01, 0.9, 1e-4, 100.0
-REPLAY_ITEMS = 1024                      # synthetic transitions resident in the HBM ring per rank
-FLOP_M1, FLOP_M2 = 38.963e9, 64.976e9    # per transition, SURVEY 8d [probe-derived] (fwd+bwd / full train())
-PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+REPLAY_ITEMS = 10000                     # replay_buffer_size of the reference's experiment configs (…-base.yml:29), resident in HBM per rank and net
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_*_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA (not the 2:1-sparse marketing figure)
 PEAK_HBM_GBS = 8000.0
+
+# per transition, SURVEY 8d [probe-derived]: (M1 fwd+bwd, M2 full train()) for Cin 4 / Cin 5 (the first convolution is the only
+# layer that sees Cin; Cout only moves the 0.6-MMAC last layer)
+FLOPS = {4: (38.963e9, 64.976e9), 5: (38.99e9, 65.03e9)}
+
+WORKLOADS = {
+    'configs1': dict(config='BASELINE configs[1] lifting_1-small_empty', nets=[(4, 2)], global_batch=32, precision='fp32'),
+    'configs2': dict(config='BASELINE configs[2] lifting_4-small_divider', nets=[(5, 2)], global_batch=128, precision='bf16'),
+    'configs3': dict(config='BASELINE configs[3] lifting_2_pushing_2-large_empty (lifting Cout=2 + pushing Cout=1, train.py:255-257)',
+                     nets=[(5, 2), (5, 1)], global_batch=256, precision='fp32'),
+    'configs4': dict(config='BASELINE configs[4] lifting_4-large_empty', nets=[(5, 2)], global_batch=1024, precision='bf16'),
+    'weak32': dict(config="BASELINE configs[1]'s net at 32 transitions per GPU (weak scaling)", nets=[(4, 2)], per_gpu=32, precision='fp32'),
+}
+AUTO = {1: 'configs1', 2: 'configs1', 4: 'configs3', 8: 'configs4'}
+DTYPE_NAMES = {'fp32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMA products, f32 accumulate)', 'bf16': 'bf16 (f32 accumulate / BN / optimiser)'}
 
 
 def parse():
@@ -49,95 +70,158 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='auto', choices=['auto'] + sorted(WORKLOADS),
+                    help='BASELINE config to run (auto: N=1 configs1, N=2 configs1 sharded, N=4 configs3, N=8 configs4, otherwise weak32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-m1', action='store_true', help='skip the forward+backward-only (M1) leg (profiling runs: every launch then belongs to a full step)')
-    ap.add_argument('--no-extras', action='store_true', help='skip the opt-in bf16 configs[2] leg of the default N=1 run')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
-                    help="arithmetic of the 3x3/1x1 convolutions; the default 'fp32' (exact) is the BASELINE configs[1] workload")
-    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='transitions per GPU per step (default: configs[1])')
-    ap.add_argument('--cin', type=int, default=CIN)
+    ap.add_argument('--no-extras', action='store_true', help='skip the second leg (N=1: configs[2] bf16 beside configs[1]; N>1: weak32 beside the config)')
+    ap.add_argument('--precision', default=None, choices=['fp32', 'bf16x3', 'bf16'], help="override the workload's arithmetic (tools only)")
+    ap.add_argument('--batch', type=int, default=None, help='override: transitions per GPU (and net) per step (tools only)')
+    ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
+    ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo only to debug the rank logic on one GPU)')
     return ap.parse_args()
 
 
-def cpu_baseline(batch):
-    """The oracle (CPU restatement, pinned bit-exact to the reference in the build container)
-    running the SAME step on this box's host cores.  Bounded sample (~10-30 s): 1 warm-up + up to 3
-    timed train() calls at the GPU workload's batch size.  Threads: the CPUs this process may run
-    on, capped at 32 (oversubscribing a 256-thread host made MKL-DNN 30x slower: 0.26 tr/s)."""
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the form the reference's
+    single-process nn.DataParallel, policies.py:39, takes here) and hand their exit status back."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(cin, cout, batch):
+    """The oracle (CPU restatement, pinned bit-exact to the reference in the build container) running the SAME step on this
+    box's host cores.  Bounded sample (~10-30 s): per thread count of the sweep 1 warm-up + up to 2 timed train() calls at the
+    GPU workload's batch size (capped at 32; the rate is flat in the batch); the best count is reported.  A count whose
+    warm-up call is already 3x slower than the best so far is not timed further (oversubscribing a 256-thread host made MKL-DNN
+    30x slower)."""
+    import torch
     from oracle import cases, fcn as ofcn, learner as olearner
     from simq import synth
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    nthreads = max(1, min(avail, 32))
-    torch.set_num_threads(nthreads)
+    sweep = sorted({max(1, min(avail, n)) for n in (32, 64, 128)})
     cfg = cases.make_cfg(batch)
-    spec = ofcn.state_spec(CIN, COUT)
-    st = ofcn.state_from_numpy(synth.make_state_dict(CIN, COUT, 1))
-    tg = ofcn.state_from_numpy(synth.make_state_dict(CIN, COUT, 2))
-    mom = [None] * len(olearner.grad_keys(spec))
-    trs = synth.make_transitions(batch, CIN, COUT, 3, terminal_frac=0.1)
+    spec = ofcn.state_spec(cin, cout)
+    trs = synth.make_transitions(batch, cin, cout, 3, terminal_frac=0.1)
     b = olearner.Transition(*zip(*trs))
-    t0 = time.perf_counter()
-    olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
-    warm = time.perf_counter() - t0
-    steps = 3 if warm < 8 else 1
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    results, best_call = [], None
+    t_all = time.perf_counter()
+    for nthreads in sweep:
+        if time.perf_counter() - t_all > 25:
+            break
+        torch.set_num_threads(nthreads)
+        st = ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 1))
+        tg = ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 2))
+        mom = [None] * len(olearner.grad_keys(spec))
+        t0 = time.perf_counter()
         olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
-    dt = time.perf_counter() - t0
-    return {'value': round(batch * steps / dt, 3), 'unit': 'transitions/s', 'cores': nthreads,
-            'kind': 'port',
-            'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), batch %d, '
-                      '1 warm-up (%.1f s) + %d timed calls (%.1f s); host reports %d CPUs (%d usable)'
-                      % (batch, warm, steps, dt, os.cpu_count() or 0, avail)}
+        warm = time.perf_counter() - t0
+        if best_call is not None and warm > 3 * best_call:
+            results.append((batch / warm, nthreads, 0, warm, warm))
+            continue
+        steps = 2 if warm < 6 else 1
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
+        dt = time.perf_counter() - t0
+        best_call = dt / steps if best_call is None else min(best_call, dt / steps)
+        results.append((batch * steps / dt, nthreads, steps, warm, dt))
+    rate, nthreads, steps, warm, dt = max(results)
+    return {'value': round(rate, 3), 'unit': 'transitions/s', 'cores': nthreads, 'kind': 'port',
+            'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), Cin %d, batch %d, 1 warm-up (%.1f s) + '
+                      '%d timed calls (%.1f s) at the best thread count; sweep %s tr/s; host reports %d CPUs (%d usable)'
+                      % (cin, batch, warm, steps, dt, ', '.join('%d thr: %.1f' % (n, r) for r, n, _, _, _ in results),
+                         os.cpu_count() or 0, avail)}
 
 
-PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summary, kernel whose bytes per launch `roofline.traffic` quotes)
-    'fp32': ('r02_pmc_traffic.json', 'igemm_conv_kernel<64, 64, true, true>'),
-    'bf16': ('r02_pmc_traffic_bf16_b128.json', None),          # None: the kernel named by DOMINANT_BF16 below
+PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summaries newest first, kernel whose bytes per launch `roofline.traffic` quotes)
+    'fp32': (('r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true>'),
+    'bf16': (('r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
 }
 DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
 
 
 def pmc_traffic(precision):
-    """HBM-side bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes) from the committed
-    rocprofv3 PMC passes over this same command (profiles/r02_pmc_traffic*.json, tools/pmc_traffic.py); PMC counters cannot
-    be read from inside the timed process, so the value is the recorded one, or None when the file is absent."""
+    """(HBM-side bytes per launch of the dominant kernel, the file they were read from): FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes,
+    from the committed rocprofv3 PMC passes over this same command (tools/pmc_traffic.py).  PMC counters cannot be read from inside
+    the timed process, so this is a RECORDED number -- `traffic_source` in the line names the file -- or (None, None)."""
     if precision not in PMC_TRAFFIC:
-        return None
-    fname, kernel = PMC_TRAFFIC[precision]
-    for f in (fname, fname.replace('r02_', 'r01_')):
+        return None, None
+    files, kernel = PMC_TRAFFIC[precision]
+    for f in files:
         try:
             t = json.load(open(os.path.join(ROOT, 'profiles', f)))
         except (OSError, ValueError):
             continue
         if kernel is not None and kernel in t:
-            return round(t[kernel]['bytes_per_launch'])
+            return round(t[kernel]['bytes_per_launch']), 'profiles/' + f
         cand = [(v['launches'] * v['bytes_per_launch'], v) for k, v in t.items() if k.startswith(DOMINANT_BF16) or k.startswith('igemm_bf16_dma_kernel')]
         if kernel is None and cand:
-            return round(max(cand, key=lambda kv: kv[0])[1]['bytes_per_launch'])
-    return None
+            return round(max(cand, key=lambda kv: kv[0])[1]['bytes_per_launch']), 'profiles/' + f
+    return None, None
+
+
+KERNEL_NAMES = {
+    'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd layers -- 128->256, 256- and 512-channel 3x3 '
+            'convolutions: 16 GEMMs per launch for the grad-mode forward in F(2x2,3x3), 36 for the no-grad forwards, dgrads and weight '
+            'gradients in F(4x4,3x3); v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
+    'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
+              'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
+    'bf16': 'igemm_bf16_img_kernel (image-tile 3x3 convolution: one 24x24 map x 128 channels per block, halo patch in LDS, ping-pong wave '
+            'groups, v_mfma_f32_16x16x32_bf16): forward + dgrad of the 256- and 512-channel 3x3 convolutions; the 288-row LDS-DMA kernels of '
+            'the other layers are counted under all_gemm_tiles)'}
+
+
+def resolve_workload(args, world):
+    name = args.workload if args.workload != 'auto' else AUTO.get(world, 'weak32')
+    w = dict(WORKLOADS[name], name=name)
+    if args.cin is not None:
+        w['nets'] = [(args.cin, 2)]
+        w['config'] += ' [--cin %d]' % args.cin
+    if args.precision is not None:
+        w['precision'] = args.precision
+    if args.batch is not None:
+        w.pop('global_batch', None)
+        w['per_gpu'] = args.batch
+        w['config'] += ' [--batch %d per GPU]' % args.batch
+    if 'per_gpu' in w:
+        w['global_batch'] = w['per_gpu'] * world
+        w['scaling'] = 'weak'
+    else:
+        if w['global_batch'] % world:
+            sys.exit('bench.py: %s has a global minibatch of %d, not divisible by %d ranks' % (name, w['global_batch'], world))
+        w['per_gpu'] = w['global_batch'] // world
+        w['scaling'] = 'strong'          # the config fixes the TOTAL minibatch; more GPUs shard it
+    return w
 
 
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    import numpy as np
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no GPU visible); there is no CPU product path')
     ndev = torch.cuda.device_count()
     if world > 1 and args.backend == 'nccl' and ndev < world:
-        sys.exit('bench.py: %d ranks need %d GPUs, only %d visible' % (world, world, ndev))
+        sys.exit('bench.py: %d ranks need %d GPUs, only %d visible (--backend gloo stacks ranks on one GPU to debug the rank logic)' % (world, world, ndev))
     local_dev = local_rank % ndev       # (gloo debugging may stack ranks on one GPU)
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
@@ -153,78 +237,97 @@ def main():
 
     import simq
     from simq import dist as sdist, synth
-    from simq._lib import lib
+    from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
     from simq.learner import _opt_state, train_step
 
     # gradient exchange: libsimq's own RCCL communicator (simq_comm_*: the data-parallel step is then ONE library call, buckets on
     # the communicator's stream); checked once against torch.distributed's all-reduce.  If RCCL cannot be initialised through
-    # the library on this node the step falls back to torch.distributed's RCCL collectives around the backward phases -- still
-    # RCCL over xGMI, never a CPU path.  `transport` in the JSON line says which one ran.
-    comm, transport = None, 'none (single GPU)'
+    # the library on this node the step uses torch.distributed's RCCL collectives around the backward phases -- still
+    # RCCL over xGMI, never a CPU path.  Comm's construction fails on EVERY rank or on none (simq.dist.Comm), and the check below
+    # is agreed with a MIN all-reduce, so the ranks cannot end up on different transports.
+    comm, transport, comm_world = None, 'none (single GPU)', None
     if pg is not None:
         transport = 'torch.distributed (%s)' % args.backend
         if args.backend == 'nccl' and os.environ.get('SIMQ_BENCH_COMM', '1') != '0':
             try:
                 comm = sdist.Comm(pg, dev)
-                probe = torch.arange(1024, dtype=torch.float32, device=dev) * (rank + 1)
-                want = probe.clone()
-                torch.distributed.all_reduce(want, group=pg)
-                comm.all_reduce(probe)
-                comm.wait()
-                torch.cuda.synchronize(dev)
-                ok = torch.tensor([1.0 if torch.equal(probe, want) else 0.0], device=dev)
-                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=pg)
-                if float(ok.item()) != 1.0:
-                    raise RuntimeError('simq_comm all-reduce disagrees with torch.distributed')
-                transport = 'libsimq simq_comm (RCCL, library-owned stream)'
-            except Exception as ex:            # noqa: BLE001  (report and use the other RCCL transport)
+            except Exception as ex:            # noqa: BLE001  (collective failure: every rank is here)
                 if rank == 0:
                     print('bench: simq_comm unavailable (%r); using torch.distributed collectives' % (ex,), file=sys.stderr)
                 comm = None
+            if comm is not None:
+                probe = torch.arange(1024, dtype=torch.float32, device=dev) * (rank + 1)
+                want = probe.clone()
+                torch.distributed.all_reduce(want, group=pg)
+                good = 1.0
+                try:
+                    comm.all_reduce(probe)
+                    comm.wait()
+                    torch.cuda.synchronize(dev)
+                    good = 1.0 if torch.equal(probe, want) else 0.0
+                except Exception:              # noqa: BLE001
+                    good = 0.0
+                ok = torch.tensor([good], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=pg)
+                if float(ok.item()) != 1.0:
+                    if rank == 0:
+                        print('bench: simq_comm all-reduce disagrees with torch.distributed; using torch.distributed collectives', file=sys.stderr)
+                    comm.close()
+                    comm = None
+                else:
+                    transport = 'libsimq simq_comm (RCCL, library-owned stream)'
+                    comm_world = comm.world_size()
 
-    def run_workload(CIN, BATCH_PER_GPU, precision, steps, warmup, replay_items):
-        # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
-        # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
-        # stay O(1) so that many steps of synthetic training remain finite
-        torch.manual_seed(20260928)
-        policy = simq.FCN(CIN, COUT, device=dev, precision=precision)
-        target = simq.FCN(CIN, COUT, device=dev, precision=precision)
-        target.copy_state_from(policy)
-        policy.train()
-        target.eval()
-        st_opt = _opt_state(policy, None)
+    def barrier():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
 
-        # synthetic replay, resident in HBM before the timed region (same content on every rank)
-        trs = synth.make_transitions(replay_items, CIN, COUT, 5, terminal_frac=0.1)
-        ring = simq.DeviceReplayBuffer(replay_items, CIN, device=dev)
-        ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
-                       np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
-                       [t[3] is None for t in trs])
-        B, gB = BATCH_PER_GPU, BATCH_PER_GPU * world
-        random.seed(1234)                   # every rank draws the same global minibatch, then takes its slice
+    def run_workload(nets, B, precision, steps, warmup, replay_items):
+        """nets: [(Cin, Cout)] -- one policy/target pair, optimiser state and replay ring per robot group (train.py:180-195);
+        B: this rank's transitions per net and step."""
+        gB = B * world
+        groups = []
+        for gi, (cin, cout) in enumerate(nets):
+            # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
+            # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
+            # stay O(1) so that many steps of synthetic training remain finite
+            torch.manual_seed(20260928 + gi)
+            policy = simq.FCN(cin, cout, device=dev, precision=precision)
+            target = simq.FCN(cin, cout, device=dev, precision=precision)
+            target.copy_state_from(policy)
+            policy.train()
+            target.eval()
+            # synthetic replay, resident in HBM before the timed region (same content on every rank), filled in chunks
+            ring = simq.DeviceReplayBuffer(replay_items, cin, device=dev)
+            for c0 in range(0, replay_items, 1000):
+                trs = synth.make_transitions(min(1000, replay_items - c0), cin, cout, 5 + 31 * gi + c0, terminal_frac=0.1)
+                ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
+                               np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
+                               [t[3] is None for t in trs])
+            groups.append(dict(policy=policy, target=target, ring=ring, opt=_opt_state(policy, None), drawn=None, cin=cin, cout=cout))
+        random.seed(1234)                   # every rank draws the same global minibatches, then takes its slice
 
-        def draw():
-            idx = ring.sample_indices(gB)
-            return ring.gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
-
-        drawn = [None]
+        def draw(g):
+            idx = g['ring'].sample_indices(gB)
+            return g['ring'].gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
 
         def step():
-            # One minibatch draw (host-side picks + index upload + HBM gather) and one train() per step, as in train.py:252-258.
-            # The draw for step k+1 is issued while step k's kernels run and BEFORE step k's loss is read back (the
+            # train.py:252-258: per robot group one minibatch draw (host-side picks + index upload + HBM gather) and one train().
+            # The draw a group needs NEXT step is issued while this step's kernels run and BEFORE its loss is read back (the
             # reference's .item() sync), so the host-side sampler is hidden behind the GPU instead of idling it; picks, their
-            # order and the work per step are unchanged (the replay ring is static during the benchmark).
-            batch = drawn[0] if drawn[0] is not None else draw()
-            out4 = train_step(policy, target, batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
-                              opt_state=st_opt, process_group=pg, global_batch=gB, sync=False, comm=comm)
-            drawn[0] = draw()
-            o = out4.tolist()
-            return {'td_error': o[1] / gB, 'loss': o[0] / gB}
-
-        def barrier():
-            if pg is not None:
-                torch.distributed.barrier()
-            torch.cuda.synchronize(dev)
+            # order per group and the work per step are unchanged (the replay ring is static during the benchmark).
+            info = None
+            for g in groups:
+                batch = g['drawn'] if g['drawn'] is not None else draw(g)
+                out4 = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
+                                  opt_state=g['opt'], process_group=pg, global_batch=gB, sync=False, comm=comm)
+                g['drawn'] = draw(g)
+                o = out4.tolist()                                   # train.py:138-139
+                info = {'td_error': o[1] / gB, 'loss': o[0] / gB}
+                if not np.isfinite(info['loss']):
+                    sys.exit('bench: non-finite loss %r' % (info,))
+            return info
 
         for _ in range(warmup):
             info = step()
@@ -236,26 +339,24 @@ def main():
         dt = time.perf_counter() - t0
         if pg is not None:
             dt = sdist.max_over_ranks(dt, dev, pg)
-        if not np.isfinite(info['loss']):
-            sys.exit('bench: non-finite loss %r' % (info,))
-        value = gB * steps / dt
+        value = gB * len(groups) * steps / dt
 
         # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
-        # backward only -- no next-state forwards, clip or SGD.  Reported beside the full-step `value`, never instead of it.
-        from simq._lib import MODE_TRAIN, ptr, stream_ptr
-        idx = ring.sample_indices(gB)
-        fb = ring.gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
-        nq = COUT * 96 * 96
-        fb_out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
-        fb_o4 = torch.empty(4, dtype=torch.float32, device=dev)
-        fb_nsv = torch.zeros(B, dtype=torch.float32, device=dev)
+        # backward only -- no next-state forwards, all-reduce, clip or SGD.  Reported beside the full-step `value`, never instead of it.
+        m1 = []
+        for g in groups:
+            idx = g['ring'].sample_indices(gB)
+            fb = g['ring'].gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
+            m1.append(dict(fb=fb, nq=g['cout'] * 96 * 96, out=[torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)],
+                           o4=torch.empty(4, dtype=torch.float32, device=dev), nsv=torch.zeros(B, dtype=torch.float32, device=dev)))
 
         def fwd_bwd():
-            q = policy._forward_raw(fb.state, MODE_TRAIN)
-            dq = torch.empty_like(q)
-            lib.call('simq_td_huber', ptr(q), B, nq, ptr(fb.action), ptr(fb.reward), ptr(fb_nsv), GAMMA, 1.0 / gB, ptr(fb_out[0]),
-                     ptr(fb_out[1]), ptr(fb_out[2]), ptr(fb_o4), ptr(dq), stream_ptr(dev))
-            policy._backward_raw(dq, B)
+            for g, m in zip(groups, m1):
+                q = g['policy']._forward_raw(m['fb'].state, MODE_TRAIN)
+                dq = torch.empty_like(q)
+                lib.call('simq_td_huber', ptr(q), B, m['nq'], ptr(m['fb'].action), ptr(m['fb'].reward), ptr(m['nsv']), GAMMA, 1.0 / gB,
+                         ptr(m['out'][0]), ptr(m['out'][1]), ptr(m['out'][2]), ptr(m['o4']), ptr(dq), stream_ptr(dev))
+                g['policy']._backward_raw(dq, B)
 
         dt_m1 = float('nan')
         if not args.no_m1:
@@ -267,38 +368,23 @@ def main():
                 fwd_bwd()
             barrier()
             dt_m1 = time.perf_counter() - t2
-        if pg is not None and not args.no_m1:
-            dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
+            if pg is not None:
+                dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
+        return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'B': B, 'gB': gB, 'n_nets': len(groups),
+                'm1': None if args.no_m1 else gB * len(groups) * steps / dt_m1, 'groups': groups}
 
-        return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'barrier': barrier, 'B': B, 'gB': gB}
-
-    global CIN, BATCH_PER_GPU
-    CIN, BATCH_PER_GPU = args.cin, args.batch
-    w = run_workload(CIN, BATCH_PER_GPU, args.precision, args.steps, args.warmup, REPLAY_ITEMS)
-    value, dt, dt_m1, info, step, barrier, B, gB = (w[k] for k in ('value', 'dt', 'dt_m1', 'info', 'step', 'barrier', 'B', 'gB'))
-
-    KERNEL_NAMES = {
-        'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd layers -- 128->256, 256- and 512-channel 3x3 '
-                'convolutions: 16 GEMMs per launch for the grad-mode forward in F(2x2,3x3), 36 for the no-grad forwards, dgrads and weight '
-                'gradients in F(4x4,3x3); v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
-        'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
-                  'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
-        'bf16': 'igemm_bf16_img_kernel (image-tile 3x3 convolution: one 24x24 map x 128 channels per block, halo patch in LDS, ping-pong wave '
-                'groups, v_mfma_f32_16x16x32_bf16): forward + dgrad of the 256- and 512-channel 3x3 convolutions; the 288-row LDS-DMA kernels of '
-                'the other layers are counted under all_gemm_tiles)'}
-
-    def roofline_pass(step_fn, barrier_fn, steps, precision, ms_per_step, per_gpu_rate):
+    def roofline_pass(step_fn, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
         `steps` more steps with the two-stream overlap off, so that every bracket times one kernel alone."""
         import simq.learner as slearner
         keep = slearner.OVERLAP_TARGET_FORWARD
         slearner.OVERLAP_TARGET_FORWARD = False
         lib.call('simq_profile_start')
-        barrier_fn()
+        barrier()
         t1 = time.perf_counter()
         for _ in range(steps):
             step_fn()
-        barrier_fn()
+        barrier()
         dt_inst = time.perf_counter() - t1
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
@@ -308,19 +394,19 @@ def main():
         oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # kind 2: every other implicit-GEMM tile
         allg = {k: dom[k] + oth[k] for k in dom}
         # fp32: the batched GEMM of the Winograd layers (EXECUTED flops: 16 x 2*T*Cout*Cin per launch, 2.25x fewer than the 3x3
-        # convolution it implements); bf16: the large-tile LDS-DMA kernel; when a precision has no kind-0 launches, all tiles
+        # convolution it implements); bf16: the image-tile kernel; when a precision has no kind-0 launches, all tiles
         ig = dom if dom['launches'] > 0 else allg
         tf = lambda d: d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
         PEAK = PEAK_FP32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
         executed = (dom['flops'] + oth['flops'] + wg['flops']) / steps          # matrix-core flops actually issued per step
+        traffic, traffic_source = pmc_traffic(precision)
         return {
             'bound': 'mfma', 'kernel': KERNEL_NAMES[precision],
             'achieved': round(tf(ig), 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(tf(ig) / PEAK, 4),
-            'traffic': pmc_traffic(precision),
+            'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_step': ig['launches'] / steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
             'algorithmic_flops_per_launch': ig['flops'] / max(ig['launches'], 1),
             'kernel_ms_per_step': round(ig['ms'] / steps, 4),
-            
             # flat copies of the secondary figures (nested objects do not survive the driver's summary of the line)
             'all_gemm_tiles_launches_per_step': allg['launches'] / steps, 'all_gemm_tiles_ms_per_step': round(allg['ms'] / steps, 4),
             'all_gemm_tiles_achieved': round(tf(allg), 2), 'all_gemm_tiles_frac': round(tf(allg) / PEAK, 4),
@@ -333,62 +419,100 @@ def main():
             'ms_per_step_instrumented': round(dt_inst / steps * 1e3, 3),
         }
 
+    def per_rank(roof):
+        """Every rank's own dominant-kernel figure (each rank times its own launches), gathered to rank 0."""
+        if pg is None or roof is None:
+            return None
+        mine = {'rank': rank, 'achieved': roof['achieved'], 'frac': roof['frac'], 'kernel_ms_per_step': roof['kernel_ms_per_step']}
+        every = [None] * world
+        torch.distributed.all_gather_object(every, mine, group=pg)
+        return every
+
+    def release(w):
+        for g in w['groups']:
+            g.clear()
+        w.clear()
+        torch.cuda.empty_cache()
+
+    wl = resolve_workload(args, world)
+    w = run_workload(wl['nets'], wl['per_gpu'], wl['precision'], args.steps, args.warmup, args.replay)
+    value, dt, info, gB = w['value'], w['dt'], w['info'], w['gB']
     roof = None
     if not args.no_roofline:
-        roof = roofline_pass(step, barrier, args.steps, args.precision, dt / args.steps * 1e3, value / world)
+        roof = roofline_pass(w['step'], args.steps, wl['precision'], dt / args.steps * 1e3, value / world)
+        ranks_roof = per_rank(roof)
+        if ranks_roof is not None:
+            roof['per_rank'] = ranks_roof
+    m1, dt_m1, n_nets = w['m1'], w['dt_m1'], w['n_nets']
+    release(w)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(min(BATCH_PER_GPU, 32))
+        cpu = cpu_baseline(wl['nets'][0][0], wl['nets'][0][1], min(wl['per_gpu'], 32))
 
-    # BASELINE configs[2] (lifting_4-small_divider: Cin=5, batch 128, bf16 operands) on the opt-in bf16 matrix-core path,
-    # reported beside the fp32 headline, never instead of it (N=1 default run only; a few seconds)
-    extras, roof_bf16 = None, None
-    if world == 1 and args.precision == 'fp32' and not args.no_extras and args.cin == 4 and args.batch == 32:
+    # second leg, reported beside the headline, never instead of it.  N=1 (configs[1] headline): BASELINE configs[2] on the bf16
+    # matrix-core path.  N>1: the weak-scaling form (configs[1]'s net at 32 transitions per GPU) next to the config-faithful value.
+    extra_name = None
+    if not args.no_extras and args.batch is None and args.cin is None and args.precision is None:
+        if world == 1 and wl['name'] == 'configs1':
+            extra_name = 'configs2'
+        elif world > 1 and wl['name'] != 'weak32':
+            extra_name = 'weak32'
+    extras, roof_x = None, None
+    if extra_name is not None:
+        xl = resolve_workload(argparse.Namespace(workload=extra_name, cin=None, precision=None, batch=None), world)
         try:
-            e = run_workload(5, 128, 'bf16', 10, 3, 256)
-            extras = {'workload': 'BASELINE configs[2] lifting_4-small_divider (Cin=5), minibatch 128, bf16 operands (f32 accumulate / BN / optimiser)',
-                      'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / 10 * 1e3, 3),
-                      'fwd_bwd_only_transitions_per_s': round(e['gB'] * 10 / e['dt_m1'], 1),
-                      'fwd_bwd_only_ms_per_step': round(e['dt_m1'] / 10 * 1e3, 3), 'last_loss': e['info']['loss']}
+            e = run_workload(xl['nets'], xl['per_gpu'], xl['precision'], args.steps, args.warmup, args.replay)
+            extras = {'workload': '%s: Cin %d, global minibatch %d (%d per GPU), %s' % (xl['config'], xl['nets'][0][0], e['gB'], e['B'], DTYPE_NAMES[xl['precision']]),
+                      'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / args.steps * 1e3, 3),
+                      'steps': args.steps, 'warmup': args.warmup, 'scaling': xl['scaling'],
+                      'fwd_bwd_only_transitions_per_s': None if e['m1'] is None else round(e['m1'], 1),
+                      'fwd_bwd_only_ms_per_step': None if e['m1'] is None else round(e['dt_m1'] / args.steps * 1e3, 3), 'last_loss': e['info']['loss']}
             if not args.no_roofline:
-                roof_bf16 = roofline_pass(e['step'], e['barrier'], 10, 'bf16', e['dt'] / 10 * 1e3, e['value'])
-            del e
-            torch.cuda.empty_cache()
-        except Exception as ex:       # the headline line must not depend on the opt-in leg
+                roof_x = roofline_pass(e['step'], args.steps, xl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
+            release(e)
+        except Exception as ex:       # the headline line must not depend on the second leg
+            if pg is not None:
+                raise                 # (a rank that left the collectives cannot rejoin them)
             extras = {'error': repr(ex)}
 
     if rank == 0:
-        m1 = None if args.no_m1 else round(gB * args.steps / dt_m1, 2)
+        cin0 = wl['nets'][0][0]
+        flop_m1, flop_m2 = FLOPS.get(cin0, FLOPS[5])
         line = {
-            'metric': 'Q-map transitions/sec (full train() step: 3 fwd + bwd + clip + SGD, 96x96)',
+            'metric': 'Q-map transitions/sec, 96x96: `value` = full train() step (M2: policy fwd + bwd, double-DQN next-state forwards, clip, SGD); '
+                      '`value_fwd_bwd_only` = policy fwd+bwd alone (M1, the literal reading of "fwd+bwd")',
             'value': round(value, 2), 'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMA products, f32 accumulate)', 'bf16': 'bf16 (f32 accumulate / BN / optimiser)'}[args.precision], 'data': 'synthetic',
-            # BASELINE's metric text says "fwd+bwd": the literal reading (M1 of SURVEY 8d: policy forward + gather + Huber + backward only,
-            # no next-state forwards / all-reduce / clip / SGD) beside the full-step `value` (M2), never instead of it
-            'value_fwd_bwd_only': m1, 'ms_per_step_fwd_bwd_only': None if args.no_m1 else round(dt_m1 / args.steps * 1e3, 3),
-            'config': {'workload': '%s (Cin=%d, Cout=2, 96x96), minibatch %d per GPU, double DQN, '
-                                   'device-resident replay of %d transitions' % ('lifting_1-small_empty' if CIN == 4 else 'Cin=%d variant' % CIN, CIN, BATCH_PER_GPU, REPLAY_ITEMS),
-                       'global_batch': gB, 'parallelism': 'dp%d' % world, 'gradient_transport': transport,
-                       'flop_per_transition': FLOP_M2, 'flop_per_transition_fwd_bwd_only': FLOP_M1,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': wl['scaling'],
+            'vs_baseline': None, 'dtype': DTYPE_NAMES[wl['precision']], 'data': 'synthetic',
+            'value_fwd_bwd_only': None if m1 is None else round(m1, 2),
+            'ms_per_step_fwd_bwd_only': None if m1 is None else round(dt_m1 / args.steps * 1e3, 3),
+            'config': {'workload': '%s: %s, 96x96, global minibatch %d%s = %d per GPU%s, double DQN, device-resident replay of %d transitions per net'
+                                   % (wl['config'], ' + '.join('Cin=%d->Cout=%d' % n for n in wl['nets']), gB, ' per net' if n_nets > 1 else '',
+                                      wl['per_gpu'], ' and net' if n_nets > 1 else '', args.replay),
+                       'workload_key': wl['name'], 'nets': n_nets, 'global_batch': gB, 'per_gpu_batch': wl['per_gpu'],
+                       'transitions_per_step': gB * n_nets, 'parallelism': 'dp%d' % world,
+                       'gradient_transport': transport, 'simq_comm_world_size': comm_world, 'backend': args.backend if world > 1 else None,
+                       'flop_per_transition': flop_m2, 'flop_per_transition_fwd_bwd_only': flop_m1,
                        'last_loss': info['loss'], 'last_td_error': info['td_error']},
             'roofline': roof, 'cpu_baseline': cpu,
         }
-        if extras is not None:      # BASELINE configs[2] on the opt-in bf16 path: flat `bf16_*` keys + its own roofline object
-            line['bf16_configs2'] = extras
-            line['roofline_bf16_configs2'] = roof_bf16
+        if extras is not None:
+            key = 'bf16_configs2' if extra_name == 'configs2' else extra_name
+            line[key] = extras
+            line['roofline_' + key] = roof_x
             for k in ('full_step_transitions_per_s', 'fwd_bwd_only_transitions_per_s', 'ms_per_step'):
                 if k in extras:
-                    line['config']['bf16_configs2_' + k] = extras[k]
-            if roof_bf16 is not None:
-                for k in ('achieved', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step', 'whole_step_executed_frac',
-                          'wgrad_frac', 'all_gemm_tiles_frac'):
-                    line['roofline']['bf16_configs2_' + k] = roof_bf16[k]
-        print(json.dumps(line))
+                    line['config'][key + '_' + k] = extras[k]
+            if roof_x is not None and roof is not None:
+                for k in ('achieved', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step',
+                          'whole_step_executed_frac', 'wgrad_frac', 'all_gemm_tiles_frac'):
+                    line['roofline'][key + '_' + k] = roof_x[k]
+        print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()
     if pg is not None:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

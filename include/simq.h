@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 201            /* 0.2.1 */
+#define SIMQ_VERSION 300            /* 0.3.0 */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -144,8 +144,11 @@ int simq_backward_sync(const simq_plan* plan, int batch, const float* d_params, 
 int simq_comm_reduce_f64(void* comm, double* d_buf, int64_t count, void* stream);
 /* A rank whose shard holds no input for a synchronised train-mode forward (the double-DQN forward over the non-final next states of
  * an all-terminal shard) still has to take part in that forward's reductions: contributes zeros, in the forward's order.
+ * The reduced sums are the global batch statistics: with d_bnbuf != NULL the rank also applies the running-mean / running-var
+ * update the other ranks apply (momentum 0.1, unbiased variance over rows x sync->global_batch), so that its BatchNorm buffers do
+ * not drift from theirs (the caller counts the forward in num_batches_tracked like the ranks that had rows).
  * d_workspace: any workspace of this plan sized for `layout_batch` >= 1. */
-int simq_forward_sync_null(const simq_plan* plan, int layout_batch, void* d_workspace, void* stream, const simq_sync* sync);
+int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnbuf, void* d_workspace, void* stream, const simq_sync* sync);
 
 /* ---- learner pieces of train() (train.py:115-129) -------------------------------------------- */
 /* flat max / first-index argmax over each row of d_q [rows][n]  (train.py:121,124; policies.py:64) */

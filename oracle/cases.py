@@ -27,6 +27,10 @@ FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), (
 TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
 # the bench workload's own size (BASELINE configs[1]); summaries only, checked on the GPU without re-running the oracle
 TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
+# BASELINE configs[2] / configs[4]'s per-GPU shape (Cin 5, Cout 2, 128 transitions) and configs[3]'s two per-GPU shapes (Cin 5; lifting
+# Cout 2 and pushing Cout 1, 64 transitions per GPU and net): reference train.train at the batch sizes the large-batch kernels are
+# selected at, summaries + fp64 yardstick + the reference's own bf16-autocast error AT THAT SIZE (gen_golden.gen_train_sized)
+TRAIN_CASES_SIZED = [('train_c5o2_b128', 5, 2, 128, 61, 71), ('train_c5o2_b64', 5, 2, 64, 62, 72), ('train_c5o1_b64', 5, 1, 64, 63, 73)]
 # data-parallel emulation (SURVEY 8e / fixture G7): (name, cin, cout, global batch, shards, weight seed, data seed)
 DP_CASES = [('dp_c5o2_b8_w1', 5, 2, 8, 1, 37, 50), ('dp_c5o2_b8_w2', 5, 2, 8, 2, 37, 50), ('dp_c5o2_b8_w4', 5, 2, 8, 4, 37, 50),
             ('dp_c5o2_b8_w8', 5, 2, 8, 8, 37, 50), ('dp_c5o1_b8_w2', 5, 1, 8, 2, 38, 48)]

@@ -33,6 +33,66 @@ sys.modules['torch.utils.tensorboard'] = _tb                     # train.py:17
 import networks as ref_networks  # noqa: E402
 import train as ref_train  # noqa: E402
 
+
+def import_ref_policies():
+    """The reference's own policies.py, imported with the two modules this image lacks replaced by what policies.py uses of them:
+    torchvision.transforms.ToTensor on a float32 HWC ndarray (policies.py:19,45: CHW tensor, no rescaling for float input) and the
+    three VectorEnv statics (envs.py:366-376 -> the constants at envs.py:810,1090,2010).  Nothing else of either module is touched
+    by policies.py:11-146."""
+    if 'policies' in sys.modules:
+        return sys.modules['policies']
+    tv, tvt = types.ModuleType('torchvision'), types.ModuleType('torchvision.transforms')
+
+    class ToTensor:
+        def __call__(self, pic):
+            assert isinstance(pic, np.ndarray) and pic.dtype == np.float32 and pic.ndim == 3
+            return torch.from_numpy(np.ascontiguousarray(pic.transpose(2, 0, 1)))
+    tvt.ToTensor = ToTensor
+    tv.transforms = tvt
+    envs = types.ModuleType('envs')
+
+    class VectorEnv:
+        _channels = {'pushing_robot': 1, 'lifting_robot': 2, 'throwing_robot': 2, 'rescue_robot': 2}    # envs.py:810,1090 (+ subclasses)
+
+        @staticmethod
+        def get_state_width():
+            return 96                                                                                # envs.py:2010
+
+        @staticmethod
+        def get_num_output_channels(robot_type):
+            if robot_type not in VectorEnv._channels:
+                raise Exception(robot_type)                                                          # envs.py:1052
+            return VectorEnv._channels[robot_type]
+
+        @staticmethod
+        def get_action_space(robot_type):
+            return VectorEnv.get_num_output_channels(robot_type) * 96 * 96                           # envs.py:376
+    envs.VectorEnv = VectorEnv
+    saved = {k: sys.modules.get(k) for k in ('torchvision', 'torchvision.transforms', 'envs')}
+    sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt, 'envs': envs})
+    try:
+        import policies as ref_policies
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ref_policies
+
+
+def ref_policy(cls_name, cfg, seeds, random_seed):
+    """policies.DQNPolicy / DQNIntentionPolicy of the reference itself with seeded weights loaded into the nets it built
+    (build_policy_nets draws torch-RNG initial weights; the python `random` stream policies.py:17 seeds is untouched by that)."""
+    pol = getattr(import_ref_policies(), cls_name)(cfg, train=False, random_seed=random_seed)
+    nets = list(pol.policy_nets) + list(getattr(pol, 'intention_nets', []))
+    for net, (cin, cout, seed) in zip(nets, seeds):
+        sd = fcn.state_from_numpy(synth.make_state_dict(cin, cout, seed))
+        assert list(sd.keys()) == list(net.state_dict().keys())
+        net.load_state_dict(sd)
+        net.eval()                                  # (policies.py:31-32 does this for a loaded checkpoint when train=False)
+    return pol
+
 from oracle import cases, fcn, learner  # noqa: E402
 from oracle import policy as opolicy  # noqa: E402
 from simq import synth  # noqa: E402
@@ -142,6 +202,121 @@ def gen_train(case_list=None):
         np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'), **out)
         print('train case', name, 'oracle == reference (bit-exact, 2 steps); ref fp32 grad rel err vs fp64 = %.3g'
               % out['ref_fp32_grad_relerr'])
+
+
+def gen_train_sized(case_list=None):
+    """BASELINE configs[2..4]'s per-GPU shapes (cases.TRAIN_CASES_SIZED): the reference's own train.train (imported), two consecutive
+    calls in fp32, bit-exact against the oracle; the fp64 oracle as the yardstick; and the error the REFERENCE makes on the same
+    batch (i) in its own fp32 and (ii) with its own modules under torch.autocast('cpu', bfloat16) -- the calibration the HIP bf16
+    path is held to at these sizes (train-mode BatchNorm over 64-128 samples is well conditioned, unlike the 4-8 sample fixtures).
+    Only summaries are stored: scalars, per-transition q / y, per-tensor gradient norms and 16 sampled elements per tensor of the
+    gradient and of the first parameter update."""
+    from torch.nn.functional import smooth_l1_loss
+    import time
+    for name, cin, cout, B, wseed, dseed in (case_list or cases.TRAIN_CASES_SIZED):
+        t_start = time.time()
+        cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
+        gkeys = learner.grad_keys(spec)
+        # --- the reference itself, fp32, two steps ---
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)   # train.py:186
+        p0 = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+        info_ref = [ref_train.train(cfg, policy, target, opt, batch, learner.apply_transform, cases.GAMMA)]
+        p1_ref = {k: v.detach().clone() for k, v in policy.state_dict().items()}
+        info_ref.append(ref_train.train(cfg, policy, target, opt, batch, learner.apply_transform, cases.GAMMA))
+        # --- oracle fp32, bit-exact (also hands out the pre-clip gradient) ---
+        st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        mom, extras = [None] * len(gkeys), [{}, {}]
+        info_or = [learner.train_step(cfg, st, tg, spec, mom, batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                      extras=extras[i]) for i in range(2)]
+        assert info_or == info_ref, (name, info_or, info_ref)
+        for k, v in policy.state_dict().items():
+            assert_same(st[k], v, name + ' post-step ' + k)
+        for (k, p), m in zip([(k, p) for k, p in policy.named_parameters() if p.grad is not None], mom):
+            assert_same(m, opt.state[p]['momentum_buffer'], name + ' momentum ' + k)
+        print('  %s: reference + oracle fp32 done (%.0f s)' % (name, time.time() - t_start), flush=True)
+        # --- oracle fp64, two steps ---
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        mom64, ex64 = [None] * len(gkeys), {}
+        i64 = [learner.train_step(cfg, st64, tg64, spec, mom64, batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                  dtype=torch.float64, extras=ex64)]
+        p1_64 = {k: st64[k].detach().clone() for k in gkeys}
+        bn1_64 = cases.bn_buffer_vector(st64)
+        i64.append(learner.train_step(cfg, st64, tg64, spec, mom64, batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY,
+                                      dtype=torch.float64))
+        print('  %s: oracle fp64 done (%.0f s)' % (name, time.time() - t_start), flush=True)
+        # --- the reference's modules under bf16 autocast (train.py:109-135 restated so that autocast wraps the three forwards) ---
+        pol16, tgt16 = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        pol16.train()
+        tgt16.eval()
+        state_b = torch.cat([learner.apply_transform(s) for s in batch.state])
+        act = torch.tensor(batch.action, dtype=torch.long)
+        rew = torch.tensor(batch.reward, dtype=torch.float32)
+        nf = torch.cat([learner.apply_transform(s) for s in batch.next_state if s is not None])
+        mask = torch.tensor([s is not None for s in batch.next_state], dtype=torch.bool)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            q16 = pol16(state_b).float().view(B, -1).gather(1, act.unsqueeze(1)).squeeze(1)
+            nsv = torch.zeros(B)
+            with torch.no_grad():
+                best = pol16(nf).float().view(nf.size(0), -1).max(1)[1].view(-1, 1)
+                nsv[mask] = tgt16(nf).float().view(nf.size(0), -1).gather(1, best).view(-1)
+        y16 = rew + cases.GAMMA * nsv
+        loss16 = smooth_l1_loss(q16, y16)
+        loss16.backward()
+        named16 = {('module.' + k if not k.startswith('module.') else k): p for k, p in pol16.module.named_parameters()}
+        g16 = {k: named16[k].grad.detach().clone() for k in gkeys}
+        opt16 = torch.optim.SGD(pol16.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+        torch.nn.utils.clip_grad_norm_(pol16.parameters(), cases.CLIP)
+        opt16.step()
+        p1_16 = {k: v.detach().clone() for k, v in pol16.state_dict().items()}
+        print('  %s: reference under bf16 autocast done (%.0f s)' % (name, time.time() - t_start), flush=True)
+
+        def sampled(d, cast=lambda t: t.double()):
+            return np.stack([cast(d[k]).reshape(-1)[torch.tensor(cases.sample_indices(d[k].numel()))].numpy() for k in gkeys])
+        rl2 = lambda a, b: float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum() / (b ** 2).sum()))
+        relmax = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+        g64s, g32s, g16s = sampled(ex64['grads']), sampled(extras[0]['grads']), sampled(g16)
+        d64s = sampled({k: p1_64[k] - p0[k].double() for k in gkeys})
+        d32s = sampled({k: p1_ref[k].double() - p0[k].double() for k in gkeys})
+        d16s = sampled({k: p1_16[k].double() - p0[k].double() for k in gkeys})
+        fullrel = lambda g: (sum(float((g[k].double() - ex64['grads'][k]).pow(2).sum()) for k in gkeys)
+                             / sum(float(ex64['grads'][k].pow(2).sum()) for k in gkeys)) ** 0.5
+        out = {
+            'loss': np.array([i['loss'] for i in info_ref]), 'td_error': np.array([i['td_error'] for i in info_ref]),
+            'total_norm': np.array([e['total_norm'] for e in extras]),
+            'q_sa': extras[0]['q'].numpy(), 'y': extras[0]['y'].numpy(),
+            'param_summary_after2': cases.param_summary(st, spec),
+            'bn_buffers_after2': cases.bn_buffer_vector(st).astype(np.float32),
+            'num_batches_tracked': np.array([int(st[k]) for k in st if k.endswith('num_batches_tracked')]),
+            # fp64 yardstick
+            'loss64': np.array([i['loss'] for i in i64]), 'td_error64': np.array([i['td_error'] for i in i64]),
+            'total_norm64': np.array(ex64['total_norm']), 'q_sa64': ex64['q'].numpy(), 'y64': ex64['y'].numpy(),
+            'grad_keys': np.array(gkeys),
+            'grad_norm64': np.array([float(ex64['grads'][k].norm()) for k in gkeys]),
+            'grad64': g64s, 'dparam64': d64s, 'bn_buffers_after1_64': bn1_64,
+            # the reference's own fp32 against fp64 (what "as accurate as the reference" means on this batch)
+            'ref_fp32_grad_relerr': np.array(fullrel(extras[0]['grads'])), 'ref_grad_err': np.array(rl2(g32s, g64s)),
+            'ref_dparam_err': np.array(rl2(d32s, d64s)),
+            'ref_loss_err': np.array([abs(info_ref[j]['loss'] - i64[j]['loss']) / abs(i64[j]['loss']) for j in range(2)]),
+            'ref_q_err': np.array(relmax(extras[0]['q'].numpy(), ex64['q'].numpy())),
+            # the reference under bf16 autocast against fp64, on this batch
+            'bf16cal_loss': np.array(abs(float(loss16.detach()) - i64[0]['loss']) / abs(i64[0]['loss'])),
+            'bf16cal_td_error': np.array(abs(float(torch.abs(q16 - y16).mean()) - i64[0]['td_error']) / abs(i64[0]['td_error'])),
+            'bf16cal_q_sa': np.array(relmax(q16.detach().numpy(), ex64['q'].numpy())),
+            'bf16cal_y': np.array(relmax(y16.detach().numpy(), ex64['y'].numpy())),
+            'bf16cal_grad': np.array(fullrel(g16)), 'bf16cal_grad_sampled': np.array(rl2(g16s, g64s)),
+            'bf16cal_dparam_sampled': np.array(rl2(d16s, d64s)),
+        }
+        np.savez_compressed(os.path.join(cases.GOLDEN_DIR, name + '.npz'), **out)
+        print('sized train case %s: oracle == reference (bit-exact, 2 steps).  vs fp64 -- reference fp32: grad %.3g (sampled %.3g), '
+              'update %.3g, loss %.2g / %.2g, q %.2g;  reference bf16-autocast: loss %.3g, td %.3g, q_sa %.3g, y %.3g, grad %.3g '
+              '(sampled %.3g), update %.3g   [%.0f s]'
+              % (name, out['ref_fp32_grad_relerr'], out['ref_grad_err'], out['ref_dparam_err'], out['ref_loss_err'][0],
+                 out['ref_loss_err'][1], out['ref_q_err'], out['bf16cal_loss'], out['bf16cal_td_error'], out['bf16cal_q_sa'],
+                 out['bf16cal_y'], out['bf16cal_grad'], out['bf16cal_grad_sampled'], out['bf16cal_dparam_sampled'],
+                 time.time() - t_start), flush=True)
 
 
 def gen_dp():
@@ -375,19 +550,34 @@ def gen_intention():
 
 
 def gen_intention_step():
-    """DQNIntentionPolicy.step fixture from the oracle restatement (policies.py is not importable here, see gen_step)."""
+    """DQNIntentionPolicy.step (policies.py:119-146, through step_intention :97-117) of the REFERENCE's own class, compared bit-exactly
+    with the oracle restatement, then stored."""
     cin = 5
     cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 1}, {'pushing_robot': 1}], num_input_channels=cin,
-                                final_exploration=0.01)
-    seeds = iter([71, 72, 73, 74])
+                                final_exploration=0.01, checkpoint_path=None)
+    wseeds = [71, 72, 73, 74]
+    ref = ref_policy('DQNIntentionPolicy', cfg, [(cin, 2, 71), (cin, 1, 72), (cin - 1, 1, 73), (cin - 1, 1, 74)], 9)
+    seeds = iter(wseeds)
     pol = opolicy.DQNIntentionPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=9)
     s = synth.make_states(2, cin - 1, 81)
+    a_ref, info_ref = ref.step([[s[0]], [s[1]]], exploration_eps=0.0, debug=True)
     a, info = pol.step([[s[0]], [s[1]]], exploration_eps=0.0, debug=True)
-    np.savez(os.path.join(cases.GOLDEN_DIR, 'intention_step.npz'), actions=np.array([a[0][0], a[1][0]], dtype=np.int64),
-             output_intention=np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]),
-             state_intention=np.stack([info['state_intention'][0][0], info['state_intention'][1][0]]),
-             q0=info['output'][0][0], q1=info['output'][1][0])
-    print('intention policy.step case saved (oracle restatement)')
+    assert a == a_ref, (a, a_ref)
+    for key in ('output_intention', 'state_intention', 'output'):
+        for i in range(2):
+            assert_same(info[key][i][0], info_ref[key][i][0], 'intention step %s[%d]' % (key, i))
+    # the non-debug call and a stochastic one consume the python RNG alike
+    random.seed(123)
+    r1 = [ref.step([[s[0]], [s[1]]], exploration_eps=0.5) for _ in range(3)]
+    random.seed(123)
+    o1 = [pol.step([[s[0]], [s[1]]], exploration_eps=0.5) for _ in range(3)]
+    assert r1 == o1, (r1, o1)
+    np.savez(os.path.join(cases.GOLDEN_DIR, 'intention_step.npz'), actions=np.array([a_ref[0][0], a_ref[1][0]], dtype=np.int64),
+             output_intention=np.stack([info_ref['output_intention'][0][0], info_ref['output_intention'][1][0]]),
+             state_intention=np.stack([info_ref['state_intention'][0][0], info_ref['state_intention'][1][0]]),
+             q0=info_ref['output'][0][0], q1=info_ref['output'][1][0],
+             eps_half_actions=np.array([[x[0][0], x[1][0]] for x in r1], dtype=np.int64))
+    print('intention policy.step case: oracle == reference policies.DQNIntentionPolicy (bit-exact); saved')
 
 
 def gen_tracker():
@@ -436,24 +626,28 @@ def gen_sampler():
 
 
 def gen_step():
-    """policies.py cannot be imported (torchvision/pybullet absent): the step()
-    fixture is produced by the oracle restatement; its network forward is the
-    reference-pinned fcn_forward and its RNG draw order follows policies.py:61-64."""
+    """DQNPolicy.step (policies.py:47-74) of the REFERENCE's own class (import_ref_policies) on seeded weights and states, compared
+    bit-exactly with the oracle restatement -- actions under exploration_eps 0 / 0.5 / 1 (the random.random() / randrange draw
+    order of policies.py:61-62), None entries, the debug outputs -- then stored."""
     cin, wseed = 4, 51
     cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], num_input_channels=cin,
-                                final_exploration=0.01)
-    seeds = iter([wseed, wseed + 1])
-    pol = opolicy.DQNPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=5)
+                                final_exploration=0.01, checkpoint_path=None)
+    ref = ref_policy('DQNPolicy', cfg, [(cin, 2, wseed), (cin, 1, wseed + 1)], 5)
     s = synth.make_states(3, cin, 61)
     state = [[s[0], None], [s[1]]]
-    acts = []
-    for eps in (0.0, 0.5, 1.0, 0.5):
-        acts.append(pol.step(state, exploration_eps=eps))
+    acts_ref = [ref.step(state, exploration_eps=eps) for eps in (0.0, 0.5, 1.0, 0.5)]
+    a_ref, info_ref = ref.step([[None, s[2]], [None]], exploration_eps=0.0, debug=True)
+    seeds = iter([wseed, wseed + 1])
+    pol = opolicy.DQNPolicy(cfg, lambda ci, co: cases.oracle_state(ci, co, next(seeds)), train=False, random_seed=5)
+    acts = [pol.step(state, exploration_eps=eps) for eps in (0.0, 0.5, 1.0, 0.5)]
     a, info = pol.step([[None, s[2]], [None]], exploration_eps=0.0, debug=True)
+    assert acts == acts_ref and a == a_ref, (acts, acts_ref, a, a_ref)
+    assert_same(info['output'][0][1], info_ref['output'][0][1], 'policy step debug output')
+    assert info_ref['output'][0][0] is None and info_ref['output'][1][0] is None
     np.savez(os.path.join(cases.GOLDEN_DIR, 'policy_step.npz'),
-             actions=np.array([[x[0][0], x[1][0]] for x in acts], dtype=np.int64),
-             debug_action=np.array([a[0][1]], dtype=np.int64), debug_output=info['output'][0][1])
-    print('policy.step case saved (oracle restatement; policies.py not importable here)')
+             actions=np.array([[x[0][0], x[1][0]] for x in acts_ref], dtype=np.int64),
+             debug_action=np.array([a_ref[0][1]], dtype=np.int64), debug_output=info_ref['output'][0][1])
+    print('policy.step case: oracle == reference policies.DQNPolicy (bit-exact); saved')
 
 
 if __name__ == '__main__':
@@ -461,7 +655,7 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
             'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration,
             'grad_study': gen_grad_study}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family

@@ -1,8 +1,12 @@
 """Oracle: CPU restatement of the reference DQNPolicy.  TEST INFRASTRUCTURE.
 
-/root/reference/policies.py cannot be imported here (needs torchvision, pybullet,
-anki_vector, skimage), so this follows policies.py:11-74 literally, with the
-three VectorEnv statics it calls replaced by the constants they return:
+Follows policies.py:11-146 literally, with the three VectorEnv statics it calls
+replaced by the constants they return (below).  PINNED: oracle/gen_golden.py
+imports the reference's own policies.py (torchvision.transforms.ToTensor and
+envs.VectorEnv's three statics stood in for, since torchvision / pybullet are
+absent here), runs policies.DQNPolicy / DQNIntentionPolicy on seeded weights and
+asserts actions, RNG draw order and debug outputs bit-exact against the classes
+below before it writes tests/golden/{policy,intention}_step.npz.
   envs.py:2010        Mapper.LOCAL_MAP_PIXEL_WIDTH = 96
   envs.py:810,1090    NUM_OUTPUT_CHANNELS: pushing 1; lifting/throwing/rescue 2
   envs.py:374-376     action space = channels * 96 * 96

@@ -138,6 +138,8 @@ struct BnRef {
 struct BnEvalDesc { int64_t g_off, b_off, buf_off, aux_off; int C, pad_; };
 struct BnEvalTable { BnEvalDesc d[24]; int n; };
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream);
+// running mean / var <- momentum update from [sum | sum of squares] over `rows` rows (no normalisation: simq_forward_sync_null)
+int launch_bn_running_update(const double* stats, float* rmean, float* rvar, double rows, int C, hipStream_t stream);
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
 // y_bf16: `y` points at bf16 values (uint16_t), see ConvEpilogue::y_bf16

@@ -666,6 +666,29 @@ inline int grid_for(size_t work_items, int block = 256, int cap = 256 * 8) {
 
 }  // namespace
 
+namespace {
+// running-statistics update of a train-mode BatchNorm from its (globally reduced) [sum | sum of squares] alone -- the commit
+// bn_commit performs inside the consuming kernel, for a rank that has no rows of its own to normalise (simq_forward_sync_null)
+__global__ void bn_running_update_kernel(const double* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar,
+                                         double rows, int C) {
+    const double inv_rows = 1.0 / rows;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = stats[c] * inv_rows;
+        double var = stats[C + c] * inv_rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+        rmean[c] = (float)(BN_MOMENTUM * mean + (1.0 - BN_MOMENTUM) * (double)rmean[c]);
+        rvar[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)rvar[c]);
+    }
+}
+}  // namespace
+
+int launch_bn_running_update(const double* stats, float* rmean, float* rvar, double rows, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(256), 0, stream, stats, rmean, rvar, rows, C);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream) {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(t.n), dim3(256), 0, stream, t, params, bnbuf, aux);
     SIMQ_CHECK_LAUNCH();

@@ -881,21 +881,31 @@ int simq_forward_sync(const simq_plan* plan, int mode, int batch, const float* d
     return forward_impl(c, mode, d_x, d_q);
 }
 
-int simq_forward_sync_null(const simq_plan* plan, int layout_batch, void* d_workspace, void* stream, const simq_sync* sync) {
+int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnbuf, void* d_workspace, void* stream, const simq_sync* sync) {
     SIMQ_REQUIRE(plan && d_workspace && sync && sync->reduce && layout_batch >= 1, "forward_sync_null: bad argument");
-    Ctx c{plan, layout_batch, nullptr, nullptr, nullptr, static_cast<char*>(d_workspace), make_layout(plan, layout_batch), static_cast<hipStream_t>(stream)};
+    Ctx c{plan, layout_batch, nullptr, nullptr, d_bnbuf, static_cast<char*>(d_workspace), make_layout(plan, layout_batch), static_cast<hipStream_t>(stream)};
     c.sync = sync;
     SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + c.L.red, 0, plan->red_total * sizeof(double), c.stream));
+    // One BatchNorm of the forward: zeros into the other ranks' sums; the reduced sums are the GLOBAL batch statistics, and this
+    // rank commits them to its running statistics exactly as the ranks that had rows do (bn_commit) -- its BatchNorm buffers stay
+    // equal to theirs, whichever rank's buffers are later broadcast / checkpointed.  rows_per_sample x global_batch rows.
+    auto one = [&](const BnL& bn, int64_t rows_per_sample) -> int {
+        RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));
+        if (d_bnbuf)
+            RC(launch_bn_running_update(c.red(bn), d_bnbuf + bn.buf_off, d_bnbuf + bn.buf_off + bn.C,
+                                        (double)rows_per_sample * (double)sync->global_batch, bn.C, c.stream));
+        return 0;
+    };
     // the order in which forward_impl's convolutions hand their statistics over: stem; per block conv1, conv2, downsample; head
-    RC(c.sync_reduce(c.red(plan->stem_bn), 2 * (int64_t)plan->stem_bn.C));
+    RC(one(plan->stem_bn, 2304));
     for (int i = 0; i < 8; ++i) {
         const BlockL& b = plan->blocks[i];
-        RC(c.sync_reduce(c.red(b.b1), 2 * (int64_t)b.b1.C));
-        RC(c.sync_reduce(c.red(b.b2), 2 * (int64_t)b.b2.C));
-        if (b.has_ds) RC(c.sync_reduce(c.red(b.bds), 2 * (int64_t)b.bds.C));
+        RC(one(b.b1, 576));
+        RC(one(b.b2, 576));
+        if (b.has_ds) RC(one(b.bds, 576));
     }
-    RC(c.sync_reduce(c.red(plan->hb1), 2 * (int64_t)plan->hb1.C));
-    RC(c.sync_reduce(c.red(plan->hb2), 2 * (int64_t)plan->hb2.C));
+    RC(one(plan->hb1, 576));
+    RC(one(plan->hb2, 2304));
     return 0;
 }
 
@@ -1001,7 +1011,7 @@ int simq_train_step(const simq_train_args* a) {
     if (Nn == 0 && sync && a->use_double_dqn && a->global_nonfinal > 0) {     // all-terminal shard: zeros into the other ranks' reductions
         simq_sync sync_nf = sync_storage;
         sync_nf.global_batch = a->global_nonfinal;
-        RC(simq_forward_sync_null(p, 1, a->ws_tmp, main, &sync_nf));
+        RC(simq_forward_sync_null(p, 1, a->bnbuf, a->ws_tmp, main, &sync_nf));
     }
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,

@@ -110,7 +110,7 @@ _SIGS = {
     'simq_backward_sync': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p]),
     'simq_comm_reduce_f64': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    'simq_forward_sync_null': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'simq_forward_sync_null': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_comm_unique_id': (c_int, [c_void_p]),
     'simq_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     'simq_comm_world_size': (c_int, [c_void_p]),

@@ -115,21 +115,46 @@ class Comm:
     submitted to the current stream; wait() makes the current stream wait for them."""
 
     def __init__(self, group=None, device=None):
-        from ._lib import COMM_ID_BYTES, lib
+        from ._lib import COMM_ID_BYTES, SimqError, lib
         self._lib = lib
+        self.handle = None
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        ident = (ctypes.c_ubyte * COMM_ID_BYTES)()
-        if self.rank == 0:
-            lib.call('simq_comm_unique_id', ident)
         on_device = dist.get_backend(group) == 'nccl'
-        t = torch.tensor(list(ident), dtype=torch.uint8, device=self.device if on_device else 'cpu')
+        where = self.device if on_device else 'cpu'
+        # Construction is collective and so is its failure: rank 0's identifier travels with a status byte, and the ranks agree
+        # (MIN) on whether every simq_comm_init succeeded -- either all of them hold a communicator or all of them raise, so a
+        # caller that falls back to another transport does so on every rank (no rank is left waiting in a collective).
+        ident = (ctypes.c_ubyte * COMM_ID_BYTES)()
+        status, why = 1, ''
+        if self.rank == 0:
+            try:
+                lib.call('simq_comm_unique_id', ident)
+            except Exception as ex:                          # noqa: BLE001  (e.g. librccl cannot be loaded)
+                status, why = 0, str(ex)
+        t = torch.tensor([status] + list(ident), dtype=torch.uint8, device=where)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = (ctypes.c_ubyte * COMM_ID_BYTES)(*t.cpu().tolist())
+        got = t.cpu().tolist()
+        if got[0] != 1:
+            raise SimqError('Comm: rank 0 could not draw an RCCL identifier%s' % ((': ' + why) if why else ''))
+        ident = (ctypes.c_ubyte * COMM_ID_BYTES)(*got[1:])
         h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            lib.call('simq_comm_init', ident, self.world, self.rank, ctypes.byref(h))
+        try:
+            with torch.cuda.device(self.device):
+                lib.call('simq_comm_init', ident, self.world, self.rank, ctypes.byref(h))
+        except Exception as ex:                              # noqa: BLE001
+            status, why, h = 0, str(ex), ctypes.c_void_p()
+        ok = torch.tensor([status], dtype=torch.int32, device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            if h:
+                lib.call('simq_comm_destroy', h)
+            raise SimqError('Comm: simq_comm_init failed on %s%s' % ('this rank' if status == 0 else 'another rank', (': ' + why) if why else ''))
         self.handle = h
+
+    def world_size(self):
+        """Ranks RCCL itself reports for the communicator (simq_comm_world_size)."""
+        return int(self._lib.c.simq_comm_world_size(self.handle))
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -143,6 +168,11 @@ class Comm:
         return tensor
 
     def broadcast(self, tensor, src=0):
+        from ._lib import SimqError
+        if not tensor.is_contiguous() or tensor.device != self.device:
+            raise SimqError('Comm.broadcast: contiguous tensor on %s expected (a permuted view would send the wrong bytes)' % self.device)
+        if not (0 <= int(src) < self.world):
+            raise SimqError('Comm.broadcast: src %r outside [0, %d)' % (src, self.world))
         self._lib.call('simq_comm_broadcast', self.handle, ctypes.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(),
                        int(src), self._stream())
         return tensor

@@ -345,8 +345,13 @@ def _opt_state(net, optimizer):
         buf = optimizer.state.get(p, {}).get('momentum_buffer')
         if buf is not None and (buf.data_ptr() != v.data_ptr() or buf.stride() != v.stride()):
             if tuple(buf.shape) != tuple(v.shape):
-                raise SimqError('optimizer state of %s has shape %s, expected %s (the reference layout)'
-                                % (name, tuple(buf.shape), tuple(v.shape)))
+                # checkpoints written before momentum buffers were presented in the reference's OIHW shape stored the OHWI
+                # storage shape: accept them (permute to the logical shape); anything else is an error
+                if buf.dim() == 4 and tuple(buf.permute(0, 3, 1, 2).shape) == tuple(v.shape):
+                    buf = buf.permute(0, 3, 1, 2)
+                else:
+                    raise SimqError('optimizer state of %s has shape %s, expected %s (the reference layout)'
+                                    % (name, tuple(buf.shape), tuple(v.shape)))
             v.copy_(buf.to(v.device))
             optimizer.state[p]['momentum_buffer'] = v
             st.initialised = True
@@ -430,7 +435,9 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     if Nn == 0:
         if use_double_dqn and bn_sync_nf is not None:       # all-terminal shard under SyncBN: zeros into the others' reductions
             ws0 = policy_net._workspace('tmp', 1)
-            lib.call('simq_forward_sync_null', policy_net.plan.handle, 1, ptr(ws0), st, bn_sync_nf.bind(ws0))
+            lib.call('simq_forward_sync_null', policy_net.plan.handle, 1, ptr(policy_net.bn_buffers), ptr(ws0), st, bn_sync_nf.bind(ws0))
+            for k in policy_net.num_batches_tracked:            # the global statistics were committed to this rank's buffers too
+                policy_net.num_batches_tracked[k] += 1
     elif use_double_dqn:
         # train.py:121: the POLICY net, still in train mode (batch statistics, 2nd running-stat update)
         q_next = policy_net._forward_raw(b.next_state, MODE_TRAIN_NOGRAD, sync=bn_sync_nf)
@@ -530,7 +537,9 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     # bookkeeping the separate calls do on the Python side
     policy_net._train_generation += 1
     for k in policy_net.num_batches_tracked:
-        policy_net.num_batches_tracked[k] += 2 if (use_double_dqn and Nn_real) else 1
+        # (an all-terminal shard under SyncBN still commits the second, global, running-stat update: simq_forward_sync_null)
+        second = use_double_dqn and (Nn_real or (a.sync_bn and a.global_nonfinal > 0))
+        policy_net.num_batches_tracked[k] += 2 if second else 1
     policy_net.weights_dirty = False          # the library refreshed the weight cache behind the SGD update
     policy_net._weights_stamp += 1
     st_opt.initialised = True

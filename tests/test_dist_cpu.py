@@ -86,3 +86,20 @@ def test_two_rank_gloo_matches_sharded_emulation(tmp_path):
     st2, tg2 = cases.oracle_state(CIN, COUT, WSEED), cases.oracle_state(CIN, COUT, WSEED + 1)
     full, _ = olearner.shard_gradients(cfg, st2, tg2, spec, batch, GB, cases.GAMMA, update_buffers=True)
     assert np.abs(full.numpy() - total.numpy()).max() / np.abs(total.numpy()).max() > 1e-3
+
+
+def test_bench_launches_its_own_ranks_when_started_bare():
+    """`python bench.py --gpus 2` without torch.distributed.run around it must start the two ranks itself instead of exiting with
+    "must be launched with ..." (the reference's multi-GPU form, nn.DataParallel at policies.py:39, needs no launcher either).
+    Without a GPU the ranks stop at the device check: the exit status is theirs and the message is the ranks' own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    env['CUDA_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0
+    assert 'needs an MI355X' in r.stderr and 'must be launched' not in r.stderr
+    assert r.stderr.count('needs an MI355X') >= 2 or 'nproc' in r.stderr or 'ChildFailedError' in r.stderr      # both ranks ran

@@ -71,8 +71,9 @@ def _worker(rank, world, port, backend, use_comm, spec, out_dir, sync_bn=False):
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
+    dev_index = rank % torch.cuda.device_count() if backend == 'nccl' else 0      # RCCL: one GPU per rank; gloo ranks share GPU 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if backend == 'nccl':
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     else:
@@ -274,6 +275,9 @@ def test_dp_step_with_syncbn_equals_the_single_device_reference_step(tmp_path, g
     r0 = ranks[0]
     for r in ranks[1:]:
         assert np.array_equal(r0['params'], r['params']) and np.array_equal(r0['grad'], r['grad'])
+        # global statistics everywhere: every rank's running mean / var equal rank 0's -- including a rank whose shard is all
+        # terminal, which normalises nothing in the double-DQN forward but commits the reduced statistics (simq_forward_sync_null)
+        assert np.abs(r['bn'] - r0['bn']).max() <= 1e-6 * np.abs(r0['bn']).max()
     rel1 = lambda a, b: abs(a - b) / abs(b)
     assert rel1(float(r0['loss']), float(g['loss'][0])) < 1e-4 and rel1(float(r0['td_error']), float(g['td_error'][0])) < 1e-4
     q_sa, y = np.concatenate([r['q_sa'] for r in ranks]), np.concatenate([r['y'] for r in ranks])
@@ -284,3 +288,66 @@ def test_dp_step_with_syncbn_equals_the_single_device_reference_step(tmp_path, g
           'total norm %.6g vs %.6g' % (name, world, err, float(g['ref_fp32_grad_relerr']), float(r0['total_norm']), float(g['total_norm64'])))
     assert err <= max(10 * float(g['ref_fp32_grad_relerr']), 5e-3), err
     assert rel1(float(r0['total_norm']), float(g['total_norm64'])) < 5e-2
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two MI355X (RCCL refuses two ranks on one device)')
+
+
+@needs_two_gpus
+@pytest.mark.parametrize('name', ['dp_c5o2_b8_w2', 'dp_c5o1_b8_w2'])
+def test_dp_step_over_rccl_between_two_gpus(tmp_path, golden_dir, name):
+    """Two ranks on two GPUs over libsimq's RCCL communicator (use_comm: the fused data-parallel simq_train_step -- event-ordered
+    bucket all-reduces on the communicator's stream, overlapped with backward phase 2) against the reference-replica fixtures."""
+    test_dp_step_against_reference_replica_fixture(tmp_path, golden_dir, name, 'nccl', True)
+
+
+@needs_two_gpus
+def test_dp_syncbn_over_rccl_between_two_gpus(tmp_path, golden_dir):
+    """SyncBN over simq_comm_reduce_f64 (44 small reductions per step inside the library) between two real ranks."""
+    test_dp_step_with_syncbn_equals_the_single_device_reference_step(tmp_path, golden_dir, 'train_c4o2_b8', 2, 'nccl', True)
+
+
+def _bench_line(argv, timeout=900):
+    """bench.py started BARE (no launcher, no WORLD_SIZE in the environment) -- the way the driver starts `--gpus 1` -- and its one
+    JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, 'bench.py %s exited %d\n%s\n%s' % (' '.join(argv), r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_from_a_bare_process():
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (torch.distributed.run on 127.0.0.1; here they
+    share the one GPU over gloo), rank 0 prints the line: BASELINE configs[1] sharded over the ranks as the headline, the
+    weak-scaling leg beside it, a per-rank roofline."""
+    line = _bench_line(['--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--replay', '256'])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['unit'] == 'transitions/s' and line['value'] > 0
+    cfg = line['config']
+    assert cfg['workload_key'] == 'configs1' and cfg['global_batch'] == 32 and cfg['per_gpu_batch'] == 16 and cfg['parallelism'] == 'dp2'
+    assert line['scaling'] == 'strong' and line['dtype'] == 'f32'
+    assert 'torch.distributed (gloo)' in cfg['gradient_transport']
+    assert np.isfinite(cfg['last_loss']) and line['value_fwd_bwd_only'] > 0
+    assert abs(line['value'] - 32 * 2 / (line['ms_per_step'] * 2e-3)) <= 1e-3 * line['value']
+    roof = line['roofline']
+    assert roof['frac'] > 0 and [r['rank'] for r in roof['per_rank']] == [0, 1] and all(r['frac'] > 0 for r in roof['per_rank'])
+    weak = line['weak32']
+    assert weak['scaling'] == 'weak' and weak['full_step_transitions_per_s'] > 0 and '64' in weak['workload']
+
+
+def test_bench_maps_gpu_counts_to_the_baseline_configs():
+    """--workload at one GPU: configs[3]'s two heterogeneous nets (one loop pass of train.py:255-257 = 2 x 256 transitions) and
+    configs[4]'s net in bf16, at reduced step counts; the line names what ran."""
+    line = _bench_line(['--workload', 'configs3', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-roofline', '--no-m1',
+                        '--batch', '16', '--replay', '128'])
+    cfg = line['config']
+    assert cfg['workload_key'] == 'configs3' and cfg['nets'] == 2 and cfg['transitions_per_step'] == 32 and line['dtype'] == 'f32'
+    assert 'Cin=5->Cout=2 + Cin=5->Cout=1' in cfg['workload'] and np.isfinite(cfg['last_loss'])
+    line = _bench_line(['--workload', 'configs4', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-m1', '--batch', '128',
+                        '--replay', '256'])
+    assert line['config']['workload_key'] == 'configs4' and line['dtype'].startswith('bf16') and line['roofline']['peak'] == 2500.0
+    assert line['roofline']['traffic_source'] is None or line['roofline']['traffic_source'].startswith('profiles/')

@@ -137,6 +137,11 @@ def test_intention_policy_step_golden(simq_mod, golden_dir):
     assert [a[0][0], a[1][0]] == g['actions'].tolist()
     # non-debug path keeps the predicted map in HBM between the two nets: same actions
     assert pol.step([[s[0]], [s[1]]], exploration_eps=0.0) == a
+    # epsilon-greedy draws: the actions the reference's own DQNIntentionPolicy returned under random.seed(123)
+    import random as _random
+    _random.seed(123)
+    o1 = [pol.step([[s[0]], [s[1]]], exploration_eps=0.5) for _ in range(3)]
+    assert [[x[0][0], x[1][0]] for x in o1] == g['eps_half_actions'].tolist()
     si = pol.step_intention([[s[0]], [None]])
     assert si[1][0] is None and si[0][0].shape == (96, 96, 5) and np.array_equal(si[0][0][:, :, :4], s[0])
     # train mode: ground-truth channel dropped (predicted) or used (policies.py:120-131); nets return to train mode

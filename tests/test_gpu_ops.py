@@ -288,8 +288,9 @@ def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
 
 
 @pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256)),
-                                             (7, 64, 64, (144, 64))],
-                         ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged', 'dma_144x64_layer1'])
+                                             (7, 64, 64, (144, 64)), (128, 256, 256, (576, 128)), (128, 64, 64, (144, 64))],
+                         ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged', 'dma_144x64_layer1',
+                              'image_tile_l3_b128', 'dma_144x64_layer1_b128'])
 def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile):
     """The two ping-pong bf16 kernels of the 3x3 layers on the 24x24 maps -- conv_igemm_bf16_img.hip (tile "576x128": one image x 128
     channels per block, halo patch staged once per 32-channel chunk, nine taps read shifted fragments) and conv_igemm_bf16_pp.hip
@@ -320,9 +321,16 @@ def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile)
     assert rel(y1, y0) < 5e-6 and rel(s1, s0) < 1e-6
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
     assert rel(y1, ref) < 3e-2                                                   # bf16-class against fp64
+    # ... and TIGHT against fp64 on the bf16-rounded operands: bf16 products are exact in fp32, only the accumulation order is the
+    # kernel's own -- a kernel that drops or doubles a tap / K-tile / halo row at any batch size fails this by orders of magnitude
+    refr = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), w.bfloat16().double().permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel(y1, refr) < 2e-5, rel(y1, refr)
+    mean64 = refr.reshape(-1, Cout).sum(0)
+    assert rel(s1[:Cout], mean64) < 1e-4                                          # batch statistics from the fp32 accumulators
 
 
-@pytest.mark.parametrize('B,Cin,Cout', [(8, 256, 256), (5, 512, 256), (6, 256, 512)], ids=['l3', 'l4b_ragged', 'l4a'])
+@pytest.mark.parametrize('B,Cin,Cout', [(8, 256, 256), (5, 512, 256), (6, 256, 512), (128, 256, 256), (64, 512, 512)],
+                         ids=['l3', 'l4b_ragged', 'l4a', 'l3_b128', 'l4_b64'])
 def test_conv_bf16_wgrad_pingpong_matches_register_staged(L, B, Cin, Cout):
     """conv_wgrad_bf16_pp.hip (256x256 tiles per tap, LDS-DMA staged rows read back by ds_read_b64_tr_b16, ping-pong wave groups,
     pixel reduction split over blocks) against the register-staged 128x128 wgrad kernel (SIMQ-internal switch) and fp64: the same

@@ -1,0 +1,144 @@
+"""GPU: BASELINE configs[2..4]'s per-GPU shapes against the REFERENCE at full size.
+
+tests/golden/train_c5o2_b128.npz (configs[2] and configs[4]: Cin 5, Cout 2, 128 transitions per GPU), train_c5o2_b64.npz and
+train_c5o1_b64.npz (configs[3]: lifting Cout 2 + pushing Cout 1, 64 per GPU and net) were written by oracle/gen_golden.py
+`train_sized` from the imported reference: two consecutive train.train calls in fp32 (the oracle asserted bit-exact against them),
+the fp64 oracle as the yardstick, the error of the reference's OWN fp32 on that batch, and the error of the reference's own modules
+under torch.autocast('cpu', bfloat16) on that batch.  These are the batch sizes at which the large-batch kernels are selected (fp32:
+the tile-menu entries and 36-plane Winograd problems of B >= 64; bf16: the image-tile implicit GEMM, the ping-pong weight gradient,
+the 144x64 / 288-row LDS-DMA tiles) -- the network-level parity of those kernels against the reference is what this file adds.
+
+Bars:
+  fp32   loss / td error / q_sa / TD targets of step 1: 1e-4 against the reference's fp32 (and the fp64 yardstick);
+         pre-clip gradient and first parameter update on the fixture's sampled elements against fp64: <= 3 x the error the
+         reference's own fp32 makes on the same elements (measured: 0.4-0.9 x); gradient norm 1e-3; the second step's loss (the
+         first update seen through the network once more) against fp64: <= 4 x the reference-fp32's own second-step error or 2e-3;
+         post-second-step parameter norms 1e-4, BatchNorm buffers 1e-4.
+  bf16   against fp64, calibrated by the reference under bf16 autocast AT THIS SIZE (the fixture's bf16cal_* fields): loss, td error,
+         q_sa <= 2 x calibration; gradient / first update on the sampled elements <= 1.0 x calibration.  (The calibration says what
+         bf16 storage costs on this network whatever the batch: the reference's own autocast gradient is 0.44-0.49 off the fp64
+         gradient at B = 64-128 -- double-DQN greedy actions flip (TD targets off by up to 0.7), ReLU masks move -- so a tight
+         NETWORK-level gradient bar does not exist for bf16; the tight bars for the bf16 kernels are per kernel, on bf16-rounded
+         operands against fp64 at 2e-5, in tests/test_gpu_ops.py, including these batch sizes.)
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from oracle import fcn as ofcn
+from oracle import learner as olearner
+from simq import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def simq_mod():
+    import simq
+    from simq import _lib  # noqa: F401
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return simq
+
+
+def make_net(simq_mod, cin, cout, seed, training, precision):
+    net = simq_mod.FCN(cin, cout, precision=precision)
+    net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, seed)))
+    net.train(training)
+    return net
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def rl2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+
+
+def run_two_steps(simq_mod, case, precision, profile=False):
+    """Two consecutive simq.train calls on the fixture's batch; returns scalars, the pre-clip gradient and first update on the
+    fixture's sampled elements (reference OIHW indexing), per-tensor gradient norms, post-step summaries."""
+    from simq._lib import lib
+    name, cin, cout, B, wseed, dseed = case
+    cfg, batch = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed)
+    policy, target = make_net(simq_mod, cin, cout, wseed, True, precision), make_net(simq_mod, cin, cout, wseed + 1000, False, precision)
+    opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    p0 = [v.detach().clone().cpu().double() for v in policy.reference_views(policy.flat_params)]
+    if profile:
+        lib.call('simq_profile_start')
+    info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    kinds = None
+    if profile:
+        out = (ctypes.c_double * 12)()
+        lib.call('simq_profile_stop', out, 3)
+        kinds = [out[0], out[4], out[8]]
+    tn = float(policy._simq_opt_state.total_norm.item())
+    coef = min(1.0, cases.CLIP / (tn + 1e-6))
+    grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
+    p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
+    q_sa, y = policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy()
+    info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    gs, ds = [], []
+    for t, a, b in zip(grads, p0, p1):
+        idx = torch.tensor(cases.sample_indices(t.numel()))
+        gs.append(t.reshape(-1)[idx].numpy())
+        ds.append((b - a).reshape(-1)[idx].numpy())
+    p2 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
+    sd = policy.state_dict()
+    bn = np.concatenate([sd[k].detach().double().cpu().numpy().ravel() for k in sd if k.endswith('running_mean') or k.endswith('running_var')])
+    return dict(info=[info1, info2], total_norm=tn, grad=np.stack(gs), dparam=np.stack(ds), gnorm=np.array([float(t.norm()) for t in grads]),
+                q_sa=q_sa, y=y, p2_l2=np.array([float(t.norm()) for t in p2]), bn=bn, kinds=kinds,
+                nbt=[int(sd[k]) for k in sd if k.endswith('num_batches_tracked')])
+
+
+@pytest.mark.parametrize('case', cases.TRAIN_CASES_SIZED, ids=[c[0] for c in cases.TRAIN_CASES_SIZED])
+def test_fp32_step_at_config_size_matches_the_reference(simq_mod, golden_dir, case):
+    g = np.load('%s/%s.npz' % (golden_dir, case[0]))
+    r = run_two_steps(simq_mod, case, 'fp32')
+    e = dict(loss=abs(r['info'][0]['loss'] - float(g['loss'][0])) / float(g['loss'][0]),
+             td=abs(r['info'][0]['td_error'] - float(g['td_error'][0])) / float(g['td_error'][0]),
+             q_sa=relmax(r['q_sa'], g['q_sa']), y=relmax(r['y'], g['y']), q_sa64=relmax(r['q_sa'], g['q_sa64']),
+             grad=rl2(r['grad'], g['grad64']), dparam=rl2(r['dparam'], g['dparam64']),
+             norm=abs(r['total_norm'] - float(g['total_norm64'])) / float(g['total_norm64']),
+             loss2=abs(r['info'][1]['loss'] - float(g['loss64'][1])) / float(g['loss64'][1]))
+    big = g['grad_norm64'] > 1e-3 * float(g['total_norm64'])
+    e['tensor_norms'] = float(np.abs(r['gnorm'][big] - g['grad_norm64'][big]).max() / g['grad_norm64'][big].max())
+    print('\n[%s fp32] step-1 loss %.2g td %.2g q_sa %.2g (vs fp64 %.2g; reference fp32 %.2g) y %.2g | sampled gradient vs fp64 %.3g '
+          '(reference fp32 %.3g), update %.3g (ref %.3g), |g| %.2g, per-tensor norms %.2g | step-2 loss vs fp64 %.3g (ref %.3g)'
+          % (case[0], e['loss'], e['td'], e['q_sa'], e['q_sa64'], float(g['ref_q_err']), e['y'], e['grad'], float(g['ref_grad_err']), e['dparam'],
+             float(g['ref_dparam_err']), e['norm'], e['tensor_norms'], e['loss2'], float(g['ref_loss_err'][1])))
+    assert e['loss'] < 1e-4 and e['td'] < 1e-4 and e['q_sa'] < 1e-4 and e['y'] < 1e-4 and e['q_sa64'] < 1e-4
+    assert e['grad'] <= 3.0 * float(g['ref_grad_err']), (e['grad'], float(g['ref_grad_err']))
+    assert e['dparam'] <= 3.0 * float(g['ref_dparam_err']), (e['dparam'], float(g['ref_dparam_err']))
+    assert e['norm'] < 1e-3 and e['tensor_norms'] < 2e-2
+    assert e['loss2'] <= max(4.0 * float(g['ref_loss_err'][1]), 2e-3), (e['loss2'], float(g['ref_loss_err'][1]))
+    assert relmax(r['p2_l2'], g['param_summary_after2'][:, 1]) < 1e-4
+    assert relmax(r['bn'], g['bn_buffers_after2']) < 1e-4
+    assert r['nbt'] == [int(v) for v in g['num_batches_tracked']]
+
+
+@pytest.mark.parametrize('case', cases.TRAIN_CASES_SIZED, ids=[c[0] for c in cases.TRAIN_CASES_SIZED])
+def test_bf16_step_at_config_size_within_the_reference_autocast_calibration(simq_mod, golden_dir, case):
+    g = np.load('%s/%s.npz' % (golden_dir, case[0]))
+    r = run_two_steps(simq_mod, case, 'bf16', profile=True)
+    e = dict(loss=abs(r['info'][0]['loss'] - float(g['loss64'][0])) / float(g['loss64'][0]),
+             td=abs(r['info'][0]['td_error'] - float(g['td_error64'][0])) / float(g['td_error64'][0]),
+             q_sa=relmax(r['q_sa'], g['q_sa64']), y=relmax(r['y'], g['y64']),
+             grad=rl2(r['grad'], g['grad64']), dparam=rl2(r['dparam'], g['dparam64']),
+             norm=abs(r['total_norm'] - float(g['total_norm64'])) / float(g['total_norm64']))
+    cal = {k: float(g['bf16cal_' + k]) for k in ('loss', 'td_error', 'q_sa', 'y', 'grad_sampled', 'dparam_sampled')}
+    print('\n[%s bf16] vs fp64: loss %.3g (reference autocast %.3g) td %.3g (%.3g) q_sa %.3g (%.3g) y %.3g (%.3g) | sampled gradient %.3g (%.3g) '
+          'update %.3g (%.3g) |g| %.3g | launches: image-tile/dominant %d, direct wgrad %d, other tiles %d'
+          % (case[0], e['loss'], cal['loss'], e['td'], cal['td_error'], e['q_sa'], cal['q_sa'], e['y'], cal['y'], e['grad'], cal['grad_sampled'],
+             e['dparam'], cal['dparam_sampled'], e['norm'], r['kinds'][0], r['kinds'][1], r['kinds'][2]))
+    assert all(np.isfinite(i['loss']) for i in r['info'])
+    assert e['loss'] <= 2.0 * cal['loss'] and e['td'] <= 2.0 * cal['td_error'] and e['q_sa'] <= 2.0 * cal['q_sa']
+    assert e['grad'] <= 1.0 * cal['grad_sampled'] and e['dparam'] <= 1.0 * cal['dparam_sampled']
+    assert r['kinds'][1] > 0 and r['kinds'][0] + r['kinds'][2] > 0
+    if case[3] >= 128:
+        assert r['kinds'][0] > 0, 'the image-tile kernel (the bench leg\'s dominant kernel) was not selected at B = %d' % case[3]

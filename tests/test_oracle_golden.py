@@ -157,6 +157,11 @@ def test_intention_policy_step_golden(golden_dir):
     assert rel(np.stack([info['output_intention'][0][0], info['output_intention'][1][0]]), g['output_intention']) < 1e-4   # host-independent bar
     si = info['state_intention'][0][0]
     assert si.shape == (96, 96, 5) and np.array_equal(si[:, :, :4], s[0]) and 0.0 <= si[:, :, 4].min() <= si[:, :, 4].max() <= 1.0
+    # epsilon-greedy draws of the reference's own class under random.seed(123) (policies.py:61-62 through :119-146)
+    import random
+    random.seed(123)
+    o1 = [pol.step([[s[0]], [s[1]]], exploration_eps=0.5) for _ in range(3)]
+    assert [[x[0][0], x[1][0]] for x in o1] == g['eps_half_actions'].tolist()
     # train-mode policy: the ground-truth map (last channel) is dropped before predicting, or used as is
     pol.train = True
     full = np.concatenate([s[0], np.zeros((96, 96, 1), np.float32)], axis=2)
