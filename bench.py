@@ -239,6 +239,8 @@ def main():
     from simq import dist as sdist, synth
     from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
     from simq.learner import _opt_state, train_step
+    if lib.build_flags != 0:
+        sys.exit('bench.py: %s is the ablation build (simq_build_flags = %d); the benchmark runs the product library only' % (lib.path, lib.build_flags))
 
     # gradient exchange: libsimq's own RCCL communicator (simq_comm_*: the data-parallel step is then ONE library call, buckets on
     # the communicator's stream); checked once against torch.distributed's all-reduce.  If RCCL cannot be initialised through

@@ -59,11 +59,43 @@ extern "C" {
 typedef struct simq_plan simq_plan;
 
 int simq_version(void);
+/* 0 for the product library.  SIMQ_BUILD_ABLATIONS: libsimq_ablate.so (tools only): kernel-selection switches are read from SIMQ_*
+ * environment variables and the timing-ablation kernels are present; bench.py and the parity tests refuse such a build. */
+#define SIMQ_BUILD_ABLATIONS 1
+int simq_build_flags(void);
 const char* simq_last_error(void);
 
 /* ---- plan: the network of networks.py:7-14 for (Cin, Cout); replaces FCN.__init__ ---------- */
 int simq_plan_create(int num_input_channels, int num_output_channels, simq_plan** out);   /* SIMQ_PREC_FP32 */
 int simq_plan_create_ex(int num_input_channels, int num_output_channels, int precision, simq_plan** out);
+/* What a plan computes WITH -- which algebraic form, storage precision and fusion each layer uses -- is fixed when the plan is
+ * created and is a property of the plan; the library never reads it from the process environment.  Every default below is what the
+ * parity tests and the bench run; the other settings exist for A/B measurements and diagnostics and some of them change the
+ * round-off of the results (noted per field).  Fill the struct with simq_plan_options_default, change fields, pass it to
+ * simq_plan_create_opts (NULL = defaults); struct_bytes must be sizeof(simq_plan_options). */
+typedef struct simq_plan_options {
+    int struct_bytes;
+    /* fp32 plans: Winograd forms of the wide 3x3 layers */
+    int winograd;                 /* 1: layers with Cin*Cout >= winograd_min_cc run as F(2x2,3x3) / F(4x4,3x3); 0: direct implicit GEMM */
+    int winograd_min_cc;          /* 128*128: layers 2-4 */
+    int winograd_f4_forward;      /* 1: the forwards nothing is differentiated through (target net, greedy next action, step()) in F(4x4,3x3) */
+    int winograd_f4_min_tiles;    /* 256: ... from this many 4x4 tiles (B*36) */
+    int winograd_f4_grad;         /* 2: dgrads in F(4x4,3x3); 1: the grad-mode forward too (doubles the median gradient error); 0: neither */
+    int winograd_wgrad;           /* 1: weight gradients of the Winograd layers through the transform domain */
+    int winograd_wgrad_f4;        /* 1: ... in F(4x4,3x3) where the tile count allows */
+    /* bf16 plans: storage */
+    int stem_bf16;                /* 1: first convolution + its weight gradient on the bf16 matrix cores */
+    int bf16_act_grads;           /* 1: activation gradients between the residual blocks' kernels travel as bf16 */
+    int keep_fp32_activations;    /* 0: post-BN activations exist as bf16 planes only; 1 keeps fp32 copies (simq_workspace_tensor readers) */
+    int fold_eval_bn_bf16;        /* 1: eval-mode BatchNorm folded into the convolution epilogues (one rounding instead of two) */
+    /* every precision: fusions (0 = separate reduction launches, same arithmetic in a different summation order) */
+    int fuse_bn_backward_sums;    /* 1 */
+    int fuse_stem_backward_sums;  /* 1 */
+} simq_plan_options;
+void simq_plan_options_default(simq_plan_options* options);
+int simq_plan_create_opts(int num_input_channels, int num_output_channels, int precision, const simq_plan_options* options,
+                          simq_plan** out);
+int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out);
 int simq_plan_precision(const simq_plan* plan);
 void simq_plan_destroy(simq_plan* plan);
 
@@ -303,10 +335,8 @@ int simq_profile_stop(double* out, int max_kinds);
 /* tuning aid (tools/tune_conv.py): force the implicit-GEMM block tile BM x BN; bm = 0 restores the cost model */
 int simq_tune_force_tile(int bm, int bn);
 /* tuning aid: switch the fp32 implicit-GEMM kernel's balanced last round (K-sliced tail tiles + fix-up kernel) on (1) /
- * off (0); default off (it pays only when the forwards run serialised), also SIMQ_TAIL_SPLIT=1 in the environment */
+ * off (0); default off (it pays only when the forwards run serialised) */
 int simq_tune_tail_split(int on);
-/* tuning aid: Winograd path of the plan's eligible layers on (1, default) / off (0); also SIMQ_WINOGRAD=0 */
-int simq_tune_winograd(int on);
 
 #ifdef __cplusplus
 }

@@ -31,12 +31,26 @@ TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
 # Cout 2 and pushing Cout 1, 64 transitions per GPU and net): reference train.train at the batch sizes the large-batch kernels are
 # selected at, summaries + fp64 yardstick + the reference's own bf16-autocast error AT THAT SIZE (gen_golden.gen_train_sized)
 TRAIN_CASES_SIZED = [('train_c5o2_b128', 5, 2, 128, 61, 71), ('train_c5o2_b64', 5, 2, 64, 62, 72), ('train_c5o1_b64', 5, 1, 64, 63, 73)]
+# dense-upstream-gradient backward at those sizes (gen_golden.gen_dense_grad): loss = sum(Q * R) for a seeded dense R -- train-mode
+# BatchNorm backward of a DENSE gradient does not cancel the way the TD loss's one-hot gradient does, so this is the well-conditioned
+# network-level gradient case (fp32 ~1e-5, bf16 ~1e-2 against fp64) -- (name, cin, cout, batch, weight seed, data seed)
+DENSE_GRAD_CASES = [('dense_c5o2_b128', 5, 2, 128, 64, 74), ('dense_c5o1_b64', 5, 1, 64, 65, 75)]
+
+
+def dense_upstream(cout, batch, seed):
+    """The dense dLoss/dQ of a DENSE_GRAD case: [B, Cout, 96, 96] float32, N(0,1) / sqrt(B * 96 * 96)."""
+    rs = np.random.RandomState(seed + 15485863)
+    return (rs.standard_normal((batch, cout, 96, 96)) / np.sqrt(batch * 96.0 * 96.0)).astype(np.float32)
+
+
 # data-parallel emulation (SURVEY 8e / fixture G7): (name, cin, cout, global batch, shards, weight seed, data seed)
 DP_CASES = [('dp_c5o2_b8_w1', 5, 2, 8, 1, 37, 50), ('dp_c5o2_b8_w2', 5, 2, 8, 2, 37, 50), ('dp_c5o2_b8_w4', 5, 2, 8, 4, 37, 50),
             ('dp_c5o2_b8_w8', 5, 2, 8, 8, 37, 50), ('dp_c5o1_b8_w2', 5, 1, 8, 2, 38, 48)]
 # gradient-parity study (SURVEY section 0: err_build <= k * err_reference-fp32): many seeded batches, judged as a distribution
 GRAD_STUDY_CASES = [('gs_b8_%02d' % i, (4, 5)[i % 2], (2, 1)[(i // 2) % 2], 8, 200 + i, 300 + i) for i in range(10)] + \
                    [('gs_b32_%02d' % i, (4, 5, 4)[i], (2, 2, 1)[i], 32, 250 + i, 350 + i) for i in range(3)]
+# the same study at configs[3]'s per-GPU batch (64): is the HIP fp32 gradient as accurate as the reference's at the larger sizes too?
+GRAD_STUDY_B64_CASES = [('gs_b64_%02d' % i, 5, (2, 1)[i % 2], 64, 270 + i, 370 + i) for i in range(6)]
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 

@@ -319,6 +319,68 @@ def gen_train_sized(case_list=None):
                  time.time() - t_start), flush=True)
 
 
+def gen_dense_grad():
+    """The reference's own networks.FCN (train mode, wrapped as policies.py:39 does) differentiated through a DENSE upstream gradient
+    at BASELINE configs[2..4]'s per-GPU sizes: loss = sum(Q * R), R seeded (cases.dense_upstream).  Unlike the TD loss's one-hot
+    gradient, a dense gradient does not cancel catastrophically in the train-mode BatchNorm backward, so this is the
+    network-level gradient fixture with a TIGHT bar: the fp64 gradient (per-tensor norms + 16 sampled elements per tensor) beside the
+    error of the reference's own fp32 and of the reference under bf16 autocast on the same inputs.  The oracle's forward_backward
+    restatement is asserted bit-exact against the reference first."""
+    import time
+    for name, cin, cout, B, wseed, dseed in cases.DENSE_GRAD_CASES:
+        t0 = time.time()
+        spec = fcn.state_spec(cin, cout)
+        gkeys = learner.grad_keys(spec)
+        x = torch.cat([learner.apply_transform(s) for s in synth.make_states(B, cin, dseed)])
+        R = torch.from_numpy(cases.dense_upstream(cout, B, dseed))
+
+        def ref_grads(autocast):
+            net = ref_net(cin, cout, wseed)
+            net.train()
+            if autocast:
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    q = net(x).float()
+            else:
+                q = net(x)
+            (q * R).sum().backward()
+            named = {'module.' + k: p for k, p in net.module.named_parameters()}
+            return q.detach(), {k: named[k].grad.detach().clone() for k in gkeys}
+        q32, g32 = ref_grads(False)
+        # oracle fp32 == reference (bit-exact), then fp64
+        def oracle_grads(dtype):
+            st = cases.oracle_state(cin, cout, wseed, dtype)
+            params = [st[k] for k in gkeys]
+            for p_ in params:
+                p_.requires_grad_(True)
+            q = fcn.fcn_forward(st, x.to(dtype), True)
+            grads = torch.autograd.grad((q * R.to(dtype)).sum(), params)
+            return q.detach(), dict(zip(gkeys, grads))
+        qo, go = oracle_grads(torch.float32)
+        assert_same(qo, q32, name + ' forward')
+        for k in gkeys:
+            assert_same(go[k], g32[k], name + ' gradient ' + k)
+        q64, g64 = oracle_grads(torch.float64)
+        q16, g16 = ref_grads(True)
+
+        def sampled(d):
+            return np.stack([d[k].double().reshape(-1)[torch.tensor(cases.sample_indices(d[k].numel()))].numpy() for k in gkeys])
+        rl2 = lambda a, b: float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum() / (b ** 2).sum()))
+        fullrel = lambda g: (sum(float((g[k].double() - g64[k]).pow(2).sum()) for k in gkeys) / sum(float(g64[k].pow(2).sum()) for k in gkeys)) ** 0.5
+        worst = lambda g: max(float((g[k].double() - g64[k]).norm() / g64[k].norm()) for k in gkeys if float(g64[k].norm()) > 1e-3 * max(float(g64[j].norm()) for j in gkeys))
+        relmax = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+        out = dict(grad_keys=np.array(gkeys), grad_norm64=np.array([float(g64[k].norm()) for k in gkeys]), grad64=sampled(g64),
+                   q_checksum64=np.array([float(q64.sum()), float(q64.abs().sum()), float((q64 * R.double()).sum())]),
+                   ref_fp32_grad=np.array(fullrel(g32)), ref_fp32_grad_sampled=np.array(rl2(sampled(g32), sampled(g64))),
+                   ref_fp32_worst_tensor=np.array(worst(g32)), ref_fp32_q=np.array(relmax(q32, q64)),
+                   bf16cal_grad=np.array(fullrel(g16)), bf16cal_grad_sampled=np.array(rl2(sampled(g16), sampled(g64))),
+                   bf16cal_worst_tensor=np.array(worst(g16)), bf16cal_q=np.array(relmax(q16, q64)))
+        np.savez_compressed(os.path.join(cases.GOLDEN_DIR, name + '.npz'), **out)
+        print('dense-gradient case %s: oracle == reference (bit-exact).  vs fp64 -- reference fp32: Q %.2g, gradient %.3g (sampled %.3g, worst '
+              'tensor %.3g);  reference bf16-autocast: Q %.3g, gradient %.3g (sampled %.3g, worst tensor %.3g)   [%.0f s]'
+              % (name, out['ref_fp32_q'], out['ref_fp32_grad'], out['ref_fp32_grad_sampled'], out['ref_fp32_worst_tensor'], out['bf16cal_q'],
+                 out['bf16cal_grad'], out['bf16cal_grad_sampled'], out['bf16cal_worst_tensor'], time.time() - t0), flush=True)
+
+
 def gen_dp():
     """Fixture G7: the reference's multi-GPU form is nn.DataParallel (policies.py:39) -- the minibatch is cut
     into contiguous chunks, every replica runs the reference's own FCN on its chunk with ITS OWN train-mode BatchNorm statistics,
@@ -400,15 +462,16 @@ def gen_dp():
               'all-terminal shards: %d; per-shard-BN vs single replica: %.3g' % (relerr, empty_shards, float((t64 - one).norm() / one.norm())))
 
 
-def gen_grad_study():
+def gen_grad_study(case_list=None, fname='grad_study.npz'):
     """Gradient-parity study: fp32 gradients of these small train-mode-BN batches are only 1e-4 .. 1e-2
     accurate -- for the reference as much as for any other fp32 implementation -- and WHICH implementation is luckier changes from
     batch to batch.  So the bar is a distribution: 10 seeded B=8 and 3 seeded B=32 batches; per case the reference's own fp32
     train.train (imported, two consecutive calls) and the fp64 oracle.  Stored per case: the fp64 gradient / parameter-update
     summaries (16 sampled elements per tensor) and the REFERENCE-fp32 error on exactly those samples -- the yardstick the GPU test
     (tests/test_gpu_fcn.py::test_gradient_parity_distribution) holds the HIP path to (median <= 2 x, no case > 10 x)."""
-    out = {'names': np.array([c[0] for c in cases.GRAD_STUDY_CASES])}
-    for name, cin, cout, B, wseed, dseed in cases.GRAD_STUDY_CASES:
+    case_list = case_list or cases.GRAD_STUDY_CASES
+    out = {'names': np.array([c[0] for c in case_list])}
+    for name, cin, cout, B, wseed, dseed in case_list:
         cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
         gkeys = learner.grad_keys(spec)
         # the reference itself, fp32, two steps
@@ -451,7 +514,7 @@ def gen_grad_study():
         out[name + '.ref_loss_err'] = np.array([abs(info_ref[j]['loss'] - i64[j]['loss']) / abs(i64[j]['loss']) for j in range(2)])
         print('grad study %-10s ref fp32 vs fp64: sampled grad rel-L2 %.3g, sampled update rel-L2 %.3g, loss err %.2g / %.2g (step 1 / 2)'
               % (name, out[name + '.ref_grad_err'], out[name + '.ref_dparam_err'], out[name + '.ref_loss_err'][0], out[name + '.ref_loss_err'][1]), flush=True)
-    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, 'grad_study.npz'), **out)
+    np.savez_compressed(os.path.join(cases.GOLDEN_DIR, fname), **out)
 
 
 def gen_bf16_calibration():
@@ -655,8 +718,9 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
             'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration,
-            'grad_study': gen_grad_study}
+            'grad_study': gen_grad_study,
+            'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz')}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

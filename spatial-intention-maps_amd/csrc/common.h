@@ -12,6 +12,18 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 void set_error(const char* fmt, ...);
 
+// Kernel-selection / tuning / timing-ablation switches.  They never change WHAT is computed (beyond fp32 summation order) and they are
+// not part of the product: libsimq.so is built without SIMQ_ABLATIONS, every SIMQ_TUNE_INT is then its default as a compile-time
+// constant (the environment is not read, the switch's name is not even in the binary) and the ablation instantiations of the
+// ping-pong kernels are not compiled.  `make ablate` builds libsimq_ablate.so with -DSIMQ_ABLATIONS for tools/ (tools/_ablate.py).
+// Switches that change the ARITHMETIC of a plan (Winograd forms, storage precisions, fusions) are simq_plan_options (include/simq.h).
+#ifdef SIMQ_ABLATIONS
+int tune_env_int(const char* name, int dflt);
+#define SIMQ_TUNE_INT(name, dflt) (simq::tune_env_int(name, dflt))
+#else
+#define SIMQ_TUNE_INT(name, dflt) (dflt)
+#endif
+
 #define SIMQ_CHECK_HIP(expr)                                                        \
     do {                                                                            \
         hipError_t _e = (expr);                                                     \
@@ -72,10 +84,8 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
 // conv_winograd.hip: Winograd F(2x2,3x3) for the wide 3x3 layers; U = transformed weights [16][Cout][Cin]
-bool winograd_enabled();
-void tune_winograd(int on);
 bool winograd_eligible(const ConvGeom& g);
-bool winograd_pays(int cin, int cout);
+bool winograd_pays(int cin, int cout, long min_cc);
 int64_t winograd_scratch_floats(const ConvGeom& g);
 int launch_wino_weight(const float* w_ohwi, float* U, int cout, int cin, hipStream_t stream);
 struct WinoWeightDesc { int64_t src_off, u_off; int cout, cin, from_wt, pad_; };   // cout / cin of the convolution U serves; pad_ = 1: F(4x4,3x3) form (36 planes)
@@ -85,17 +95,15 @@ int launch_wino_weight_all(const float* params, const float* wt, float* ubase, c
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                          hipStream_t stream);
 // F(4x4,3x3) form for forwards nothing is differentiated through (U4: 36 planes [Cout][Cin])
-bool winograd_f4_forward(const ConvGeom& g);
-int winograd_f4_grad();
+bool winograd_f4_forward(const ConvGeom& g, int min_tiles);
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                           hipStream_t stream);
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
 // conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
 int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
 bool winograd_wgrad_eligible(const ConvGeom& g);
-bool winograd_wgrad_enabled();
-bool winograd_wgrad_pays(const ConvGeom& g);
-int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream);
+bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4);
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4 = true);
 int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
 int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,

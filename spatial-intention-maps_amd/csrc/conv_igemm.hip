@@ -458,7 +458,7 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     p.full_tiles = tiles; p.splits = 1; p.kper = 0; p.partial = nullptr;
     int tail = 0;
     if constexpr (VEC && !BATCHED) {
-        if (g_tail_split < 0) { const char* s = getenv("SIMQ_TAIL_SPLIT"); g_tail_split = (s && atoi(s) != 0) ? 1 : 0; }
+        if (g_tail_split < 0) g_tail_split = SIMQ_TUNE_INT("SIMQ_TAIL_SPLIT", 0) != 0 ? 1 : 0;
         const int slots = kNumCU * resident_blocks<BM, BN, VEC>();
         const int rem = tiles % slots, nk = p.K / BK;
         // worth it when the last round leaves a CU with one or two blocks (three or more co-resident blocks already keep the
@@ -483,12 +483,12 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
         // 2422 / 2426 / 2391 tr/s -- carrying the pipeline across tiles does NOT recover the short-K loss (the shortk probe's
         // 97 -> 130 TF/s from K = 256 to 1024 comes with 4x fewer output bytes per flop, not only fewer prologues), and
         // longer runs cost block-level parallelism.  Kept as a switch for other shapes.
-        static const int forced = getenv("SIMQ_GEMM_NT_RUN") ? atoi(getenv("SIMQ_GEMM_NT_RUN")) : 1;
+        static const int forced = SIMQ_TUNE_INT("SIMQ_GEMM_NT_RUN", 1);
         if ((p.K / BK) % 2 == 0 && forced >= 1 && p.tilesN % forced == 0) p.nt_run = forced;
         launch_tiles = tilesM * (p.tilesN / p.nt_run);
         p.full_tiles = launch_tiles;
     }
-    if (g_xcd_remap < 0) { const char* s = getenv("SIMQ_XCD_REMAP"); g_xcd_remap = (s && atoi(s) == 0) ? 0 : 1; }
+    if (g_xcd_remap < 0) g_xcd_remap = SIMQ_TUNE_INT("SIMQ_XCD_REMAP", 1) != 0 ? 1 : 0;
     p.xcd_chunk = (g_xcd_remap && p.tilesN / p.nt_run > 1 && p.full_tiles >= 64) ? p.full_tiles / 8 : 0;
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
@@ -518,13 +518,15 @@ constexpr TileCfg kMenu[] = {
     {128, 32, 0.86f, 0.915f}, {64, 32, 0.86f, 0.877f},  {32, 64, 0.86f, 0.854f}, {96, 32, 0.84f, 0.882f}, {128, 128, 0.75f, 0.70f},
     {32, 32, 0.72f, 0.75f},
 };
-int g_forced_bm = -1, g_forced_bn = -1;   // tuning aid (tools/tune_conv.py): SIMQ_IGEMM_TILE=BMxBN or simq_tune_force_tile()
+int g_forced_bm = -1, g_forced_bn = -1;   // tuning aid (tools/tune_conv.py): simq_tune_force_tile(), or SIMQ_IGEMM_TILE=BMxBN in the ablation build
 
 int forced_tile(int* bm, int* bn) {
     if (g_forced_bm == -1) {
         g_forced_bm = 0;
+#ifdef SIMQ_ABLATIONS
         const char* s = getenv("SIMQ_IGEMM_TILE");
         if (s && sscanf(s, "%dx%d", &g_forced_bm, &g_forced_bn) != 2) g_forced_bm = 0;
+#endif
     }
     *bm = g_forced_bm; *bn = g_forced_bn;
     return g_forced_bm > 0;
@@ -582,7 +584,9 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 // launch (grid.y = batch): the transform-domain contractions of conv_winograd.hip.  K % 16 == 0, N % 64 == 0.
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream) {
     SIMQ_REQUIRE(M > 0 && K % BK == 0 && N % 64 == 0 && batch >= 1, "gemm_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
-    if (int rc = try_gemm_batched_pp(x, w, y, M, N, K, batch, stream)) return rc < 0 ? rc : 0;     // gemm_f32_pp.hip (N % 128 == 0)
+#ifdef SIMQ_ABLATIONS      // the opt-in ping-pong form (gemm_f32_pp.hip, step-neutral: DESIGN 4) exists in libsimq_ablate.so only
+    if (int rc = try_gemm_batched_pp(x, w, y, M, N, K, batch, stream)) return rc < 0 ? rc : 0;     // (N % 128 == 0)
+#endif
     IgemmArgs a;
     a.x = x; a.w = w;
     ConvEpilogue e;

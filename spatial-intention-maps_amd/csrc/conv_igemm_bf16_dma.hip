@@ -263,13 +263,14 @@ int run(const IgemmBfArgs& a, hipStream_t stream) {
 
 int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
     if (bm == 288 && bn == 128) {
-        if (const char* e = getenv("SIMQ_BF16_DBG")) {
-            const int v = atoi(e);
+#ifdef SIMQ_ABLATIONS      // timing ablations (tools/bf16_tiles.py): compiled into libsimq_ablate.so only
+        if (const int v = SIMQ_TUNE_INT("SIMQ_BF16_DBG", 0)) {
 #define SIMQ_DBG(N) if (v == N) return run<288, 128, 2, 8, N>(a, stream)
             SIMQ_DBG(1); SIMQ_DBG(2); SIMQ_DBG(8); SIMQ_DBG(16); SIMQ_DBG(23); SIMQ_DBG(32);
             if (v == 100) return run<288, 128, 2, 4, 0>(a, stream);      // four-wave variant (wave tile 144 x 64)
 #undef SIMQ_DBG
         }
+#endif
         return run<288, 128, 2, 8>(a, stream);
     }
     if (bm == 288 && bn == 256) return run<288, 256, 2, 8, 0, true>(a, stream);
@@ -283,7 +284,7 @@ int dispatch(int bm, int bn, const IgemmBfArgs& a, hipStream_t stream) {
 
 int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.R * a.S > 32) return 0;
-    static const int mode = [] { const char* e = getenv("SIMQ_BF16_DMA"); return e ? atoi(e) : 1; }();   // 0 = off
+    static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_DMA", 1);   // 0 = off
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
     if (tune_forced_tile(&fbm, &fbn)) return (a.Cout % fbn == 0) ? dispatch(fbm, fbn, a, stream) : 0;
@@ -291,7 +292,7 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
     // of the 256 CUs -- the 512-channel layers (95 vs 132 us on layer4's 3x3, 92 vs 130 us at 29 samples); on the
     // 256/128-channel layers the register-staged 96-row tiles (3-4 blocks per CU) stay ahead, so only that case is taken.
     int bm = 0, bn = 0;
-    static const int min_k = [] { const char* e = getenv("SIMQ_BF16_DMA_MINK"); return e ? atoi(e) : 64; }();
+    static const int min_k = SIMQ_TUNE_INT("SIMQ_BF16_DMA_MINK", 64);
     if (a.Cout % 128 == 0 && a.K >= min_k) {
         const long blocks = (long)((a.M + 287) / 288) * (a.Cout / 128);
         const long rounds = (blocks + 255) / 256;
@@ -300,7 +301,7 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
     // 64 output channels (layer1 at large batches): the 144 x 64 four-wave tile, two blocks per CU (512 blocks at B = 128).  These
     // launches are bound by their epilogue traffic and by the operand volume staged per flop; against the register-staged 96 x 64 tile
     // +1.0 % on the bf16 configs[2] step, +1.4 % forward + backward (the 288 x 64 tile: neutral).  SIMQ_BF16_DMA_N64=0: off.
-    static const int n64 = [] { const char* e = getenv("SIMQ_BF16_DMA_N64"); return e ? atoi(e) : 1; }();
+    static const int n64 = SIMQ_TUNE_INT("SIMQ_BF16_DMA_N64", 1);
     if (!bm && n64 && a.Cout == 64 && a.K >= min_k && a.M >= 144 * 400) { bm = n64 == 2 ? 288 : 144; bn = 64; }
     return bm ? dispatch(bm, bn, a, stream) : 0;
 }

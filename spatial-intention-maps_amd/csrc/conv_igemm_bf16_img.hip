@@ -240,7 +240,7 @@ void launch(const IgemmBfArgs& p, unsigned blocks, hipStream_t stream) {
 int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.Hin != HW || a.Win != HW || a.Hout != HW || a.Wout != HW) return 0;
     if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.M % BM != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
-    static const int mode = [] { const char* e = getenv("SIMQ_BF16_IMG"); return e ? atoi(e) : 1; }();   // 0 = off
+    static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_IMG", 1);   // 0 = off
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
     const bool forced = tune_forced_tile(&fbm, &fbn);
@@ -254,7 +254,8 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     p.xcd_chunk = bf16_xcd_chunk((int)blocks, p.tilesN);
     prof_launch_begin(0, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout), stream);
-    static const int dbg = [] { const char* e = getenv("SIMQ_BF16_IMG_DBG"); return e ? atoi(e) : 0; }();   // timing ablations (tools/pp_check.py)
+#ifdef SIMQ_ABLATIONS      // timing ablations (tools/pp_check.py): compiled into libsimq_ablate.so only
+    static const int dbg = SIMQ_TUNE_INT("SIMQ_BF16_IMG_DBG", 0);   // timing ablations (tools/pp_check.py)
     switch (dbg) {
         case 1: launch<1>(p, (unsigned)blocks, stream); break;      // no DMA
         case 2: launch<2>(p, (unsigned)blocks, stream); break;      // no barriers
@@ -271,6 +272,9 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
         case 128: launch<128>(p, (unsigned)blocks, stream); break;  // no s_setprio
         default: launch<0>(p, (unsigned)blocks, stream);
     }
+#else
+    launch<0>(p, (unsigned)blocks, stream);
+#endif
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 1;

@@ -212,9 +212,9 @@ int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream) {
     // short K (the 1x1 downsample / head convolutions and their dgrads, K = 128 .. 512) included: those launches are bound by their
     // epilogue traffic, and this kernel's 16-byte staged epilogue moves it 2-4x faster than the register-staged kernel's (layer4
     // downsample forward 101 -> 60 us, head conv1 dgrad with the fused BN-backward sums 290 -> 66 us at B = 128)
-    static const int min_k = [] { const char* e = getenv("SIMQ_BF16_PP_MINK"); return e ? atoi(e) : BK; }();
+    static const int min_k = SIMQ_TUNE_INT("SIMQ_BF16_PP_MINK", BK);
     if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.R * a.S > 32 || a.K < min_k) return 0;
-    static const int mode = [] { const char* e = getenv("SIMQ_BF16_PP"); return e ? atoi(e) : 1; }();   // 0 = off
+    static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_PP", 1);   // 0 = off
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
     const bool forced = tune_forced_tile(&fbm, &fbn);
@@ -229,7 +229,8 @@ int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream) {
     p.xcd_chunk = bf16_xcd_chunk((int)blocks, p.tilesN);
     prof_launch_begin(2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout), stream);
-    static const int dbg = [] { const char* e = getenv("SIMQ_BF16_PP_DBG"); return e ? atoi(e) : 0; }();   // timing ablations (tools/pp_check.py)
+#ifdef SIMQ_ABLATIONS      // timing ablations (tools/pp_check.py): compiled into libsimq_ablate.so only
+    static const int dbg = SIMQ_TUNE_INT("SIMQ_BF16_PP_DBG", 0);   // timing ablations (tools/pp_check.py)
     switch (dbg) {
         case 1: launch<1>(p, (unsigned)blocks, stream); break;      // no DMA
         case 2: launch<2>(p, (unsigned)blocks, stream); break;      // no barriers
@@ -245,6 +246,9 @@ int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream) {
         case 80: launch<80>(p, (unsigned)blocks, stream); break;    // masked DMA, no MFMA
         default: launch<0>(p, (unsigned)blocks, stream);
     }
+#else
+    launch<0>(p, (unsigned)blocks, stream);
+#endif
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 1;

@@ -249,7 +249,7 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
         const double cost = (double)rounds * ((rsteps + s - 1) / s + 6) / util;
         if (cost < best * 0.999) { best = cost; splits = s; }
     }
-    if (const char* e = getenv(batch > 1 ? "SIMQ_WGRAD_BATCHED_SPLITS" : "SIMQ_WGRAD_SPLITS")) splits = atoi(e);   // tuning aid (tools/wgrad_splits.py)
+    if (const int forced_s = batch > 1 ? SIMQ_TUNE_INT("SIMQ_WGRAD_BATCHED_SPLITS", 0) : SIMQ_TUNE_INT("SIMQ_WGRAD_SPLITS", 0)) splits = forced_s;   // tuning aid (tools/wgrad_splits.py, ablation build)
     int rps = (p.M + splits - 1) / splits;
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;

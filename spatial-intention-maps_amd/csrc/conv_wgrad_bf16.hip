@@ -247,7 +247,7 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
     // block slots per CU the split count is chosen for: with a long pixel reduction the register-staged kernel is latency-bound at one
     // block per CU and two co-resident blocks cover each other's staging (bf16 configs[2], B = 128: 1 / 2 / 3 slots -> 12 213 / 12 331 /
     // 12 200 tr/s); at B = 32 the shorter reductions lose more to the extra atomics than they gain (7009 vs 6880 tr/s)
-    static const int occ_env = [] { const char* e = getenv("SIMQ_WGRAD_BF16_OCC"); return e ? atoi(e) : 0; }();
+    static const int occ_env = SIMQ_TUNE_INT("SIMQ_WGRAD_BF16_OCC", 0);
     const int occ = occ_env >= 1 ? occ_env : (p.M >= 32768 ? 2 : 1);
     for (int s = 1; s <= max_splits; ++s) {
         const long rounds = ((long)tiles * s + 256 * occ - 1) / (256 * occ);

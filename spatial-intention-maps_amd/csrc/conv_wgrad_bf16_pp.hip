@@ -217,7 +217,7 @@ int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, con
                            hipStream_t stream) {
     if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.Hin != HW || g.Win != HW || g.Hout != HW || g.Wout != HW) return 0;
     if (g.Cin % TJ != 0 || g.Cout % TI != 0) return 0;
-    static const int mode = [] { const char* e = getenv("SIMQ_BF16_WGRAD_PP"); return e ? atoi(e) : 1; }();   // 0 = off
+    static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_WGRAD_PP", 1);   // 0 = off
     if (mode == 0) return 0;
     WgradPpArgs p;
     p.x = x; p.dy = dy; p.dw = dw; p.Cin = g.Cin; p.Cout = g.Cout; p.M = g.M(); p.K = g.K();
@@ -228,7 +228,7 @@ int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, con
     const int rsteps = (p.M + BRB - 1) / BRB;
     if (rsteps < 64) return 0;                           // tiny batches: the register-staged kernel
     // splits: tiles x splits fills whole rounds of the 256 CUs (one block per CU), at least ~24 steps per block
-    static const int dbg = [] { const char* e = getenv("SIMQ_BF16_WGRAD_PP_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = SIMQ_TUNE_INT("SIMQ_BF16_WGRAD_PP_DBG", 0);
     p.dbg = dbg;
     int best_s = 1;
     double best = 1e300;

@@ -656,22 +656,10 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ 
     }
 }
 
-int g_winograd = -1;   // SIMQ_WINOGRAD=0 keeps every convolution on the implicit-GEMM kernel (A-B runs)
-
 }  // namespace
 
-bool winograd_enabled() {
-    if (g_winograd < 0) { const char* s = getenv("SIMQ_WINOGRAD"); g_winograd = (s && atoi(s) == 0) ? 0 : 1; }
-    return g_winograd != 0;
-}
-
-void tune_winograd(int on) { g_winograd = on ? 1 : 0; }
-
-bool winograd_wgrad_enabled() {   // SIMQ_WINOGRAD_WGRAD=0: weight gradients of the Winograd layers stay on the direct kernel
-    static int on = -1;
-    if (on < 0) { const char* s = getenv("SIMQ_WINOGRAD_WGRAD"); on = (s && atoi(s) == 0) ? 0 : 1; }
-    return on != 0;
-}
+// Which convolutions of a plan run in Winograd form, and in which form, is a property of the PLAN: simq_plan_options
+// (include/simq.h), read by plan.hip.  The functions below are pure geometry / cost rules.
 
 // Geometry the kernels handle: 3x3 / stride 1 / pad 1 on an even-sized map, channel counts that fill the float4 lanes of the
 // transform kernels (C / 4 divides 256) and the GEMM's tiles.
@@ -681,15 +669,11 @@ bool winograd_eligible(const ConvGeom& g) {
            g.Cin % 16 == 0 && g.Cout % 64 == 0 && lanes_ok(g.Cin) && lanes_ok(g.Cout);
 }
 
-// Layers the transform pays for: enough multiply-adds per transformed element (tools/winograd_probe.py); SIMQ_WINOGRAD_MIN
-// overrides the Cin * Cout threshold.  Round 1 (F(2x2,3x3) only) drew the line at 128 * 256; with the F(4x4,3x3) forms of the
+// Layers the transform pays for: enough multiply-adds per transformed element (tools/winograd_probe.py); the Cin * Cout threshold
+// is simq_plan_options.winograd_min_cc (default 128 * 128).  Round 1 (F(2x2,3x3) only) drew the line at 128 * 256; with the F(4x4,3x3) forms of the
 // no-grad forwards and dgrads the 128 -> 128 layers of layer2 pay as well: 3131 -> 3175 tr/s on configs[1] (forward + backward alone
 // unchanged: the gain is in the two no-grad forwards); 64 -> 64 (layer1) does not (3155, forward + backward -0.7 %).
-bool winograd_pays(int cin, int cout) {
-    static long min_cc = -1;
-    if (min_cc < 0) { const char* s = getenv("SIMQ_WINOGRAD_MIN"); min_cc = s ? atol(s) : 128L * 128; }
-    return (long)cin * cout >= min_cc;
-}
+bool winograd_pays(int cin, int cout, long min_cc) { return (long)cin * cout >= min_cc; }
 
 int64_t winograd_scratch_floats(const ConvGeom& g) {
     const int64_t T = (int64_t)g.B * (g.Hin / 2) * (g.Win / 2);
@@ -738,13 +722,11 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
 
 // F(4x4,3x3) form for the no-grad forwards: U4 = G4 w G4^T [36][Cout][Cin] (weight cache); scratch as for the F(2x2,3x3) form
 // (V4 | Mt4 = 9 * T * (Cin + Cout) floats fit the 16 * T * (Cin + Cout) region).  Eligible maps are multiples of 4.
-bool winograd_f4_forward(const ConvGeom& g) {
-    static const int on = getenv("SIMQ_WINOGRAD_F4_FWD") ? atoi(getenv("SIMQ_WINOGRAD_F4_FWD")) : 1;       // 0: no-grad forwards stay F(2x2,3x3)
-    static const int min_tiles = getenv("SIMQ_WINOGRAD_F4_MIN_TILES") ? atoi(getenv("SIMQ_WINOGRAD_F4_MIN_TILES")) : 256;
-    return on && winograd_eligible(g) && g.Hin % 4 == 0 && g.Win % 4 == 0 && g.B * (g.Hin / 4) * (g.Win / 4) >= min_tiles;
+bool winograd_f4_forward(const ConvGeom& g, int min_tiles) {      // (simq_plan_options.winograd_f4_forward / _f4_min_tiles)
+    return winograd_eligible(g) && g.Hin % 4 == 0 && g.Win % 4 == 0 && g.B * (g.Hin / 4) * (g.Win / 4) >= min_tiles;
 }
 
-// How far F(4x4,3x3) reaches into the differentiated path (SIMQ_WINOGRAD_F4_GRAD):
+// How far F(4x4,3x3) reaches into the differentiated path (simq_plan_options.winograd_f4_grad):
 //   2 (default)  the DGRADS too.  The gradient-parity study (tests/test_gpu_fcn.py::test_gradient_parity_distribution, 13 seeded
 //                batches vs fp64) is unchanged to three digits by it -- median error 1.61e-3 either way (reference fp32: 2.04e-3):
 //                the error of these gradients is made by the FORWARD's round-off (ReLU masks, x-hat of the train-mode BatchNorms),
@@ -752,10 +734,6 @@ bool winograd_f4_forward(const ConvGeom& g) {
 //   1            the grad-mode forward as well: 3231 tr/s, but the median gradient error doubles to 3.1e-3 (1.5 x the reference's
 //                own fp32) -- within the study's bar, not adopted: the forward's accuracy is the gradient's accuracy.
 //   0            the differentiated path stays F(2x2,3x3) entirely.
-int winograd_f4_grad() {
-    static const int on = getenv("SIMQ_WINOGRAD_F4_GRAD") ? atoi(getenv("SIMQ_WINOGRAD_F4_GRAD")) : 2;
-    return on;
-}
 
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                           hipStream_t stream) {
@@ -784,24 +762,25 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
 // Cin % 128 == 0 and Cout % 128 == 0.
 bool winograd_wgrad_eligible(const ConvGeom& g) { return winograd_eligible(g) && g.Cin % 128 == 0 && g.Cout % 128 == 0; }
 
-bool winograd_wgrad_f4(const ConvGeom& g) {   // the F(4x4,3x3) form applies (SIMQ_WINOGRAD_WGRAD_F4=0 switches it off)
-    static const int f4 = getenv("SIMQ_WINOGRAD_WGRAD_F4") ? atoi(getenv("SIMQ_WINOGRAD_WGRAD_F4")) : 1;
-    return f4 && g.Hin % 4 == 0 && g.Win % 4 == 0 && (g.B * (g.Hin / 4) * (g.Win / 4)) % 16 == 0;
+bool winograd_wgrad_f4(const ConvGeom& g) {   // the F(4x4,3x3) form applies to this geometry (simq_plan_options.winograd_wgrad_f4 allows it)
+    return g.Hin % 4 == 0 && g.Win % 4 == 0 && (g.B * (g.Hin / 4) * (g.Win / 4)) % 16 == 0;
 }
 
 // where the transform domain beats the direct wgrad kernel (tools/winograd_probe.py): from 256 x 256 channels with F(2x2,3x3),
 // from 128 x 256 with F(4x4,3x3) (0.081 vs 0.118 ms; F(2x2,3x3) loses there)
-bool winograd_wgrad_pays(const ConvGeom& g) { return (long)g.Cin * g.Cout >= (winograd_wgrad_f4(g) ? 128L * 256 : 256L * 256); }
+bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4) {
+    return (long)g.Cin * g.Cout >= ((allow_f4 && winograd_wgrad_f4(g)) ? 128L * 256 : 256L * 256);
+}
 
-int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream) {
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
     const int T = g.B * (g.Hin / 2) * (g.Win / 2);
     float* Vt = scratch;                                   // [16][Cin][T]
     float* dMt = scratch + (size_t)16 * T * g.Cin;         // [16][Cout][T]
     float* dU = dMt + (size_t)16 * T * g.Cout;             // [16][Cout][Cin]
-    static const int direct_form = getenv("SIMQ_WINOGRAD_WGRAD_SPLITK") ? atoi(getenv("SIMQ_WINOGRAD_WGRAD_SPLITK")) : 0;
+    static const int direct_form = SIMQ_TUNE_INT("SIMQ_WINOGRAD_WGRAD_SPLITK", 0);     // (kernel-form ablation)
     const int T4 = g.B * (g.Hin / 4) * (g.Win / 4);
-    if (!direct_form && winograd_wgrad_f4(g)) {   // F(4x4,3x3): 36 GEMMs over T4 = T / 4 tiles
+    if (!direct_form && allow_f4 && winograd_wgrad_f4(g)) {   // F(4x4,3x3): 36 GEMMs over T4 = T / 4 tiles
         float* Vt4 = scratch;                                   // [36][Cin][T4]
         float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][Cout][T4]
         float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][Cout][Cin]

@@ -201,10 +201,10 @@ int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, 
     // 2 x 256 block slots) -- and 0.0 % on the whole step (3098 vs 3100 tr/s), where the side-stream forward already fills the
     // matrix pipe's idle slots.  Ablations on the 512 -> 512 problem: no DMA 304 us, no fragment reads 312 us, no MFMA 132 us: the
     // matrix pipe alone runs at 127 TF/s inside this structure, the staging adds ~60 us that the ping-pong does not hide.
-    static const int mode = [] { const char* e = getenv("SIMQ_F32_PP"); return e ? atoi(e) : 0; }();
+    static const int mode = SIMQ_TUNE_INT("SIMQ_F32_PP", 0);
     if (mode == 0 || N % BN != 0 || K % BK != 0 || K < BK) return 0;
-    static const int min_m = [] { const char* e = getenv("SIMQ_F32_PP_MIN_M"); return e ? atoi(e) : 4096; }();
-    static const int min_n = [] { const char* e = getenv("SIMQ_F32_PP_MIN_N"); return e ? atoi(e) : 512; }();
+    static const int min_m = SIMQ_TUNE_INT("SIMQ_F32_PP_MIN_M", 4096);
+    static const int min_n = SIMQ_TUNE_INT("SIMQ_F32_PP_MIN_N", 512);
     if (mode != 2 && (M < min_m || N < min_n)) return 0;
     const double xb = 4.0 * M * K, wb = 4.0 * N * K, yb = 4.0 * M * N;
     if (xb >= 4294967000.0 || wb >= 4294967000.0 || yb >= 4294967000.0) return 0;
@@ -217,13 +217,14 @@ int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, 
     const int tiles = tilesM * p.tilesN;
     // XCD-aware order (blocks go round-robin over the 8 XCDs, each with its own L2): one XCD walks a contiguous run of tiles, so the
     // N-tiles that share a row block read it through one L2
-    static const bool remap = [] { const char* e = getenv("SIMQ_XCD_REMAP"); return !(e && atoi(e) == 0); }();
+    static const bool remap = SIMQ_TUNE_INT("SIMQ_XCD_REMAP", 1) != 0;
     p.xcd_chunk = (remap && p.tilesN > 1 && tiles >= 64 && tiles % 8 == 0) ? tiles / 8 : 0;
     p.tiles = tiles; p.batch = batch;
     p.full = remap ? (batch / 8) * 8 : 0;
     prof_launch_begin(0, 2.0 * M * N * K * batch, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N), stream);
-    static const int dbg = [] { const char* e = getenv("SIMQ_F32_PP_DBG"); return e ? atoi(e) : 0; }();   // timing ablations
     const dim3 grid((unsigned)tiles * (unsigned)batch);
+#ifdef SIMQ_ABLATIONS      // timing ablations (tools/f32pp_check.py): compiled into libsimq_ablate.so only
+    static const int dbg = SIMQ_TUNE_INT("SIMQ_F32_PP_DBG", 0);   // timing ablations
     switch (dbg) {
         case 1: launch<1>(p, grid, stream); break;       // no DMA
         case 2: launch<2>(p, grid, stream); break;       // no barriers
@@ -231,6 +232,9 @@ int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, 
         case 16: launch<16>(p, grid, stream); break;     // no MFMAs
         default: launch<0>(p, grid, stream);
     }
+#else
+    launch<0>(p, grid, stream);
+#endif
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 1;

@@ -29,7 +29,7 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream);
 
 // SIMQ_XCD_REMAP=0 keeps launch order
 inline int bf16_xcd_chunk(int tiles, int tilesN) {
-    static const int on = (getenv("SIMQ_XCD_REMAP") && atoi(getenv("SIMQ_XCD_REMAP")) == 0) ? 0 : 1;
+    static const int on = SIMQ_TUNE_INT("SIMQ_XCD_REMAP", 1) != 0 ? 1 : 0;
     return (on && tilesN > 1 && tiles >= 64) ? tiles / 8 : 0;
 }
 

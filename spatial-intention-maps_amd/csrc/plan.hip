@@ -22,6 +22,13 @@ namespace simq {
 
 static thread_local char g_error[512] = "";
 
+#ifdef SIMQ_ABLATIONS
+int tune_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -72,6 +79,7 @@ using namespace simq;
 struct simq_plan {
     int cin, cout;
     int precision = SIMQ_PREC_FP32;   // arithmetic of the 3x3 / 1x1 convolutions (stem and conv3 are always fp32)
+    simq_plan_options opt;            // which form / storage / fusion every layer uses: fixed at creation, never read from the environment
     int np() const { return precision == SIMQ_PREC_BF16X3 ? 2 : 1; }
     ConvL stem, h1, h2, h3;
     BnL stem_bn, hb1, hb2;
@@ -102,7 +110,7 @@ struct Builder {
         }
         if (dgrad) { c.wt_off = p->wt_total; p->wt_total += c.wcount(); c.wp_off = p->wp_total; p->wp_total += c.wcount(); }
         // fp32 plans: the wide 3x3 layers run as Winograd F(2x2,3x3) (conv_winograd.hip); every one of them sits on the 24x24 maps
-        if (p->precision == SIMQ_PREC_FP32 && dgrad && k == 3 && stride == 1 && pad == 1 && winograd_enabled() && winograd_pays(cin, cout)) {
+        if (p->precision == SIMQ_PREC_FP32 && dgrad && k == 3 && stride == 1 && pad == 1 && p->opt.winograd && winograd_pays(cin, cout, p->opt.winograd_min_cc)) {
             ConvGeom g;
             g.B = 1; g.Hin = g.Win = g.Hout = g.Wout = 24; g.Cin = cin; g.Cout = cout; g.R = g.S = 3; g.stride = 1; g.pad = 1;
             ConvGeom gt = g;
@@ -115,7 +123,7 @@ struct Builder {
             }
             if (winograd_eligible(gt)) {
                 c.wut_off = p->wu_total; p->wu_total += 16 * c.wcount() / 9;
-                if (winograd_f4_grad()) { c.wut4_off = p->wu_total; p->wu_total += 36 * c.wcount() / 9; }
+                if (p->opt.winograd_f4_grad) { c.wut4_off = p->wu_total; p->wu_total += 36 * c.wcount() / 9; }
                 p->wino_scratch_per_sample = std::max(p->wino_scratch_per_sample, winograd_scratch_floats(gt));
             }
         }
@@ -207,9 +215,8 @@ WLayout make_wlayout(const simq_plan* p) {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
         W.wpl = take(p->wp_total * h);
         W.wtpl = take(p->wp_total * h);
-        // plain-bf16 plans: the first convolution's weights in the layout of stem_conv_bf16.hip (SIMQ_NO_STEM16=1: fp32 kernel)
-        static const bool no_stem16 = getenv("SIMQ_NO_STEM16") != nullptr;
-        if (p->precision == SIMQ_PREC_BF16 && !no_stem16 &&
+        // plain-bf16 plans: the first convolution's weights in the layout of stem_conv_bf16.hip (options.stem_bf16 = 0: fp32 kernel)
+        if (p->precision == SIMQ_PREC_BF16 && p->opt.stem_bf16 &&
             stem_conv_bf16_eligible(96, 96, p->stem.cin, p->stem.cout, p->stem.k, p->stem.stride, p->stem.pad))
             W.stem16 = take(stem_conv_bf16_wbytes());
     }
@@ -247,11 +254,8 @@ struct Ctx {
     int ybf() const { return p->precision == SIMQ_PREC_BF16 ? 1 : 0; }
     int ybf(const ConvL& cv) const { return (p->precision == SIMQ_PREC_BF16 && cv.wp_off >= 0) ? 1 : 0; }
     // ... and the activation gradients that travel between the residual blocks' kernels (dgrad epilogue -> BatchNorm backward ->
-    // next dgrad's addend) as bf16 too: the dgrad epilogues are HBM-bound (SIMQ_FP32_ACT_GRADS=1 keeps them fp32, diagnostics)
-    int gbf() const {
-        static const bool fp32g = getenv("SIMQ_FP32_ACT_GRADS") != nullptr;
-        return (p->precision == SIMQ_PREC_BF16 && !fp32g) ? 1 : 0;
-    }
+    // next dgrad's addend) as bf16 too: the dgrad epilogues are HBM-bound (options.bf16_act_grads = 0 keeps them fp32, diagnostics)
+    int gbf() const { return (p->precision == SIMQ_PREC_BF16 && p->opt.bf16_act_grads) ? 1 : 0; }
     Planes planes(int64_t off, int64_t elems) const {
         Planes pl;
         if (mc() && off >= 0) {
@@ -262,12 +266,9 @@ struct Ctx {
     }
     Act act(int64_t off, int64_t poff, int64_t elems) const { Act a; a.f = f(off); a.pl = planes(poff, elems); return a; }
     // matrix-core precisions: the post-BN activations inside the residual blocks are consumed as bf16 planes only (convolution
-    // operands, residuals, ReLU masks), so their fp32 copies are neither written nor read (SIMQ_KEEP_FP32_ACT=1 keeps them,
-    // for FCN.saved_activation / tests/diag)
-    bool planes_only() const {
-        static const bool keep = getenv("SIMQ_KEEP_FP32_ACT") != nullptr || getenv("SIMQ_NO_BNR_FUSE") != nullptr;
-        return mc() && !keep;
-    }
+    // operands, residuals, ReLU masks), so their fp32 copies are neither written nor read (options.keep_fp32_activations = 1 keeps them,
+    // for FCN.saved_activation / tests/diag; the unfused BatchNorm-backward reductions read them too)
+    bool planes_only() const { return mc() && !p->opt.keep_fp32_activations && p->opt.fuse_bn_backward_sums; }
     Act block_act(int64_t off, int64_t poff, int64_t elems) const { Act a = act(off, poff, elems); a.fv = !planes_only(); return a; }
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
@@ -294,7 +295,8 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
         c.wplanes(cv, false, wsp);
         return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
     }
-    if ((nograd || winograd_f4_grad() == 1) && cv.wu4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
+    if ((nograd || c.p->opt.winograd_f4_grad == 1) && cv.wu4_off >= 0 && c.L.wino >= 0 && c.p->opt.winograd_f4_forward &&
+        winograd_f4_forward(g, c.p->opt.winograd_f4_min_tiles))
         return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream);
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
         return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream);
@@ -409,7 +411,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     // eval mode, fp32 arithmetic: BatchNorm folded into the convolution epilogues (no bn_apply launches, no pre-BN
     // round trip through HBM); the matrix-core precisions keep bn_apply, which also writes their bf16 planes
     // ... and so do plain-bf16 plans when only the planes of the block activations are kept (conv_bn_folded_planes)
-    static const bool no_fold16 = getenv("SIMQ_NO_BF16_EVAL_FOLD") != nullptr;      // diagnostics
+    const bool no_fold16 = !p->opt.fold_eval_bn_bf16;      // diagnostics
     const bool folded16 = mode == SIMQ_MODE_EVAL && p->precision == SIMQ_PREC_BF16 && c.planes_only() && !no_fold16;
     const bool folded = (mode == SIMQ_MODE_EVAL && !c.mc()) || folded16;
     if (folded) RC(launch_bn_eval_coeff(bn_eval_table(p), c.params, c.bnbuf, c.f(L.aux), c.stream));
@@ -533,8 +535,9 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
     }
-    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && winograd_wgrad_pays(g) && winograd_wgrad_enabled())
-        return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream);
+    if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && c.p->opt.winograd_wgrad &&
+        winograd_wgrad_pays(g, c.p->opt.winograd_wgrad_f4 != 0))
+        return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream, c.p->opt.winograd_wgrad_f4 != 0);
     return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
 }
 
@@ -555,7 +558,7 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
         c.wplanes(cv, true, wsp);
         return launch_conv_igemm_bf16(ds, wsp, c.p->np(), dx, g, e, c.stream);
     }
-    if (cv.wut4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g))
+    if (cv.wut4_off >= 0 && c.L.wino >= 0 && winograd_f4_forward(g, c.p->opt.winograd_f4_min_tiles))
         return launch_conv_winograd4(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wut4_off, dx, g, e, c.f(c.L.wino), c.stream);
     if (cv.wut_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
         return launch_conv_winograd(dy.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wut_off, dx, g, e, c.f(c.L.wino), c.stream);
@@ -584,7 +587,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
-    static const bool no_fuse_head = getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // (diagnostics: separate reduction kernels)
+    const bool no_fuse_head = !p->opt.fuse_bn_backward_sums;   // (diagnostics: separate reduction kernels)
     if (phase != 2) {
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
         RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
@@ -622,7 +625,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     }
     // every dgrad that completes the gradient of a block output (or of a block's inner activation) also
     // accumulates sum(dz), sum(dz*xhat) of the BatchNorm(s) that consume that gradient next
-    static const bool no_fuse = getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // diagnostics: separate reduction kernels
+    const bool no_fuse = !p->opt.fuse_bn_backward_sums;   // diagnostics: separate reduction kernels
     auto fuse_block_out = [&](int bi) {   // bn2 (+ downsample BN) of block bi: mask = its output
         ConvEpilogue e;
         if (no_fuse) return e;
@@ -689,7 +692,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     if (stem16) { T1 = dyact(S[(gi + 2) & 3], 1); T1.fv = false; }
     Act x0; x0.f = c.f(L.x);
     const int y0_bf16 = c.W.stem16 >= 0 ? 1 : 0;     // pre-BN output: fp32, or bf16 from stem_conv_bf16
-    static const bool no_stem_fuse = getenv("SIMQ_NO_STEM_FUSE") != nullptr || getenv("SIMQ_NO_BNR_FUSE") != nullptr;   // diagnostics
+    const bool no_stem_fuse = !p->opt.fuse_stem_backward_sums || !p->opt.fuse_bn_backward_sums;   // diagnostics
     double* srep = reinterpret_cast<double*>(c.ws + L.red) + p->stem_rep_off;
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf(),
                             c.f(L.y0), c.aux(p->stem_bn, 2), c.aux(p->stem_bn, 3), no_stem_fuse ? nullptr : srep, y0_bf16, kStatReplicas));
@@ -713,15 +716,50 @@ int copy_name(const std::string& s, char* dst, int cap) {
 extern "C" {
 
 int simq_version(void) { return SIMQ_VERSION; }
+
+int simq_build_flags(void) {
+#ifdef SIMQ_ABLATIONS
+    return SIMQ_BUILD_ABLATIONS;
+#else
+    return 0;
+#endif
+}
 const char* simq_last_error(void) { return simq::g_error; }
 
-int simq_plan_create_ex(int cin, int cout, int precision, simq_plan** out) {
+void simq_plan_options_default(simq_plan_options* o) {
+    if (!o) return;
+    o->struct_bytes = (int)sizeof(simq_plan_options);
+    o->winograd = 1; o->winograd_min_cc = 128 * 128; o->winograd_f4_forward = 1; o->winograd_f4_min_tiles = 256;
+    o->winograd_f4_grad = 2; o->winograd_wgrad = 1; o->winograd_wgrad_f4 = 1;
+    o->stem_bf16 = 1; o->bf16_act_grads = 1; o->keep_fp32_activations = 0; o->fold_eval_bn_bf16 = 1;
+    o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
+}
+
+int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out) {
+    SIMQ_REQUIRE(plan && out, "plan_get_options: NULL argument");
+    *out = plan->opt;
+    return 0;
+}
+
+int simq_plan_create_ex(int cin, int cout, int precision, simq_plan** out) { return simq_plan_create_opts(cin, cout, precision, nullptr, out); }
+
+int simq_plan_create_opts(int cin, int cout, int precision, const simq_plan_options* opts, simq_plan** out) {
     SIMQ_REQUIRE(out != nullptr, "plan_create: out is NULL");
+    simq_plan_options opt;
+    simq_plan_options_default(&opt);
+    if (opts) {
+        SIMQ_REQUIRE(opts->struct_bytes == (int)sizeof(simq_plan_options), "plan_create: simq_plan_options.struct_bytes = %d, this library's struct has %d "
+                     "(fill it with simq_plan_options_default first)", opts->struct_bytes, (int)sizeof(simq_plan_options));
+        opt = *opts;
+        SIMQ_REQUIRE(opt.winograd_f4_grad >= 0 && opt.winograd_f4_grad <= 2, "plan_create: winograd_f4_grad = %d (0, 1 or 2)", opt.winograd_f4_grad);
+        SIMQ_REQUIRE(opt.winograd_min_cc >= 64 * 64, "plan_create: winograd_min_cc = %d below 64*64 (layer1 does not fit the transform table)", opt.winograd_min_cc);
+        SIMQ_REQUIRE(opt.winograd_f4_min_tiles >= 1, "plan_create: winograd_f4_min_tiles = %d", opt.winograd_f4_min_tiles);
+    }
     SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
     SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);
     SIMQ_REQUIRE(precision >= SIMQ_PREC_FP32 && precision <= SIMQ_PREC_BF16, "plan_create: bad precision %d", precision);
     simq_plan* p = new simq_plan();
-    p->cin = cin; p->cout = cout; p->precision = precision;
+    p->cin = cin; p->cout = cout; p->precision = precision; p->opt = opt;
     Builder bd{p};
     bd.conv(p->stem, "resnet18.conv1", cin, 64, 7, 2, 3, false, false);
     bd.bn(p->stem_bn, "resnet18.bn1", 64);

@@ -71,11 +71,6 @@ int simq_tune_force_tile(int bm, int bn) {
     return 0;
 }
 
-int simq_tune_winograd(int on) {
-    simq::tune_winograd(on);
-    return 0;
-}
-
 int simq_tune_tail_split(int on) {
     simq::tune_tail_split(on);
     return 0;

@@ -13,7 +13,10 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401  (must precede the CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsimq.so')
+# The product library.  tools/ may name the ablation build (libsimq_ablate.so, `make -C csrc ablate`: kernel-selection switches from
+# SIMQ_* environment variables, timing-ablation kernels) through SIMQ_LIBRARY; `build_flags` says which one is loaded and bench.py /
+# the parity tests refuse anything but the product.  Neither build reads its ARITHMETIC from the environment (simq_plan_options).
+LIB_PATH = os.environ.get('SIMQ_LIBRARY') or os.path.join(_HERE, 'libsimq.so')
 
 MODE_EVAL, MODE_TRAIN, MODE_TRAIN_NOGRAD = 0, 1, 2
 KIND_CONV_W, KIND_CONV_B, KIND_BN_W, KIND_BN_B = 0, 1, 2, 3
@@ -39,6 +42,14 @@ class SyncArgs(ctypes.Structure):
     _fields_ = [('reduce', REDUCE_FN), ('user', c_void_p), ('global_batch', c_int), ('world_size', c_int)]
 
 
+class PlanOptions(ctypes.Structure):
+    """simq_plan_options of include/simq.h: the algebraic forms / storage precisions / fusions of a plan (fixed at creation)."""
+    _fields_ = [(n, c_int) for n in (
+        'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
+        'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
+        'fuse_bn_backward_sums', 'fuse_stem_backward_sums')]
+
+
 class TrainArgs(ctypes.Structure):
     """simq_train_args of include/simq.h (the whole TD step in one library call)."""
     _fields_ = [('plan', c_void_p),
@@ -55,9 +66,13 @@ class TrainArgs(ctypes.Structure):
 
 _SIGS = {
     'simq_version': (c_int, []),
+    'simq_build_flags': (c_int, []),
     'simq_last_error': (c_char_p, []),
     'simq_plan_create': (c_int, [c_int, c_int, POINTER(c_void_p)]),
     'simq_plan_create_ex': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    'simq_plan_options_default': (None, [c_void_p]),
+    'simq_plan_create_opts': (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    'simq_plan_get_options': (c_int, [c_void_p, c_void_p]),
     'simq_plan_precision': (c_int, [c_void_p]),
     'simq_plan_destroy': (None, [c_void_p]),
     'simq_param_count': (c_int64, [c_void_p]),
@@ -100,7 +115,6 @@ _SIGS = {
     'simq_profile_stop': (c_int, [c_void_p, c_int]),
     'simq_tune_force_tile': (c_int, [c_int, c_int]),
     'simq_tune_tail_split': (c_int, [c_int]),
-    'simq_tune_winograd': (c_int, [c_int]),
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
@@ -152,6 +166,8 @@ class Lib:
     """Thin checked wrappers; all pointers come from torch tensors."""
     c = _c
     version = _c.simq_version()
+    build_flags = _c.simq_build_flags()          # 0: the product; 1: the ablation build (tools only)
+    path = LIB_PATH
 
     @staticmethod
     def call(name, *args):
@@ -161,17 +177,32 @@ class Lib:
 lib = Lib()
 
 
+# in-process default overrides for every Plan created afterwards (tools/ and diagnostics set entries here; never read from the
+# environment: a plan's arithmetic must not depend on who exported what)
+DEFAULT_PLAN_OPTIONS = {}
+
+
 class Plan:
     """Owns a simq_plan* and exposes its buffer layout."""
 
-    def __init__(self, num_input_channels, num_output_channels, precision='fp32'):
+    def __init__(self, num_input_channels, num_output_channels, precision='fp32', options=None):
+        """options: {simq_plan_options field: int} overriding the defaults (include/simq.h) -- A/B measurements and diagnostics."""
         self.cin, self.cout = int(num_input_channels), int(num_output_channels)
         if precision not in PRECISIONS:
             raise SimqError('unknown precision %r (choose from %s)' % (precision, sorted(PRECISIONS)))
         self.precision = precision
+        o = PlanOptions()
+        _c.simq_plan_options_default(ctypes.byref(o))
+        for k, v in dict(DEFAULT_PLAN_OPTIONS, **(options or {})).items():
+            if k == 'struct_bytes' or not hasattr(o, k):
+                raise SimqError('unknown plan option %r (fields of simq_plan_options: %s)' % (k, ', '.join(n for n, _ in PlanOptions._fields_[1:])))
+            setattr(o, k, int(v))
         h = c_void_p()
-        check(_c.simq_plan_create_ex(self.cin, self.cout, PRECISIONS[precision], ctypes.byref(h)), 'simq_plan_create_ex')
+        check(_c.simq_plan_create_opts(self.cin, self.cout, PRECISIONS[precision], ctypes.byref(o), ctypes.byref(h)), 'simq_plan_create_opts')
         self.handle = h
+        got = PlanOptions()
+        check(_c.simq_plan_get_options(h, ctypes.byref(got)), 'simq_plan_get_options')
+        self.options = {n: getattr(got, n) for n, _ in PlanOptions._fields_[1:]}
         self.param_count = _c.simq_param_count(h)
         self.bnbuf_count = _c.simq_bnbuf_count(h)
         self.tensors = []     # (name, offset, shape(list), kind)

@@ -59,7 +59,7 @@ def _reference_view(flat, shape):
 
 
 class FCN(torch.nn.Module):
-    def __init__(self, num_input_channels=3, num_output_channels=1, device=None, dataparallel_keys=True, precision='fp32'):
+    def __init__(self, num_input_channels=3, num_output_channels=1, device=None, dataparallel_keys=True, precision='fp32', options=None):
         super().__init__()
         if device is None:
             device = torch.device('cuda')
@@ -69,7 +69,7 @@ class FCN(torch.nn.Module):
         self.num_input_channels, self.num_output_channels = int(num_input_channels), int(num_output_channels)
         self.key_prefix = arch.PREFIX if dataparallel_keys else ''
         self.precision = precision   # 'fp32' (exact fp32 MFMA) | 'bf16x3' (split-bf16, fp32-class) | 'bf16'
-        self.plan = Plan(num_input_channels, num_output_channels, precision)
+        self.plan = Plan(num_input_channels, num_output_channels, precision, options)   # options: simq_plan_options overrides (A/B, diagnostics)
         P = self.plan.param_count
         self.flat_params = torch.zeros(P, dtype=torch.float32, device=self.device_)
         self.flat_grads = torch.zeros(P, dtype=torch.float32, device=self.device_)

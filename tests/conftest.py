@@ -32,6 +32,15 @@ def pytest_sessionstart(session):
         raise pytest.UsageError('libsimq build failed (make rc %d):\n%s' % (r.returncode, r.stdout[-3000:]))
 
 
+@pytest.fixture(autouse=True, scope='session')
+def _product_library_only():
+    """The parity tests run the product libsimq.so: never the ablation build (SIMQ_LIBRARY), whose kernel selection follows the
+    environment."""
+    if os.environ.get('SIMQ_LIBRARY'):
+        raise pytest.UsageError('SIMQ_LIBRARY is set (%s): the tests run the product library only' % os.environ['SIMQ_LIBRARY'])
+    yield
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests must FAIL (not skip) on a GPU box whose HIP library is missing;
     on a box without any GPU they are deselected by -m "not gpu"."""

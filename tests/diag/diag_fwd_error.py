@@ -1,11 +1,11 @@
 """Diagnostic (GPU): per-layer forward error of a precision mode vs the fp64 oracle (and the fp32 oracle's own error)."""
 import os, sys
-os.environ.setdefault("SIMQ_KEEP_FP32_ACT", "1")   # this tool reads the fp32 copies of the block activations (FCN.saved_activation)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')]
 import torch
 import simq
-from simq import synth
+from simq import synth, _lib
+_lib.DEFAULT_PLAN_OPTIONS['keep_fp32_activations'] = 1   # this tool reads the fp32 copies of the block activations (FCN.saved_activation)
 from oracle import cases, fcn as ofcn, learner as ol
 
 PREC = sys.argv[1] if len(sys.argv) > 1 else 'bf16x3'

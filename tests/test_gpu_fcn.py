@@ -47,8 +47,8 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def make_net(simq_mod, cin, cout, seed, training, precision='fp32'):
-    net = simq_mod.FCN(cin, cout, precision=precision)
+def make_net(simq_mod, cin, cout, seed, training, precision='fp32', options=None):
+    net = simq_mod.FCN(cin, cout, precision=precision, options=options)
     net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, seed)))
     net.train(training)
     return net
@@ -738,28 +738,29 @@ def test_checkpoint_files_reference_ring_and_resume(simq_mod, tmp_path, golden_d
 
 
 def test_winograd_layers_equal_direct_convolution_network(simq_mod):
-    """The fp32 plan runs its 256/512-channel 3x3 layers as Winograd F(2x2,3x3) (conv_winograd.hip).  A plan created with
-    the path switched off (simq_tune_winograd(0): every layer on the implicit-GEMM kernel) gives the same Q-maps, batch
-    statistics, loss and gradients to fp32 round-off."""
-    from simq import _lib
+    """The fp32 plan runs its 128- to 512-channel 3x3 layers in Winograd form (conv_winograd.hip).  A plan created with
+    simq_plan_options.winograd = 0 (every layer on the implicit-GEMM kernel) gives the same Q-maps, batch statistics, loss and
+    gradients to fp32 round-off; the options a plan was created with are reported back by simq_plan_get_options."""
     import simq.learner as sl
     cin, cout, B = 4, 2, 6
     batch = cases.make_batch(cin, cout, B, 321)
     res = []
-    try:
-        for on in (1, 0):
-            _lib.lib.call('simq_tune_winograd', on)
-            policy, target = make_net(simq_mod, cin, cout, 81, True), make_net(simq_mod, cin, cout, 82, False)
-            info = sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
-                                 use_double_dqn=True)
-            res.append((info, policy._last['q'].clone(), policy._last['y'].clone(), policy.flat_grads.clone(), policy.bn_buffers.clone()))
-    finally:
-        _lib.lib.call('simq_tune_winograd', 1)
+    for on in (1, 0):
+        opts = {'winograd': on}
+        policy, target = make_net(simq_mod, cin, cout, 81, True, options=opts), make_net(simq_mod, cin, cout, 82, False, options=opts)
+        assert policy.plan.options['winograd'] == on and policy.plan.options['winograd_f4_grad'] == 2
+        info = sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                             use_double_dqn=True)
+        res.append((info, policy._last['q'].clone(), policy._last['y'].clone(), policy.flat_grads.clone(), policy.bn_buffers.clone()))
     (ia, qa, ya, ga, ba), (ib, qb, yb, gb, bb) = res
     assert rel(qa, qb) < 1e-5 and rel(ya, yb) < 1e-5 and rel(ba, bb) < 1e-5
     assert abs(ia['loss'] - ib['loss']) <= 1e-5 * abs(ib['loss'])
     # gradient conditioning, see this file's header (both forms are judged against the fp64 oracle elsewhere)
     assert float((ga - gb).double().norm() / gb.double().norm()) < 2e-2
+    with pytest.raises(Exception):
+        simq_mod.FCN(cin, cout, options={'no_such_option': 1})
+    with pytest.raises(Exception):
+        simq_mod.FCN(cin, cout, options={'winograd_f4_grad': 7})
 
 
 def test_replay_push_stages_through_pinned_memory(simq_mod):
@@ -791,43 +792,24 @@ def test_replay_push_stages_through_pinned_memory(simq_mod):
             assert np.array_equal(np.asarray(rec.state), kept[i][0]) and np.array_equal(np.asarray(rec.next_state), kept[i][1])
 
 
-_BF16_VARIANT_CHILD = r"""
-import os, sys
-sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'spatial-intention-maps_amd')]
-import numpy as np, torch
-import simq
-from oracle import cases, fcn as ofcn, learner as olearner
-from simq import synth
-cin, cout, B = 4, 2, 8
-policy, target = simq.FCN(cin, cout, precision='bf16'), simq.FCN(cin, cout, precision='bf16')
-policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 3))); policy.train(True)
-target.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 1003))); target.train(False)
-opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
-info = simq.train(cases.make_cfg(B), policy, target, opt, cases.make_batch(cin, cout, B, 11), olearner.apply_transform, cases.GAMMA)
-np.savez(sys.argv[1], grads=policy.flat_grads.detach().cpu().numpy(), loss=np.float64(info['loss']))
-"""
-
-
-def test_bf16_backward_agrees_across_its_storage_switches(tmp_path):
+def test_bf16_backward_agrees_across_its_storage_switches(simq_mod):
     """Plain-bf16 plans keep the activation gradients between the residual blocks' kernels in bf16, consume ReLU masks / residuals as
     bf16 planes and fuse the BatchNorm-backward sums into the dgrad epilogues (plan.hip: Ctx::gbf, planes_only, fuse_block_out).  Each
-    has a diagnostics switch that falls back to the generic kernels (fp32 gradients: SIMQ_FP32_ACT_GRADS, fp32 activation copies:
-    SIMQ_KEEP_FP32_ACT, separate reduction launches: SIMQ_NO_BNR_FUSE; read once per process, hence child processes).  One seeded
-    train step in every combination that changes the kernels taken; variants that share a forward must give the same loss and
-    gradients that differ only by where a gradient is rounded."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / 'child.py'
-    script.write_text(_BF16_VARIANT_CHILD % {'root': root})
-    variants = {'default': {}, 'fp32_grads': {'SIMQ_FP32_ACT_GRADS': '1'}, 'fp32_act': {'SIMQ_KEEP_FP32_ACT': '1'},
-                'no_fuse': {'SIMQ_NO_BNR_FUSE': '1'}, 'fp32_both': {'SIMQ_FP32_ACT_GRADS': '1', 'SIMQ_KEEP_FP32_ACT': '1'}}
+    is a simq_plan_options field whose other setting falls back to the generic kernels (bf16_act_grads = 0: fp32 gradients,
+    keep_fp32_activations = 1: fp32 activation copies, fuse_bn_backward_sums = 0: separate reduction launches).  One seeded train step
+    in every combination that changes the kernels taken; variants that share a forward must give the same loss and gradients that
+    differ only by where a gradient is rounded."""
+    cin, cout, B = 4, 2, 8
+    variants = {'default': {}, 'fp32_grads': {'bf16_act_grads': 0}, 'fp32_act': {'keep_fp32_activations': 1},
+                'no_fuse': {'fuse_bn_backward_sums': 0}, 'fp32_both': {'bf16_act_grads': 0, 'keep_fp32_activations': 1}}
     out = {}
-    for name, env in variants.items():
-        path = str(tmp_path / (name + '.npz'))
-        r = subprocess.run([sys.executable, str(script), path], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                           text=True, timeout=900)
-        assert r.returncode == 0, (name, r.stdout[-3000:])
-        out[name] = np.load(path)
+    for name, opts in variants.items():
+        policy = make_net(simq_mod, cin, cout, 3, True, precision='bf16', options=opts)
+        target = make_net(simq_mod, cin, cout, 1003, False, precision='bf16', options=opts)
+        opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+        info = simq_mod.train(cases.make_cfg(B), policy, target, opt, cases.make_batch(cin, cout, B, 11), olearner.apply_transform, cases.GAMMA)
+        out[name] = {'grads': policy.flat_grads.detach().cpu().numpy(), 'loss': np.float64(info['loss'])}
+        del policy, target, opt
     rel = lambda a, b: float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
     G = {k: v['grads'].astype(np.float64) for k, v in out.items()}
     L = {k: float(v['loss']) for k, v in out.items()}

@@ -285,6 +285,31 @@ def test_conv_bf16_matrix_core_paths(L, case, nplanes, tol_fwd):
     L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(xd), L.ptr(dyd), L.ptr(dwd), B, H, H, Cin, Cout, k, k, 1, pad, nplanes,
                L.ptr(scratch), st)
     assert rel(dwd, wd64.grad.permute(0, 2, 3, 1)) < tol_fwd
+    if nplanes == 1:
+        # tight form of the bf16 bar: fp64 on the bf16-ROUNDED operands -- the products of bf16 values are exact in fp32, so only the
+        # accumulation order is the kernel's own and 2e-5 holds; a dropped tap / K-tile / pixel row fails it by orders of magnitude
+        xr, wr, dyr = x.bfloat16().double(), w.bfloat16().double().requires_grad_(True), dy.bfloat16().double()
+        yr = F.conv2d(xr, wr, None if b is None else b.double(), padding=pad)
+        assert rel(yd, yr.detach().permute(0, 2, 3, 1)) < 2e-5
+        yr.backward(dyr)
+        assert rel(dwd, wr.grad.permute(0, 2, 3, 1)) < 2e-5
+
+
+@pytest.mark.parametrize('B,Cin,Cout', [(128, 128, 128), (128, 64, 64), (64, 64, 128)], ids=['layer2_b128', 'layer1_b128', 'l2a_b64'])
+def test_conv_bf16_register_staged_wgrad_at_config_batch_sizes(L, B, Cin, Cout):
+    """The register-staged bf16 weight-gradient kernel (conv_wgrad_bf16.hip: the 64- and 128-channel layers, which the 256x256
+    ping-pong tile does not cover) at BASELINE configs[2..4]'s per-GPU batch sizes, against fp64 on the bf16-rounded operands."""
+    H, k = 24, 3
+    g = torch.Generator().manual_seed(17 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    dy = torch.randn(B, H, H, Cout, generator=g).cuda()
+    scratch = torch.empty(2 * (x.numel() + dy.numel()) + 64, dtype=torch.int16, device='cuda')
+    d1 = torch.full((Cout, k, k, Cin), 7.0, device='cuda')
+    L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(x), L.ptr(dy), L.ptr(d1), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), L.stream_ptr())
+    xb, dyb = x.bfloat16().double(), dy.bfloat16().double()
+    ref = torch.nn.grad.conv2d_weight(xb.permute(0, 3, 1, 2), (Cout, Cin, k, k), dyb.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(d1).all()
+    assert rel(d1, ref) < 2e-5, rel(d1, ref)
 
 
 @pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256)),
@@ -351,8 +376,9 @@ def test_conv_bf16_wgrad_pingpong_matches_register_staged(L, B, Cin, Cout):
     assert rel(d1, ref) < 2e-5, rel(d1, ref)                                     # fp32 accumulation of exact bf16 products
 
 
-@pytest.mark.parametrize('B,H,Cin,Cout,k', [(16, 24, 128, 256, 3), (15, 24, 64, 128, 3), (16, 24, 256, 128, 1)],
-                         ids=['256tiles', 'ragged_rows', '1x1'])
+@pytest.mark.parametrize('B,H,Cin,Cout,k', [(16, 24, 128, 256, 3), (15, 24, 64, 128, 3), (16, 24, 256, 128, 1), (128, 24, 128, 128, 3),
+                                            (128, 24, 256, 512, 1)],
+                         ids=['256tiles', 'ragged_rows', '1x1', 'layer2_b128', 'downsample_1x1_b128'])
 def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k):
     """The large-tile LDS-DMA kernel (conv_igemm_bf16_dma.hip, 288x128 tile, 8 waves, staged vector epilogue) against
     the register-staged kernel on the same bf16 operands: identical K order (64-channel chunk outer, tap inner) and
@@ -382,6 +408,9 @@ def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k)
     # and both are bf16-class against an fp64 convolution of the same inputs
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
     assert rel(y_dma, ref) < 2e-2
+    # tight: fp64 on the bf16-rounded operands (exact products, only the accumulation order is the kernel's)
+    refr = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2), w.bfloat16().double().permute(0, 3, 1, 2), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+    assert rel(y_dma, refr) < 2e-5, rel(y_dma, refr)
 
 
 @pytest.mark.parametrize('B,H', [(29, 24), (39, 20)], ids=['112_tail_tiles', 'ragged_tail'])
@@ -561,13 +590,51 @@ def test_stem_wgrad_bf16_matches_a_bf16_operand_weight_gradient(L, B, C):
     assert err < 1e-4
 
 
-def test_f32_pingpong_gemm_serves_winograd_layers():
-    """gemm_f32_pp.hip (LDS-DMA ping-pong form of the batched transform-domain GEMM; off by default, SIMQ_F32_PP=2 routes every
-    eligible contraction through it -- the switch is read once per process, hence the child process): the Winograd forward / wgrad
-    tests of this file must hold with it, to their unchanged bars."""
+_F32PP_CHILD = r"""
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'spatial-intention-maps_amd')]
+import numpy as np, torch
+from simq import _lib as L
+assert L.lib.build_flags == 1, 'expected the ablation build'
+out = {}
+for f4, (B, Cin, Cout) in ((False, (8, 512, 512)), (True, (16, 256, 512))):
+    g = torch.Generator().manual_seed(5 + Cin)
+    x = torch.randn(B, 24, 24, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda()
+    y = torch.empty(B, 24, 24, Cout, device='cuda')
+    T, nb = (B * 36, 36) if f4 else (B * 144, 16)
+    scratch = torch.empty(nb * Cout * Cin + nb * T * (Cin + Cout) + 64, device='cuda')
+    L.lib.call('simq_conv2d_fwd_winograd4' if f4 else 'simq_conv2d_fwd_winograd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, 24, 24, Cin, Cout,
+               None, L.ptr(scratch), L.stream_ptr())
+    out['f4' if f4 else 'f2'] = y.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_f32_pingpong_gemm_serves_winograd_layers(L, tmp_path):
+    """gemm_f32_pp.hip (LDS-DMA ping-pong form of the batched transform-domain GEMM; measured step-neutral, so it is compiled into the
+    ablation build libsimq_ablate.so only, where SIMQ_F32_PP=2 routes every eligible contraction through it): a child process on that
+    build must reproduce the product library's Winograd convolutions BIT FOR BIT (v_mfma_f32_16x16x4_f32 is an exact FMA chain and
+    the K order per accumulator is the same).  Also pins the split itself: the product reports build flags 0 and ignores SIMQ_*."""
     import os, subprocess, sys
-    env = dict(os.environ, SIMQ_F32_PP='2')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k', 'winograd and not pingpong'],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    abl = os.path.join(root, 'spatial-intention-maps_amd', 'simq', 'libsimq_ablate.so')
+    assert L.lib.build_flags == 0
+    assert os.path.exists(abl), 'libsimq_ablate.so missing: __graft_entry__.build() / `make -C spatial-intention-maps_amd/csrc ablate` builds it'
+    script = tmp_path / 'child.py'
+    script.write_text(_F32PP_CHILD % {'root': root})
+    path = str(tmp_path / 'pp.npz')
+    r = subprocess.run([sys.executable, str(script), path], env=dict(os.environ, SIMQ_LIBRARY=abl, SIMQ_F32_PP='2'), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert ' passed' in r.stdout
+    got = np.load(path)
+    for f4, (B, Cin, Cout) in ((False, (8, 512, 512)), (True, (16, 256, 512))):
+        g = torch.Generator().manual_seed(5 + Cin)
+        x = torch.randn(B, 24, 24, Cin, generator=g).cuda()
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda()
+        y = torch.empty(B, 24, 24, Cout, device='cuda')
+        T, nb = (B * 36, 36) if f4 else (B * 144, 16)
+        scratch = torch.empty(nb * Cout * Cin + nb * T * (Cin + Cout) + 64, device='cuda')
+        L.lib.call('simq_conv2d_fwd_winograd4' if f4 else 'simq_conv2d_fwd_winograd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, 24, 24, Cin, Cout,
+                   None, L.ptr(scratch), L.stream_ptr())
+        assert np.array_equal(y.cpu().numpy(), got['f4' if f4 else 'f2'])
