@@ -322,6 +322,12 @@ int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w_ohwi, const float* d
                          void* stream);
 int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
                            int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream);
+/* the same with d_slab = simq_conv2d_wgrad_bf16_slab_bytes() of scratch: the image-tile weight-gradient kernel (3x3 on 24x24 maps, Cout %
+ * 256 == 0, Cin % 32 == 0, >= 2 images per block) then leaves per-block partial tiles there and a second launch adds them in a fixed
+ * order (deterministic) instead of fp32 atomics -- the form the plans use.  d_slab = NULL: as simq_conv2d_wgrad_bf16. */
+int64_t simq_conv2d_wgrad_bf16_slab_bytes(void);
+int simq_conv2d_wgrad_bf16_slab(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
+                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream);
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream);
 int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
 

@@ -108,11 +108,17 @@ int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
 int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,
                            const ConvEpilogue& e, hipStream_t stream);
+// slab: conv_wgrad_bf16_slab_bytes() of scratch for the image-tile kernel's partial tiles, or NULL (every kernel then adds into the
+// zeroed dw with fp32 atomics)
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
-                           hipStream_t stream);
+                           hipStream_t stream, float* slab = nullptr);
 // conv_wgrad_bf16_pp.hip: 256 x 256 tiles, LDS-DMA staging, ping-pong wave groups; 1 = took the launch, 0 = shape not covered
 int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, const ConvGeom& g, unsigned x_bytes, unsigned dy_bytes,
                            hipStream_t stream);
+// conv_wgrad_bf16_img.hip: image-tile form (all nine taps of a 256 x 32 tile from one halo patch in LDS); same return convention
+int try_conv_wgrad_bf16_img(const uint16_t* x, const uint16_t* dy, float* dw, const ConvGeom& g, unsigned x_bytes, unsigned dy_bytes,
+                           hipStream_t stream, float* slab = nullptr);
+int64_t conv_wgrad_bf16_slab_bytes();     // scratch the image-tile kernel needs for its partial tiles (any batch)
 // every convolution's weight transforms in one launch (see split_planes.hip)
 struct WeightPrepDesc { int64_t w_off, wt_off, wp_off; int cout, taps, cin, pad_; };
 struct WeightPrepTable { WeightPrepDesc d[24]; int n; };

@@ -282,7 +282,7 @@ int dispatch(const WgradBfArgs& a, hipStream_t stream) {
 }  // namespace
 
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
-                           hipStream_t stream) {
+                           hipStream_t stream, float* slab) {
     WgradBfArgs a;
     a.x[0] = x[0]; a.x[1] = nplanes == 2 ? x[1] : x[0];
     a.dy[0] = dy[0]; a.dy[1] = nplanes == 2 ? dy[1] : dy[0];
@@ -297,7 +297,9 @@ int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
     SIMQ_REQUIRE(nplanes == 1 || nplanes == 2, "conv_wgrad_bf16: nplanes must be 1 or 2");
     if (nplanes == 1) {                                  // wide 3x3 layers: 256 x 256 ping-pong tiles (conv_wgrad_bf16_pp.hip)
-        const int took = try_conv_wgrad_bf16_pp(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream);
+        int took = try_conv_wgrad_bf16_img(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream, slab);      // image tile: all nine taps per block
+        if (took != 0) return took < 0 ? took : 0;
+        took = try_conv_wgrad_bf16_pp(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream);
         if (took != 0) return took < 0 ? took : 0;
     }
     return nplanes == 2 ? dispatch<2>(a, stream) : dispatch<1>(a, stream);

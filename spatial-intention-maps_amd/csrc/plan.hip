@@ -152,6 +152,7 @@ struct Layout {
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
     int64_t p_pooled, p_up1, DP[2];
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
+    int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
     int64_t total;
 };
 
@@ -194,6 +195,7 @@ Layout make_layout(const simq_plan* p, int B) {
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
+    L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.total = off;
     return L;
@@ -533,7 +535,7 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
     if (c.mc() && cv.wp_off >= 0) {
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
-        return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream);
+        return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream, c.L.wslab >= 0 ? c.f(c.L.wslab) : nullptr);
     }
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && c.p->opt.winograd_wgrad &&
         winograd_wgrad_pays(g, c.p->opt.winograd_wgrad_f4 != 0))
@@ -1237,8 +1239,15 @@ int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w, const float* d_bias
     return launch_conv_igemm_bf16(xp, wp, nplanes, d_y, g, e, st);
 }
 
+int64_t simq_conv2d_wgrad_bf16_slab_bytes(void) { return conv_wgrad_bf16_slab_bytes(); }
+
 int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
                            int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream) {
+    return simq_conv2d_wgrad_bf16_slab(d_x, d_dy, d_dw, batch, hin, win, cin, cout, r, s, stride, pad, nplanes, d_scratch, nullptr, stream);
+}
+
+int simq_conv2d_wgrad_bf16_slab(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
+                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvGeom g;
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
@@ -1250,7 +1259,7 @@ int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw, int
     RC(launch_split_planes(d_x, xp[0], nplanes == 2 ? xp[1] : nullptr, nx, st));
     RC(launch_split_planes(d_dy, yp[0], nplanes == 2 ? yp[1] : nullptr, ny, st));
     SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
-    return launch_conv_wgrad_bf16(xp, yp, nplanes, d_dw, g, st);
+    return launch_conv_wgrad_bf16(xp, yp, nplanes, d_dw, g, st, static_cast<float*>(d_slab));
 }
 
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream) {

@@ -109,6 +109,8 @@ _SIGS = {
     'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'simq_conv2d_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_wgrad_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p]),
+    'simq_conv2d_wgrad_bf16_slab_bytes': (c_int64, []),
+    'simq_conv2d_wgrad_bf16_slab': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p]),
     'simq_upsample2x_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_profile_start': (c_int, []),

@@ -374,6 +374,14 @@ def test_conv_bf16_wgrad_pingpong_matches_register_staged(L, B, Cin, Cout):
     ref = torch.nn.grad.conv2d_weight(xb.permute(0, 3, 1, 2), (Cout, Cin, k, k), dyb.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     assert torch.isfinite(d1).all()
     assert rel(d1, ref) < 2e-5, rel(d1, ref)                                     # fp32 accumulation of exact bf16 products
+    # the form the plans use: per-block partial tiles in a slab + a fixed-order reduction launch (image-tile kernel) -- deterministic
+    slab = torch.empty(L._c.simq_conv2d_wgrad_bf16_slab_bytes() // 4, device='cuda')
+    d2, d3 = torch.full_like(d1, 7.0), torch.full_like(d1, -3.0)
+    for d in (d2, d3):
+        slab.fill_(float('nan'))
+        L.lib.call('simq_conv2d_wgrad_bf16_slab', L.ptr(x), L.ptr(dy), L.ptr(d), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), L.ptr(slab), st)
+    assert rel(d2, ref) < 2e-5, rel(d2, ref)
+    assert torch.equal(d2, d3)
 
 
 @pytest.mark.parametrize('B,H,Cin,Cout,k', [(16, 24, 128, 256, 3), (15, 24, 64, 128, 3), (16, 24, 256, 128, 1), (128, 24, 128, 128, 3),

@@ -14,7 +14,8 @@ Bars:
          reference's own fp32 makes on the same elements (measured 1.2 x, 2.4 x, 2.1 x: 2.6e-3 / 2.9e-3 / 5.0e-3 against the reference's
          2.2e-3 / 1.2e-3 / 2.4e-3 -- single batches; the distribution over 13 batches is tests/test_gpu_fcn.py's gradient study);
          gradient norm 1e-3 (measured 1e-5 .. 5e-5); the second step's loss against fp64: within twice the amplification of the update
-         error the reference's own fp32 shows on these fixtures; post-second-step parameter norms and BatchNorm buffers 1e-4.
+         error the reference's own fp32 shows on these fixtures; post-second-step parameter norms 1e-4; BatchNorm buffers 1e-4 after step 1
+         (against fp64), 5e-3 after step 2 (they have seen the first update).
   bf16   against fp64, calibrated by the reference under bf16 autocast AT THIS SIZE (the fixture's bf16cal_* fields): loss, td error,
          q_sa <= 2 x calibration (measured 0.8 x, 0.9 x, 0.7-1.2 x).  The TD-loss gradient is NOT a usable yardstick for bf16 at any batch
          size: the reference's own autocast gradient is 0.44-0.49 off the fp64 gradient at B = 64-128 (double-DQN greedy actions flip --
@@ -93,6 +94,9 @@ def run_two_steps(simq_mod, case, precision, profile=False):
     grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
     p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
     q_sa, y = policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy()
+    bnvec = lambda sd_: np.concatenate([sd_[k].detach().double().cpu().numpy().ravel() for k in sd_
+                                        if k.endswith('running_mean') or k.endswith('running_var')])
+    bn1 = bnvec(policy.state_dict())
     info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
     gs, ds = [], []
     for t, a, b in zip(grads, p0, p1):
@@ -101,9 +105,9 @@ def run_two_steps(simq_mod, case, precision, profile=False):
         ds.append((b - a).reshape(-1)[idx].numpy())
     sd = policy.state_dict()
     p2 = [sd[k].detach().double().cpu() for k, _, kind in ofcn.state_spec(cin, cout) if ofcn.is_parameter(kind)]   # (incl. the unused fc)
-    bn = np.concatenate([sd[k].detach().double().cpu().numpy().ravel() for k in sd if k.endswith('running_mean') or k.endswith('running_var')])
+    bn = bnvec(sd)
     return dict(info=[info1, info2], total_norm=tn, grad=np.stack(gs), dparam=np.stack(ds), gnorm=np.array([float(t.norm()) for t in grads]),
-                q_sa=q_sa, y=y, p2_l2=np.array([float(t.norm()) for t in p2]), bn=bn, kinds=kinds,
+                q_sa=q_sa, y=y, p2_l2=np.array([float(t.norm()) for t in p2]), bn=bn, bn1=bn1, kinds=kinds,
                 nbt=[int(sd[k]) for k in sd if k.endswith('num_batches_tracked')])
 
 
@@ -133,7 +137,10 @@ def test_fp32_step_at_config_size_matches_the_reference(simq_mod, golden_dir, ca
                   for h in (np.load('%s/%s.npz' % (golden_dir, c[0])) for c in cases.TRAIN_CASES_SIZED))
     assert e['loss2'] <= 2.0 * amp_ref * e['dparam'] + 1e-4, (e['loss2'], amp_ref, e['dparam'])
     assert relmax(r['p2_l2'], g['param_summary_after2'][:, 1]) < 1e-4
-    assert relmax(r['bn'], g['bn_buffers_after2']) < 1e-4
+    # running statistics: after the FIRST step (two train-mode forwards of the unmodified parameters) 1e-4 against fp64; after the
+    # second they have seen the first update, whose fp32 error differs between implementations (the reference's included)
+    assert relmax(r['bn1'], g['bn_buffers_after1_64']) < 1e-4
+    assert relmax(r['bn'], g['bn_buffers_after2']) < 5e-3
     assert r['nbt'] == [int(v) for v in g['num_batches_tracked']]
 
 
