@@ -73,6 +73,28 @@ struct WgradImgArgs {
     int dbg;                 // run-time ablation bits (ablation build): 32 no atomics, 64 no main loop
 };
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) -- the body sees its index as a
+// constant expression (immediate operands of inline assembly need one)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Transpose read through inline assembly (address = LDS byte address + immediate): seen as an ordinary LDS load, the compiler orders
+// it behind EVERY LDS-DMA in flight (s_waitcnt vmcnt(0) in front of each step's reads -- it cannot know that the pieces in flight
+// target other stages), which drains the prefetch pipeline once per step.  The ordering is the kernel's own: counted vmcnt + s_barrier
+// before a stage is read, lgkmcnt(0) + sched_barrier before the fragments are used.
+template <int IMM>
+__device__ __forceinline__ short4_ tr_read(int addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset field");
+    short4_ v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -137,25 +159,17 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_bf16_img_kernel(const WgradI
         table[sl] = ok ? (uint16_t)(((((qy - 1) * HW + (qx - 1)) * p.Cin + ci0 + plane * 16 + (lane & 1) * 8) * 2) >> 4) : (uint16_t)0xFFFF;
     }
     const unsigned img_x = (unsigned)(HW * HW * p.Cin * 2);
-    auto issue_patch = [&](int s, int img, int buf) {    // s: slot; img: image whose patch is fetched (block-uniform)
+    // table entry of (this lane, slot s) -> buffer offset of the piece in image `img` (0xFFFFFFFF: zero-fill) and its DMA
+    auto issue_patch_entry = [&](unsigned e, int s, int img, int buf) {    // img: image whose patch is fetched (block-uniform)
         const int q = s * NW + wave;
         const bool real = q < 2 * PPIECES && img < img1;
         char* dst = smem + (real ? OFF_PATCH + buf * PATCH + q * 1024 : OFF_DUMMY);
-        // (volatile LDS read: re-read per use -- as loop invariants the six values would be hoisted back into registers)
-        // The table address is recomputed from the lane id behind an opaque zero at every use: as a loop invariant it (and the six
-        // slot addresses derived from it) would be hoisted into registers this kernel does not have -- a spilled one comes back
-        // through a scratch load whose s_waitcnt vmcnt(0) drains the whole DMA pipeline.
-        int z;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-        const int l_now = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
-        const unsigned e = *(const volatile __attribute__((address_space(3))) uint16_t*)(smem + OFF_TABLE + (wave * 64 + l_now) * (XSLOTS * 2) + s * 2);
         const unsigned voff = (real && e != 0xFFFFu) ? (e << 4) + (unsigned)img * img_x : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)dst, 16, voff, 0, 0, 0);
     };
-    auto issue_idle = [&]() {                            // keeps the per-step load count constant (zero-fill, no traffic)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(smem + OFF_DUMMY), 16, 0xFFFFFFFFu, 0, 0, 0);
+    auto issue_patch = [&](int s, int img, int buf) {    // prologue form: an ordinary (compiler-visible) table read
+        issue_patch_entry(table[s], s, img, buf);
     };
-
     // ---- fragments.  Lane (t = lane & 15, g = lane >> 4); transpose read h (0, 1) covers step pixels 16 h + 4 g + (t >> 2) [rows] and
     // channels 4 (t & 3) .. + 3 of a 16-channel chunk; the lane receives 4 consecutive pixels of channel t.
     const int ft = lane & 15, fg = lane >> 4;
@@ -163,26 +177,34 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_bf16_img_kernel(const WgradI
     // chunk wi * 4 + a = (wi * 4) ^ a, so the swizzled position of chunk a is this offset XOR (a << 5) -- one register instead of eight
     const int a_r = 4 * fg + (ft >> 2);
     const int a_off0 = a_r * ROWB + (((wi * NA) ^ (a_r & 7)) << 5) + ((ft & 3) << 3);
-    // X: byte offset of tap (0, 0) inside a patch buffer; image pixel (y, x) of tap (ky, kx) is patch pixel (y + ky, x + kx)
-    int xoff[2], py[2], px[2];
+    // X.  Image pixel (y, x) under tap (ky, kx) is patch pixel (y + ky, x + kx); the patch index of image pixel p is p + 2 (p / 24).  A
+    // lane reads pixel p = c + 32 s at step s (c = 16 h + 4 g + (t >> 2) = 24 yc + xc), and p / 24 = yc + s + s / 3 + [xc >= 24 - 8 (s % 3)]:
+    // everything but the bracket is the same for all lanes -- it goes into the IMMEDIATE offset of the read -- and the bracket is one of
+    // three per-lane constants.  So: three base registers per read (s % 3 = 0, 1, 2), no address arithmetic in the loop.
+    const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);     // LDS byte address of smem[0]
+    // The slot-s table entry is read at the START of a load segment, in front of the 26 transpose reads (LDS returns in order: once at
+    // most 15 LDS operations are outstanding the entry has arrived), so that the patch DMA does not queue behind the fragment traffic.
+    // The address is re-derived from the lane id behind an opaque zero at every use: as a loop invariant it would cost a register.
+    auto table_addr = [&]() -> int {
+        int z;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        const int l_now = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+        return lds0 + OFF_TABLE + (wave * 64 + l_now) * (XSLOTS * 2);
+    };
+    int xb[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int pix = 16 * h + 4 * fg + (ft >> 2);     // 0 .. 31: image row 0, or the first 8 pixels of row 1
-        py[h] = pix / HW; px[h] = pix - py[h] * HW;
-        xoff[h] = wj * PLANE + (py[h] * PW + px[h]) * 32 + ((ft & 3) << 3);
+        const int c = 16 * h + 4 * fg + (ft >> 2);
+        const int yc = c / HW, xc = c - yc * HW;
+        const int b0 = lds0 + OFF_PATCH + wj * PLANE + (c + 2 * yc) * 32 + ((ft & 3) << 3);
+        xb[h][0] = b0;
+        xb[h][1] = b0 + (xc >= 16 ? 64 : 0);
+        xb[h][2] = b0 + (xc >= 8 ? 64 : 0);
     }
-    auto advance_x = [&]() {                             // next step: + 32 pixels = + 1 image row + 8 columns; wraps at the image end
+    // dY: the four chunk positions of read h = 0 in stage 0 (stage and h are immediates)
+    int ao[NA];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            px[h] += 8; py[h] += 1;
-            if (px[h] >= HW) { px[h] -= HW; py[h] += 1; }
-            if (py[h] >= HW) py[h] -= HW;
-            xoff[h] = wj * PLANE + (py[h] * PW + px[h]) * 32 + ((ft & 3) << 3);
-        }
-    };
-    auto tr = [&](const char* base, int off) -> short4_ {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_ __attribute__((address_space(3)))*)(base + off));
-    };
+    for (int a = 0; a < NA; ++a) ao[a] = lds0 + (a_off0 ^ (a << 5));
     auto join = [&](short4_ lo, short4_ hi) -> bf16x8 {
         short8_ v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
@@ -205,44 +227,66 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_bf16_img_kernel(const WgradI
     __builtin_amdgcn_s_barrier();
     if (wj == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0 from here on
 
-    int stage = 0;
-    for (int im = 0; im < ((p.dbg & 64) ? 0 : nimg); ++im) {
-        const char* patch = smem + OFF_PATCH + (im & 1) * PATCH;
+    // Two images per trip: 18 steps per image and a 4-stage ring make the dY stage (s + 2 (image & 1)) & 3 and the patch buffer image & 1
+    // compile-time inside the unrolled body, so every LDS address below is a base register + an immediate.
+    const int nloop = (p.dbg & 64) ? 0 : nimg;
+    for (int im2 = 0; im2 < nloop; im2 += 2) {
+        static_for<2>([&](auto HALF) {
+            constexpr int half = decltype(HALF)::value;
+            const int im = im2 + half;
+            if (im < nloop) {                                            // (block-uniform)
+                static_for<STEPS>([&](auto S) {
+                    constexpr int s = decltype(S)::value;
+                    constexpr int stage = (s + 2 * half) & (NBUF - 1);
+                    constexpr int simm = (32 * s + 2 * (s + s / 3)) * 32;     // patch offset of the step (see xb)
+                    const bool live = !(DBG & 8) || (im == 0 && s == 0);
+                    // ---------------- load segment ----------------
+                    constexpr bool patch_step = s >= 1 && s <= XSLOTS && !(DBG & 1);
+                    unsigned entry = 0;
+                    if constexpr (patch_step)
+                        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(entry) : "v"(table_addr()), "n"((s - 1) * 2) : "memory");
+                    static_for<9>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        constexpr int imm = ((t / 3) * PW + (t % 3)) * 32 + simm;
+                        if (live) bf[t] = join(tr_read<imm>(xb[0][s % 3]), tr_read<imm>(xb[1][s % 3]));
+                    });
+                    static_for<NA>([&](auto A) {
+                        constexpr int a = decltype(A)::value;
+                        if (live) af[a] = join(tr_read<stage * STAGE>(ao[a]), tr_read<stage * STAGE + 16 * ROWB>(ao[a]));
+                    });
+                    if (!(DBG & 1)) {
+                        issue_dy((stage + NBUF - 1) & (NBUF - 1));      // dY of step + 3 into the stage step - 1 used
+                        if constexpr (patch_step) {              // next image's patch, one piece per step
+                            asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(entry) :: "memory");
+                            issue_patch_entry(entry, s - 1, img0 + im + 1, (half + 1) & 1);
+                        }
+                    }
+                    // counted wait: everything issued two steps ago or earlier has landed = at most the loads of this step and of the
+                    // one before may be outstanding (2 dY pieces per step, + 1 patch piece in steps 1 .. XSLOTS)
+                    constexpr int sp = (s + STEPS - 1) % STEPS;
+                    constexpr int outstanding = 4 + ((s >= 1 && s <= XSLOTS) ? 1 : 0) + ((sp >= 1 && sp <= XSLOTS) ? 1 : 0);
+                    wait_vmcnt<(DBG & 1) ? 0 : outstanding>();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    // ---------------- MFMA segment ----------------
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            // ---------------- load segment ----------------
+                    for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = ((t / 3) * PW + (t % 3)) * 32;
-                if (!(DBG & 8) || (im == 0 && s == 0)) bf[t] = join(tr(patch, xoff[0] + toff), tr(patch, xoff[1] + toff));
+                        for (int a = 0; a < NA; ++a)
+                            if (!(DBG & 16) || (im == 0 && s == 0)) acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[t], acc[t][a], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                });
+                // the next image reads the other patch buffer
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) xb[h][k] += half == 0 ? PATCH : -PATCH;
             }
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const int o = (stage * STAGE + a_off0) ^ (a << 5);       // (stage bases are multiples of 16 KB: the XOR stays inside the row)
-                if (!(DBG & 8) || (im == 0 && s == 0)) af[a] = join(tr(smem, o), tr(smem, o + 16 * ROWB));
-            }
-            if (!(DBG & 1)) {
-            issue_dy((stage + NBUF - 1) & (NBUF - 1));                  // dY of step + 3 into the stage step - 1 used
-            if (s >= 1 && s <= XSLOTS) issue_patch(s - 1, img0 + im + 1, (im + 1) & 1);   // next image's patch, one piece per step
-            else issue_idle();
-            }
-            advance_x();
-            stage = (stage + 1) & (NBUF - 1);
-            wait_vmcnt<(NBUF - 2) * 3>();                                // everything issued two steps ago or earlier has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---------------- MFMA segment ----------------
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    if (!(DBG & 16) || (im == 0 && s == 0)) acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[t], acc[t][a], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
+        });
     }
     if (wj == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
     wait_vmcnt<0>();
