@@ -6,18 +6,18 @@
 // (tools/pp_check.py ablations): with the wave groups running one barrier apart the MFMA / fragment-read /
 // DMA-issue streams overlap, and what is left is the VOLUME staged through L2 -> LDS: an implicit GEMM re-stages every input
 // pixel once per filter tap (9 x), 2.6 GB per layer4 launch at B = 128.  Here, per 32-channel chunk,
-//   * the 26 x 26 halo patch of the image (zero border written by the DMA's range check) is staged ONCE -- 43 KB -- and the
-//     nine taps read their 16-pixel fragments from it at shifted positions: the pixel dimension of the patch is laid out
-//     16 pixels x 16 B per 256-B line ("chunk-major" pieces), so ANY run of 16 consecutive patch pixels covers all 64 banks:
-//     conflict-free ds_read_b128 at every tap shift without a swizzle;
+//   * the 26 x 26 halo patch of the image (zero border written by the DMA's range check) is staged ONCE -- 43 KB of pixels in a 52-KB
+//     buffer -- and the nine taps read their 16-pixel fragments from it at shifted positions (ky: an immediate, kx: one of three base
+//     registers); the layout is row-major with an XOR slot swizzle (see the stager): 64-byte DMA requests AND conflict-free ds_read_b128
+//     at every tap shift;
 //   * only the weights are staged per tap: 128 rows x 64 B = 8 KB per K-tile, exactly one 1-KB DMA piece per wave;
 //   -> 12.8 KB staged per K-tile and block instead of 34 KB (per flop: 0.37 x), and a whole image per block halves the number
 //      of times the weights are re-read.
 //   * 8 waves as 4 x 2 (wave tile 144 x 64, 9 x 4 MFMA tiles = 144 accumulator registers), wave groups {0-3} / {4-7} one barrier
 //     apart as in conv_igemm_bf16_pp.hip: load segment (13 fragment reads, this wave's DMA pieces, counted vmcnt, lgkmcnt(0)) |
 //     s_barrier | MFMA segment (36 x v_mfma_f32_16x16x32_bf16 under s_setprio 1) | s_barrier.
-//   * LDS: two patch buffers of 43 KB (the next chunk's patch is DMA-ed during taps 0..5 of the current one) + a 4-stage ring of
-//     8-KB weight tiles (K-tile t + 3 is DMA-ed during K-tile t).  Ordering of LDS-DMA data: every wave waits for ITS pieces
+//   * LDS: two patch buffers of 52 KB (the next chunk's patch is DMA-ed during taps 0..6 of the current one, one 1-KB piece per wave and
+//     tap) + a 4-stage ring of 8-KB weight tiles (K-tile t + 3 is DMA-ed during K-tile t).  Ordering of LDS-DMA data: every wave waits for ITS pieces
 //     with a counted vmcnt in front of a barrier, and the first read happens behind at least one more barrier.
 #include <cstdlib>
 #include <type_traits>
@@ -38,23 +38,23 @@ constexpr int WTM = BM / WM, WTN = BN / WN;              // 144 x 64
 constexpr int TM = WTM / 16, TN = WTN / 16;              // 9 x 4 MFMA tiles per wave
 constexpr int BK = 32;                                   // K-tile = (32 channels, one tap) = one MFMA k-step
 constexpr int TAPS = 9;
-constexpr int PATCH_PX = PW * PW;                        // 676 patch pixels
-constexpr int A_GROUPS = (PATCH_PX + 15) / 16;           // 43 groups of 16 patch pixels
-constexpr int PLANE = A_GROUPS * 256;                    // one 16-B channel chunk of every patch pixel: 11 008 B (a multiple of 256)
-constexpr int A_BYTES = 4 * PLANE;                       // 44 032 B per patch buffer: [chunk 0..3][pixel][16 B]
-constexpr int NA = (A_GROUPS + NW - 1) / NW;             // <= 6 pixel groups per wave
-constexpr int NPD = 4 * NA;                              // <= 24 patch DMA instructions (256 B each) per wave and channel chunk
+
+constexpr int PPITCH = 32;                               // patch rows are stored 32 pixels apart (26 used): a row = two 1-KB DMA pieces
+constexpr int PROW = PPITCH * 64;                        // 2 048 B per patch row: [pixel][4 slots of 16 B = 32 channels]
+constexpr int A_BYTES = PW * PROW;                       // 53 248 B per patch buffer
+constexpr int PPIECES = 2 * PW;                          // 52 DMA pieces (16 pixels x 64 B) per 32-channel chunk
+constexpr int XSLOTS = (PPIECES + NW - 1) / NW;          // patch pieces per wave and channel chunk (7: pieces q = slot * 8 + wave < 52)
 constexpr int B_STAGES = 4;
 constexpr int B_BYTES = BN * 64;                         // 8 192 B per weight tile: one 1-KB piece per wave
 constexpr int B_BASE = 2 * A_BYTES;
-constexpr int SMEM_LOOP = B_BASE + B_STAGES * B_BYTES;   // 120 832 B
+constexpr int OFF_DUMMY = B_BASE + B_STAGES * B_BYTES;   // 1 KB the zero-fill DMAs of empty slots land in
+constexpr int SMEM_LOOP = OFF_DUMMY + 1024;              // 140 288 B
 constexpr int SMEM_EPI = staged_epilogue_smem<BN, TN, WM, NW, 3>();
 constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
 
 static_assert(BN / 16 == NW, "one weight piece per wave and K-tile");
-static_assert(NA <= TAPS - 2, "the next chunk's patch is issued during the first taps and waited for before the chunk ends");
+static_assert(XSLOTS <= TAPS - 2, "the next chunk's patch is issued during taps 0 .. XSLOTS - 1: the last piece two K-tiles before the chunk ends");
 static_assert(SMEM <= 160 * 1024, "LDS budget");
-static_assert(PLANE % 256 == 0, "planes start on a bank-0 boundary: 16 consecutive pixels of a plane cover all 64 banks");
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -62,8 +62,32 @@ __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// 16-byte fragment read through inline assembly (LDS byte address + immediate).  As an ordinary load the compiler would order it
+// behind every LDS-DMA in flight once the taps are unrolled (s_waitcnt vmcnt(0) per K-tile: it cannot know that the pieces in flight
+// target other stages); the ordering is the kernel's own -- counted vmcnt + s_barrier before a stage is read, lgkmcnt(0) +
+// sched_barrier before the fragments are used.
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_read16(int addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset field");
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+    return v;
+}
+
+// DBG (timing ablations, libsimq_ablate.so only; results are wrong by construction): 1 no DMA, 2 no barriers, 8 no fragment reads,
+// 16 no MFMAs, 32 epilogue only, 64 DMA issued with every lane out of range, 128 no s_setprio, 256 / 512 no patch / weight pieces
 template <int DBG = 0>
-__global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_img_kernel(const IgemmBfArgs p) {
+__global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmBfArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,39 +97,46 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_img_kernel(const IgemmB
     if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
     const int img = tile / p.tilesN, tile_n = tile % p.tilesN;
     const int m0 = img * BM, n0 = tile_n * BN;
+    const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);     // LDS byte address of smem[0]
 
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x[0]), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w[0]), 0, p.w_bytes, 0x00020000);
 
-    // ---- patch stager.  The patch lives in LDS as four planes [16-B channel chunk][patch pixel][16 B]: a fragment's 16 pixels
-    // are 256 contiguous bytes and its address is AFFINE in the pixel index, so the nine taps differ by an immediate offset.
-    // One DMA instruction (dword per lane) moves 16 pixels of one chunk: lane l carries word (l & 3) of pixel 16 g + (l >> 2);
-    // the DMA writes lane-linearly (dst + 4 l), which is exactly pixel-major within the plane.  Wave w owns pixel groups
-    // g = i * NW + w.  Border / padding pixels: byte offset 0xFFFFFFFF (the range check makes the DMA write zeros).
-    unsigned abase[NA];
+    // ---- patch stager.  The patch lives in LDS row-major, [patch row (pitch 32 pixels)][pixel][4 slots x 16 B]: the 64 bytes of a
+    // pixel's 32 channels stay together, so the four lanes of a quad fetch ONE 64-byte run -- a quarter of the L2 requests of a
+    // chunk-planar layout, where every 16-byte piece of a pixel travels in a different instruction (measured: with the DMA issued but
+    // masked the kernel runs 192 us, with the traffic 257 us, and the L2 request rate -- not its bandwidth -- is what that costs).
+    // Pixels 64 B apart collide in LDS banks every four pixels; slot s of the pixel in patch column x therefore holds channel chunk
+    // s ^ (3 * ((x >> 2) & 1)): within every 16-lane group a ds_read_b128 serves together, lanes with equal x & 3 sit 4, 8, 12 columns
+    // apart and land in four different slots -- conflict-free at every tap shift and across image-row wraps (24 = 0 mod 8).
+    // One DMA piece (16 B per lane) = 16 pixels x 64 B = 1 KB = half a patch row; piece q = slot * 8 + wave (q < 52): row q / 2,
+    // columns (q & 1) * 16 + (lane >> 2).  Border / padding pixels: byte offset >= 2 GiB (the range check makes the DMA write zeros).
+    unsigned abase[XSLOTS];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int q = (i * NW + wave) * 16 + (lane >> 2);
-        const int py = q / PW, px = q - py * PW;
-        const bool ok = q < PATCH_PX && py >= 1 && py <= HW && px >= 1 && px <= HW;
-        // (invalid pixels: 2 GiB, beyond any plane this kernel accepts -- adding the chunk offsets below keeps them out of range)
-        abase[i] = ok ? (unsigned)((((img * HW + py - 1) * HW + px - 1) * p.Cin) * 2 + (lane & 3) * 4) : 0x80000000u;
+    for (int i = 0; i < XSLOTS; ++i) {
+        const int q = i * NW + wave;
+        const int py = q >> 1, px = (q & 1) * 16 + (lane >> 2);
+        const int chunk16 = (lane & 3) ^ (3 * ((px >> 2) & 1));
+        const bool ok = q < PPIECES && py >= 1 && py <= HW && px >= 1 && px <= HW;
+        // (invalid pixels: 2 GiB, beyond any tensor this kernel accepts -- adding the chunk offsets below keeps them out of range)
+        abase[i] = ok ? (unsigned)((((img * HW + py - 1) * HW + px - 1) * p.Cin) * 2 + chunk16 * 16) : 0x80000000u;
     }
-    const int na_mine = (A_GROUPS - wave + NW - 1) / NW;      // pixel groups this wave owns (6 for waves 0-2, 5 for the others)
-    const int npd_mine = 4 * na_mine;
-    // patch DMA d (0 .. npd_mine-1) of the chunk with channel offset cbytes: pixel group d / 4, channel chunk d % 4
-    auto issue_patch = [&](auto d_c, unsigned cbytes, int abuf) {
-        constexpr int D = decltype(d_c)::value;
-        constexpr int I = D / 4, C = D % 4;
-        unsigned voff = abase[I] + (cbytes + C * 16);          // one VALU add of a scalar; nothing per-(group, chunk) is kept in registers
-        if constexpr (DBG & 64) voff = 0xFFFFFFFFu;
-        char* dst = smem + abuf * A_BYTES + C * PLANE + (I * NW + wave) * 256;
-        if constexpr (!(DBG & 1) && !(DBG & 256)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)dst, 4, voff, 0, 0, 0);
-    };
-    // ---- weight stager: this wave's piece = rows 16 * wave .. + 15 of the tile, chunk-major (16 rows x 16 B per 256-B line):
-    // lane l moves row (l & 15), chunk (l >> 4) and the DMA's lane-linear write puts it at (l >> 4) * 256 + (l & 15) * 16
-    const unsigned wbase = (unsigned)(((n0 + wave * 16 + (lane & 15)) * p.K + (lane >> 4) * 8) * 2);
     const int nchunks = p.Cin / BK;
+    auto issue_patch = [&](int slot, int chunk, int abuf) {     // slot: compile-time after unrolling; chunk / abuf: block-uniform
+        const int q = slot * NW + wave;
+        const bool real = q < PPIECES && chunk < nchunks;
+        unsigned voff = real ? abase[slot] + (unsigned)(chunk * BK * 2) : 0xFFFFFFFFu;
+        if constexpr (DBG & 64) voff = 0xFFFFFFFFu;
+        char* dst = smem + (real ? abuf * A_BYTES + q * 1024 : OFF_DUMMY);
+        if constexpr (!(DBG & 1) && !(DBG & 256)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)dst, 16, voff, 0, 0, 0);
+    };
+    // ---- weight stager: this wave's piece = rows 16 * wave .. + 15 of the tile, ROW-major (64 B per row): lane l moves 16-B slot
+    // (l & 3) of row (l >> 2), so the four lanes of a quad fetch the 64 contiguous bytes of one row -- one 64-B request instead of
+    // four 16-B requests from four different quarter-waves (the L2 request rate, not its bandwidth, is what the staging traffic
+    // costs).  Rows of 64 B collide in LDS banks every four rows; slot s of row r therefore holds channel chunk s ^ (3 * ((r >> 2) & 1)):
+    // for every 16-lane group a ds_read_b128 serves together the (r & 3, slot) pairs are distinct -- conflict-free.
+    const int wrow = lane >> 2, wslot = lane & 3;
+    const unsigned wbase = (unsigned)(((n0 + wave * 16 + wrow) * p.K + (wslot ^ (3 * ((wrow >> 2) & 1))) * 8) * 2);
     auto issue_weight = [&](int chunk, int tap, int stage) {       // K-tile (chunk, tap); past the end: zero fill (keeps vmcnt uniform)
         unsigned voff = chunk < nchunks ? wbase + (unsigned)((tap * p.Cin + chunk * BK) * 2) : 0xFFFFFFFFu;
         if constexpr (DBG & 64) voff = 0xFFFFFFFFu;
@@ -116,13 +147,17 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_img_kernel(const IgemmB
     // ---- fragment addressing.  v_mfma_f32_16x16x32_bf16 lane l holds A[i = l & 15][k = 8 * (l >> 4) .. +7] (B alike).
     // Output pixel m = wm * 144 + 16 i + fi of the image sits at patch pixel q0 = (m / 24) * 26 + m % 24 (+ tap offset ky * 26 + kx).
     const int fi = lane & 15, fq = lane >> 4;
-    int a_addr[TM];                                          // byte offset inside a patch buffer, tap (0, 0)
+    // LDS address inside patch buffer 0 for kx = 0, 1, 2 (the swizzle depends on the column); ky is an immediate (one patch row)
+    int a_addr[TM][3];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wm * WTM + i * 16 + fi;
-        a_addr[i] = fq * PLANE + ((m / HW) * PW + (m % HW)) * 16;
+        const int y = m / HW, x = m - y * HW;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            a_addr[i][kx] = lds0 + y * PROW + (x + kx) * 64 + ((fq ^ (3 * (((x + kx) >> 2) & 1))) << 4);
     }
-    const int b_addr = B_BASE + (wn * (WTN / 16)) * 1024 + fq * 256 + fi * 16;      // + j * 1024 per 16-row tile, + stage * B_BYTES
+    const int b_addr = lds0 + B_BASE + (wn * (WTN / 16)) * 1024 + fi * 64 + ((fq ^ (3 * ((fi >> 2) & 1))) << 4);   // + j * 1024 per 16-row tile (immediate), + stage * B_BYTES
     bf16x8 af[TM], bf[TN];
     floatx4 acc[TM][TN];
 #pragma unroll
@@ -131,96 +166,66 @@ __global__ void __launch_bounds__(NW * 64, 1) igemm_bf16_img_kernel(const IgemmB
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_chunks = (DBG & 32) ? 0 : nchunks;
-    // ---- prologue: the patch of chunk 0 and weight tiles 0 .. 2 in flight; patch + tile 0 landed and visible to everybody
-    {
-        auto all = [&](auto self, auto d_c) {
-            constexpr int D = decltype(d_c)::value;
-            if constexpr (D < NPD) {
-                if (D < npd_mine) issue_patch(d_c, 0u, 0);
-                self(self, std::integral_constant<int, D + 1>{});
-            }
-        };
-        all(all, std::integral_constant<int, 0>{});
-    }
+    // ---- prologue: the patch of chunk 0 and weight tiles 0 .. 2, landed and visible to everybody
+#pragma unroll
+    for (int sl = 0; sl < XSLOTS; ++sl) issue_patch(sl, 0, 0);
 #pragma unroll
     for (int t = 0; t < B_STAGES - 1; ++t) issue_weight(0, t, t);
-    wait_vmcnt<B_STAGES - 2>();
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();
 
-    // One iteration = one K-tile (chunk, tap).  The tap loop is NOT unrolled (an unrolled body made the compiler keep per-tap
-    // addresses live and spill -- and a scratch reload costs an s_waitcnt vmcnt(0), which drains the DMA queue): the tap offset is a
-    // scalar added to the 9 fragment addresses (9 VALU per load segment).  Measured alternatives on layer4 at B = 128 (this form:
-    // 287-296 us): the NEXT segment's address arithmetic between the MFMAs of the wave's own MFMA segment -- 311 us (the MFMA
-    // segment grows by more than the load segment shrinks); the same arithmetic behind the fragment reads / DMA issue of the load
-    // segment (in the shadow of the LDS latency) -- 308 us, and with the DMA source steps in the instructions' scalar offsets 317 us
-    // (each variant is FASTER without the DMA traffic -- 203 vs 208 us -- so what they lose is the timing of the DMA issue relative
-    // to the partner wave's MFMA segment, not instruction count); taps unrolled with immediate offsets -- the compiler spills.
-    int chunk = 0, tap = 0, toff = 0, tx = 0, prev_issued = 0;
-    const int nk = nk_chunks * TAPS;
-    for (int kt = 0; kt < nk; ++kt) {
+    // One trip = one 32-channel chunk, its nine taps unrolled: K-tile (chunk, tap).  Every LDS address is a base register + an
+    // immediate (tap shift, 16-row tile of the weight stage); the only per-K-tile arithmetic is the weight stage (one add) and the
+    // DMA source offsets.  Per K-tile and wave: one weight piece (K-tile + 3) and, during taps 0 .. XSLOTS - 1, one piece of the NEXT
+    // chunk's patch -- a constant pattern, so the counted wait of every tap is an immediate.
+    int kt = 0;
+    for (int chunk = 0; chunk < nk_chunks; ++chunk) {
         const int abuf = chunk & 1;
-        const int stage = kt & (B_STAGES - 1);
-        // ---------------- load segment ----------------
-        if constexpr (!(DBG & 8)) {
-            const char* bs = smem + stage * B_BYTES + b_addr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bs + j * 1024);
-            const char* as = smem + abuf * A_BYTES + toff;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + a_addr[i]);
-        }
-        // staging: during tap t < na_mine the four channel-chunk planes of pixel group t of the NEXT chunk's patch, then this wave's
-        // weight piece of the K-tile three ahead
-        int issued = 0;
-        if (chunk + 1 < nchunks && tap < na_mine) {
-            unsigned ab = abase[0];                          // abase[tap]: select among the NA registers (tap is wave-uniform)
-#pragma unroll
-            for (int i = 1; i < NA; ++i) ab = tap == i ? abase[i] : ab;
-            unsigned voff = ab + (unsigned)((chunk + 1) * BK * 2);
-            if constexpr (DBG & 64) voff = 0xFFFFFFFFu;
-            char* dst = smem + (abuf ^ 1) * A_BYTES + (tap * NW + wave) * 256;
-            if constexpr (!(DBG & 1) && !(DBG & 256)) {
-                // (the 16-B channel-chunk step rides in the instruction's scalar offset: it is added to the memory address only)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst), 4, voff, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + PLANE), 4, voff, 16, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + 2 * PLANE), 4, voff, 32, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + 3 * PLANE), 4, voff, 48, 0, 0);
+        static_for<TAPS>([&](auto T) {
+            constexpr int tap = decltype(T)::value;
+            constexpr int toff = (tap / 3) * PROW;                   // ky patch rows down; kx selects the base register
+            const int stage = kt & (B_STAGES - 1);
+            // ---------------- load segment ----------------
+            if constexpr (!(DBG & 8)) {
+                const int bs = b_addr + stage * B_BYTES;
+                static_for<TN>([&](auto J) { bf[decltype(J)::value] = lds_read16<decltype(J)::value * 1024>(bs); });
+                static_for<TM>([&](auto I) { af[decltype(I)::value] = lds_read16<toff>(a_addr[decltype(I)::value][tap % 3]); });
             }
-            issued = 4;
-        }
-        {
-            const int t3 = tap + B_STAGES - 1;               // K-tile three ahead: (chunk, tap + 3) or (chunk + 1, tap - 6)
-            issue_weight(t3 < TAPS ? chunk : chunk + 1, t3 < TAPS ? t3 : t3 - TAPS, (stage + B_STAGES - 1) & (B_STAGES - 1));
-        }
-        // the weight piece of the NEXT K-tile (issued two load segments ago) has landed once at most the operations issued since
-        // then are outstanding: 2 weight pieces + the patch DMAs of this and of the previous load segment (0, 4 or 8)
-        if constexpr (!(DBG & 1) && !(DBG & 4) && !(DBG & 256) && !(DBG & 512)) {
-            const int extra = issued + prev_issued;
-            if (extra == 0) wait_vmcnt<2>();
-            else if (extra == 4) wait_vmcnt<6>();
-            else wait_vmcnt<10>();
-        }
-        prev_issued = issued;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-        // ---------------- MFMA segment ----------------
-        if constexpr (!(DBG & 128)) __builtin_amdgcn_s_setprio(1);
+            {
+                constexpr int t3 = tap + B_STAGES - 1;           // K-tile three ahead: (chunk, tap + 3) or (chunk + 1, tap - 6)
+                issue_weight(t3 < TAPS ? chunk : chunk + 1, t3 < TAPS ? t3 : t3 - TAPS, (stage + B_STAGES - 1) & (B_STAGES - 1));
+            }
+            constexpr bool patch_tap = tap < XSLOTS;
+            if constexpr (patch_tap) issue_patch(tap, chunk + 1, abuf ^ 1);
+            // counted wait: everything issued two K-tiles ago or earlier has landed = at most the loads of this K-tile and of the one
+            // before may be outstanding (one weight piece each, + one patch piece in taps 1 .. XSLOTS)
+            constexpr int tp = (tap + TAPS - 1) % TAPS;
+            constexpr int outstanding = 2 + (patch_tap ? 1 : 0) + (tp < XSLOTS ? 1 : 0);
+            wait_vmcnt<(DBG & (1 | 256 | 512)) ? 0 : outstanding>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+            // ---------------- MFMA segment ----------------
+            if constexpr (!(DBG & 128)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (DBG & 16) asm volatile("" :: "v"(af[i]), "v"(bf[j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+            if constexpr (!(DBG & 128)) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+            ++kt;
+        });
+        // the next chunk reads the other patch buffer
+        const int delta = abuf ? -A_BYTES : A_BYTES;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (DBG & 16) asm volatile("" :: "v"(af[i]), "v"(bf[j]));
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        if constexpr (!(DBG & 128)) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-        // next (chunk, tap); toff = ((tap / 3) * 26 + tap % 3) * 16
-        ++tap; ++tx; toff += 16;
-        if (tx == 3) { tx = 0; toff += (PW - 3) * 16; }
-        if (tap == TAPS) { tap = 0; tx = 0; toff = 0; ++chunk; }
+            for (int kx = 0; kx < 3; ++kx) a_addr[i][kx] += delta;
     }
     if (group == 0) __builtin_amdgcn_s_barrier();           // group 0 waits for group 1's last MFMA segment
     wait_vmcnt<0>();
@@ -259,17 +264,15 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     switch (dbg) {
         case 1: launch<1>(p, (unsigned)blocks, stream); break;      // no DMA
         case 2: launch<2>(p, (unsigned)blocks, stream); break;      // no barriers
-        case 4: launch<4>(p, (unsigned)blocks, stream); break;      // no vmcnt waits
         case 8: launch<8>(p, (unsigned)blocks, stream); break;      // no fragment reads
         case 16: launch<16>(p, (unsigned)blocks, stream); break;    // no MFMAs
         case 32: launch<32>(p, (unsigned)blocks, stream); break;    // epilogue only
         case 64: launch<64>(p, (unsigned)blocks, stream); break;    // DMA issued with every lane out of range
         case 80: launch<80>(p, (unsigned)blocks, stream); break;    // masked DMA, no MFMA
         case 17: launch<17>(p, (unsigned)blocks, stream); break;    // no DMA, no MFMA
-        case 256: launch<256>(p, (unsigned)blocks, stream); break;  // no patch pieces (no vmcnt waits)
-        case 512: launch<512>(p, (unsigned)blocks, stream); break;  // no weight pieces (no vmcnt waits)
-        case 25: launch<25>(p, (unsigned)blocks, stream); break;    // barriers only
         case 128: launch<128>(p, (unsigned)blocks, stream); break;  // no s_setprio
+        case 256: launch<256>(p, (unsigned)blocks, stream); break;  // no patch pieces (vmcnt(0) waits)
+        case 512: launch<512>(p, (unsigned)blocks, stream); break;  // no weight pieces (vmcnt(0) waits)
         default: launch<0>(p, (unsigned)blocks, stream);
     }
 #else

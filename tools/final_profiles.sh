@@ -26,7 +26,7 @@ prof() {   # name, extra bench args...
   python tools/pmc_traffic.py $(find $O -name "pf_${name}_results.db") $(find $O -name "pw_${name}_results.db") $O/pmc_traffic_${name}.json > $O/bench_${name}_pmc_traffic.txt
 }
 prof b32
-prof bf16_b128 --precision bf16 --batch 128 --cin 5
+prof bf16_b128 --workload configs2
 find $O -name "*.db" -delete
 find $O -type d -empty -delete
 tail -c 1500 $O/bench.json
