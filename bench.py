@@ -261,6 +261,9 @@ def main():
                 probe = torch.arange(1024, dtype=torch.float32, device=dev) * (rank + 1)
                 want = probe.clone()
                 torch.distributed.all_reduce(want, group=pg)
+                # two RCCL communicators live in this process (torch.distributed's and libsimq's): never let collectives of both be
+                # in flight at once -- ranks may schedule them in different orders and wait for each other forever
+                torch.cuda.synchronize(dev)
                 good = 1.0
                 try:
                     comm.all_reduce(probe)

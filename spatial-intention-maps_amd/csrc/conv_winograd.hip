@@ -675,6 +675,14 @@ bool winograd_eligible(const ConvGeom& g) {
 // unchanged: the gain is in the two no-grad forwards); 64 -> 64 (layer1) does not (3155, forward + backward -0.7 %).
 bool winograd_pays(int cin, int cout, long min_cc) { return (long)cin * cout >= min_cc; }
 
+// grid of a grid-stride kernel: at most `cap` blocks, every block the same number of trips (a capped grid whose last trip is ragged
+// runs as long as one more full trip)
+static int balanced_grid(int blocks, int cap) {
+    if (blocks <= cap) return blocks < 1 ? 1 : blocks;
+    const int trips = (blocks + cap - 1) / cap;
+    return (blocks + trips - 1) / trips;
+}
+
 int64_t winograd_scratch_floats(const ConvGeom& g) {
     const int64_t T = (int64_t)g.B * (g.Hin / 2) * (g.Win / 2);
     return 16 * T * (g.Cin + g.Cout);
@@ -712,8 +720,7 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
     int bout = (T + tpb_out - 1) / tpb_out;
     // statistics: few blocks, one fp64 atomic per channel and block (the step is insensitive to this cap from 256 to 2048)
-    const int cap = (e.stats || e.bnr_red1) ? 512 : 4096;
-    if (bout > cap) bout = cap;
+    bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 512 : 4096);
     const EpiArgs ea = make_epi(y, e);
     hipLaunchKernelGGL(wino_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T);
     SIMQ_CHECK_LAUNCH();
@@ -749,8 +756,9 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream)) return rc;
     int bout = (T4 + tpb_out - 1) / tpb_out;
-    const int cap = (e.stats || e.bnr_red1) ? 512 : 4096;
-    if (bout > cap) bout = cap;
+    // F(4x4,3x3) has a quarter of the tiles: at 512 channels a block is two tiles and B = 32 gives 576 blocks -- capped at 512, sixty-four
+    // blocks did two grid-stride trips while the rest did one (the launch took the time of two).  Up to 1024 blocks, equal trips each.
+    bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 1024 : 4096);
     const EpiArgs ea = make_epi(y, e);
     hipLaunchKernelGGL(wino4f_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T4);
     SIMQ_CHECK_LAUNCH();

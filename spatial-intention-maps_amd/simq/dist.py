@@ -134,7 +134,9 @@ class Comm:
                 status, why = 0, str(ex)
         t = torch.tensor([status] + list(ident), dtype=torch.uint8, device=where)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        got = t.cpu().tolist()
+        got = t.cpu().tolist()                              # (also drains the process group's stream: collectives of the group's and of
+        if on_device:                                       # libsimq's communicator must never be in flight together -- different
+            torch.cuda.synchronize(self.device)             # ranks may schedule them in different orders and deadlock)
         if got[0] != 1:
             raise SimqError('Comm: rank 0 could not draw an RCCL identifier%s' % ((': ' + why) if why else ''))
         ident = (ctypes.c_ubyte * COMM_ID_BYTES)(*got[1:])
@@ -144,6 +146,8 @@ class Comm:
                 lib.call('simq_comm_init', ident, self.world, self.rank, ctypes.byref(h))
         except Exception as ex:                              # noqa: BLE001
             status, why, h = 0, str(ex), ctypes.c_void_p()
+        if on_device:
+            torch.cuda.synchronize(self.device)
         ok = torch.tensor([status], dtype=torch.int32, device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) != 1:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the measurements behind profiles/r02_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
+# GPU box: the measurements behind profiles/r03_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
 #   1. python bench.py                      -> bench.json        (the judged line: fp32 configs[1] headline + bf16 configs[2] leg,
 #                                                                  both with a roofline object, cpu_baseline)
 #   per workload W in {b32 = fp32 configs[1], bf16_b128 = bf16 configs[2]}:
