@@ -54,6 +54,9 @@ GRAD_STUDY_B64_CASES = [('gs_b64_%02d' % i, 5, (2, 1)[i % 2], 64, 270 + i, 370 +
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 
+# the same with DataParallel's literal scatter of the COMPACTED next-state tensor (learner.dp_emulation_literal; gen_golden.gen_dp_literal)
+DP_LITERAL_CASES = [('dplit_c5o2_b8_w2', 5, 2, 8, 2, 37, 50), ('dplit_c5o2_b8_w4', 5, 2, 8, 4, 37, 50), ('dplit_c5o1_b8_w2', 5, 1, 8, 2, 38, 48)]
+
 LR, MOMENTUM, WEIGHT_DECAY, CLIP, GAMMA = 0.01, 0.9, 1e-4, 100, 0.75   # base config yml / train.py:186
 
 

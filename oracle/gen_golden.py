@@ -462,6 +462,93 @@ def gen_dp():
               'all-terminal shards: %d; per-shard-BN vs single replica: %.3g' % (relerr, empty_shards, float((t64 - one).norm() / one.norm())))
 
 
+def gen_dp_literal():
+    """nn.DataParallel's literal scatter (policies.py:39): the double-DQN forward policy_net(non_final_next_states) (train.py:121) hands
+    DataParallel the COMPACTED non-final tensor, which torch.chunk cuts into ceil(N'/world) rows per replica -- so replica r picks the greedy
+    actions of compacted chunk r, not of the next states of ITS slice of the minibatch (the default sharding of this package: gen_dp).
+    Emulated with the reference's own modules: the first forward replica by replica over torch.chunk(state_batch), the no-grad forward
+    replica by replica over torch.chunk(non_final_next_states) itself (replica r > 0 = a deepcopy, what DataParallel.replicate produces;
+    only replica 0's running statistics persist), then train.py:122-132 on the gathered outputs exactly as the reference's device 0 does.
+    The oracle's dp_emulation_literal must agree bit for bit."""
+    import copy
+    from torch.nn.functional import smooth_l1_loss
+    for name, cin, cout, gB, world, wseed, dseed in cases.DP_LITERAL_CASES:
+        cfg = cases.make_cfg(gB)
+        batch = cases.make_batch(cin, cout, gB, dseed)
+        spec = fcn.state_spec(cin, cout)
+        policy, target = ref_net(cin, cout, wseed), ref_net(cin, cout, wseed + 1000)
+        policy.train()
+        target.eval()
+        state_b = torch.cat([learner.apply_transform(s) for s in batch.state])
+        act = torch.tensor(batch.action, dtype=torch.long)
+        rew = torch.tensor(batch.reward, dtype=torch.float32)
+        nfns = torch.cat([learner.apply_transform(s) for s in batch.next_state if s is not None])
+        mask = torch.tensor([s is not None for s in batch.next_state], dtype=torch.bool)
+        policy.zero_grad()
+        # train.py:114 through DataParallel: scatter = torch.chunk(x, world), replicas forward their chunk, outputs are gathered
+        outs = []
+        for r, xs in enumerate(torch.chunk(state_b, world)):
+            replica = policy if r == 0 else copy.deepcopy(policy)
+            outs.append((replica, replica(xs)))
+        # gradients flow back into each replica's own parameters; DataParallel reduce-adds them onto device 0 = the rank-order sum
+        output = torch.cat([o for _, o in outs])
+        q = output.view(gB, -1).gather(1, act.unsqueeze(1)).squeeze(1)                                     # train.py:115
+        nsv = torch.zeros(gB)
+        with torch.no_grad():                                                                              # train.py:118-122
+            bests = []
+            for r, xs in enumerate(torch.chunk(nfns, world)):
+                replica = policy if r == 0 else copy.deepcopy(policy)
+                bests.append(replica(xs).view(xs.size(0), -1).max(1)[1])
+            best = torch.cat(bests)
+            nsv[mask] = target(nfns).view(nfns.size(0), -1).gather(1, best.view(-1, 1)).view(-1)
+        y = rew + cases.GAMMA * nsv                                                                        # train.py:126
+        loss = smooth_l1_loss(q, y)                                                                        # train.py:129
+        loss.backward()
+        total = None
+        for replica, _ in outs:
+            flat = torch.cat([p.grad.reshape(-1) for p in replica.parameters() if p.grad is not None])
+            total = flat if total is None else total + flat
+        td = torch.abs(q - y).detach().mean()
+        # oracle restatement, fp32: bit-exact
+        st, tg = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        o_total, o_loss, o_td, o_best, o_q, o_y = learner.dp_emulation_literal(cfg, st, tg, spec, batch, world, cases.GAMMA)
+        assert torch.equal(o_best, best), (name, o_best, best)
+        assert_same(o_q, q.detach(), name + ' q')
+        assert_same(o_y, y, name + ' y')
+        assert_same(o_total, total, name + ' gradient sum')
+        for k, v in policy.state_dict().items():
+            assert_same(st[k], v, name + ' replica-0 buffer ' + k)
+        # how the default sharding of this package (next states follow their transitions' slice) differs on this batch
+        st2, tg2 = cases.oracle_state(cin, cout, wseed), cases.oracle_state(cin, cout, wseed + 1000)
+        s_total, s_loss, s_td = learner.dp_emulation(cfg, st2, tg2, spec, batch, world, cases.GAMMA)
+        # fp64 yardstick
+        st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+        t64, loss64, td64, best64, _, y64 = learner.dp_emulation_literal(cfg, st64, tg64, spec, batch, world, cases.GAMMA, dtype=torch.float64)
+        gkeys = learner.grad_keys(spec)
+
+        def split(flat):
+            out, off = {}, 0
+            for k in gkeys:
+                n = st[k].numel()
+                out[k] = flat[off:off + n].view(st[k].shape)
+                off += n
+            return out
+        g32, g64 = cases.grad_summary(split(total)), cases.grad_summary(split(t64))
+        np.savez(os.path.join(cases.GOLDEN_DIR, name + '.npz'),
+                 loss=np.array(float(loss)), td_error=np.array(float(td)), loss64=np.array(loss64), td_error64=np.array(td64),
+                 total_norm=np.array(float(total.norm())), total_norm64=np.array(float(t64.norm())),
+                 q_sa=q.detach().numpy(), y=y.numpy(), best=best.numpy(), best64=best64.numpy(), grad_keys=np.array(gkeys),
+                 grad32=np.stack(list(g32.values())), grad64=np.stack(list(g64.values())),
+                 ref_fp32_grad_relerr=np.array(float((total.double() - t64).norm() / t64.norm())),
+                 bn_buffers_after=cases.bn_buffer_vector(st).astype(np.float32),
+                 slice_sharding_loss=np.array(s_loss), slice_vs_literal_grad=np.array(float((s_total - total).norm() / total.norm())),
+                 nonfinal=np.array(int(mask.sum())))
+        print('dp-literal case %s: oracle == reference replicas (bit-exact); %d non-final next states in chunks of %d; greedy actions '
+              'fp32 == fp64: %s; slice-sharding differs by loss %.3g vs %.3g, gradient %.3g' % (
+                  name, int(mask.sum()), -(-int(mask.sum()) // world), bool(torch.equal(best, best64)), s_loss, float(loss),
+                  float((s_total - total).norm() / total.norm())))
+
+
 def gen_grad_study(case_list=None, fname='grad_study.npz'):
     """Gradient-parity study: fp32 gradients of these small train-mode-BN batches are only 1e-4 .. 1e-2
     accurate -- for the reference as much as for any other fp32 implementation -- and WHICH implementation is luckier changes from
@@ -719,7 +806,7 @@ if __name__ == '__main__':
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
             'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
-            'dp': gen_dp, 'bf16_calibration': gen_bf16_calibration,
+            'dp': gen_dp, 'dp_literal': gen_dp_literal, 'bf16_calibration': gen_bf16_calibration,
             'grad_study': gen_grad_study,
             'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz')}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family

@@ -251,3 +251,63 @@ def dp_emulation(cfg, state, target_state, spec, batch, world_size, discount_fac
         total = flat if total is None else total + flat
         sums = sums + s
     return total, float(sums[0]) / gB, float(sums[1]) / gB
+
+
+def dp_emulation_literal(cfg, state, target_state, spec, batch, world_size, discount_factor, dtype=torch.float32):
+    """nn.DataParallel LITERALLY (policies.py:39 around train.py:114-132): like dp_emulation, except for the double-DQN forward
+    `policy_net(non_final_next_states)` (train.py:121) -- DataParallel scatters the tensor IT IS GIVEN, the COMPACTED non-final next
+    states, in torch.chunk pieces of ceil(N'/world) rows, so replica r picks the greedy actions of compacted chunk r (with ITS OWN
+    train-mode BatchNorm statistics over that chunk; replica 0's running statistics see chunk 0), whichever transitions of the
+    minibatch those rows came from.  The target net runs in eval mode: its chunking does not matter.
+    Returns (flat grad sum, loss, td_error, best actions [N'])."""
+    gB = len(batch.action)
+    chunk = -(-gB // world_size)
+    gkeys = grad_keys(spec)
+    params = [state[k] for k in gkeys]
+    action_batch = torch.tensor(batch.action, dtype=torch.long)
+    reward_batch = torch.tensor(batch.reward, dtype=torch.float32).to(dtype)
+    nf = [apply_transform(s) for s in batch.next_state if s is not None]
+    mask = torch.tensor(tuple(s is not None for s in batch.next_state), dtype=torch.bool)
+    for p in params:
+        p.requires_grad_(True)
+    try:
+        # train.py:114 -- replica r forwards rows [r * chunk, (r + 1) * chunk) of the minibatch
+        outs = []
+        for r in range(world_size):
+            lo, hi = min(r * chunk, gB), min((r + 1) * chunk, gB)
+            if lo == hi:
+                continue
+            sb = torch.cat([apply_transform(s) for s in batch.state[lo:hi]]).to(dtype)
+            outs.append(fcn.fcn_forward(state, sb, True, update_buffers=(r == 0)).view(hi - lo, -1))
+        q = torch.cat(outs).gather(1, action_batch.unsqueeze(1)).squeeze(1)                        # train.py:115
+        nsv = torch.zeros(gB, dtype=dtype)
+        best = torch.zeros(0, dtype=torch.long)
+        if nf:
+            nfns = torch.cat(nf).to(dtype)
+            n = nfns.size(0)
+            nchunk = -(-n // world_size)
+            with torch.no_grad():
+                bests = []
+                for r in range(world_size):
+                    lo, hi = min(r * nchunk, n), min((r + 1) * nchunk, n)
+                    if lo == hi:
+                        continue
+                    bests.append(fcn.fcn_forward(state, nfns[lo:hi], True, update_buffers=(r == 0)).view(hi - lo, -1).max(1)[1])
+                best = torch.cat(bests)
+                nsv[mask] = fcn.fcn_forward(target_state, nfns, False).view(n, -1).gather(1, best.view(n, 1)).view(-1)
+        y = reward_batch + discount_factor * nsv
+        huber = smooth_l1_loss(q, y, reduction='sum')
+        # DataParallel's backward: every replica differentiates ITS rows (upstream gradient huber'(q - y) / gB), the replicas' gradients
+        # are reduce-added onto device 0 in replica order
+        flat, lo = None, 0
+        for o in outs:
+            hi = lo + o.shape[0]
+            q_r = o.gather(1, action_batch[lo:hi].unsqueeze(1)).squeeze(1)
+            g_r = torch.autograd.grad(smooth_l1_loss(q_r, y[lo:hi], reduction='sum') / gB, params)
+            f_r = torch.cat([g.reshape(-1) for g in g_r])
+            flat = f_r if flat is None else flat + f_r
+            lo = hi
+    finally:
+        for p in params:
+            p.requires_grad_(False)
+    return flat, float(huber.detach()) / gB, float(torch.abs(q - y).detach().sum()) / gB, best, q.detach(), y.detach()

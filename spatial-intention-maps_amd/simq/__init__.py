@@ -19,6 +19,7 @@ _LAZY = {
     'Transition': ('.learner', 'Transition'),
     'train': ('.learner', 'train'),
     'train_step': ('.learner', 'train_step'),
+    'train_step_dataparallel': ('.learner', 'train_step_dataparallel'),
     'train_intention': ('.learner', 'train_intention'),
     'train_intention_step': ('.learner', 'train_intention_step'),
     'lib': ('._lib', 'lib'),

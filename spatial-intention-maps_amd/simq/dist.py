@@ -43,6 +43,19 @@ def shard_indices(indices, world_size, rank):
     return list(indices[lo:hi])
 
 
+def gather_greedy_actions(best_chunk, n_total, world_size, rank, group=None):
+    """DataParallel's literal scatter of the double-DQN forward (policies.py:39 around train.py:121): rank r picked the greedy actions of
+    torch.chunk piece r of the COMPACTED non-final next states (`best_chunk`, int64 on any device, possibly empty); every rank needs the
+    actions of the next states of ITS transitions, so the pieces are assembled on all ranks (a sum of disjointly filled vectors --
+    n_total int64 values, the only data-path exchange besides the gradient sum).  Returns int64 [n_total] on best_chunk's device."""
+    lo, hi = shard_bounds(n_total, world_size, rank) if n_total > 0 else (0, 0)
+    full = torch.zeros(max(n_total, 1), dtype=torch.int64, device=best_chunk.device)
+    if hi > lo:
+        full[lo:hi] = best_chunk
+    dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    return full[:n_total]
+
+
 def allreduce_gradients(flat_grads, loss_sums=None, group=None):
     """Sum the flat gradient buffer (and the per-rank loss partial sums) over all ranks, in place."""
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)

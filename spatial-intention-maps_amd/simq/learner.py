@@ -550,6 +550,78 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     return {'td_error': o[1] / gB, 'loss': o[0] / gB}
 
 
+def train_step_dataparallel(policy_net, target_net, global_batch, discount_factor, lr, momentum, weight_decay, grad_norm_clipping,
+                            process_group, opt_state=None, sync=True):
+    """One double-DQN TD step as nn.DataParallel LITERALLY runs it on N devices (policies.py:39 around train.py:108-141), one process per
+    device.  `global_batch`: the WHOLE sampled minibatch (every rank holds the ring and draws the same indices).  Rank r
+      * forwards rows shard_bounds(B, N, r) of the states (train-mode BatchNorm over its rows, as in train_step), and
+      * picks the greedy next actions of torch.chunk piece r of the COMPACTED non-final next states -- DataParallel scatters the tensor
+        train.py:121 hands it, so those rows belong to whichever transitions they came from, not to this rank's slice (the default
+        `train_step` sharding keeps next states with their transitions: simpler, no exchange, same semantics class) --;
+    the pieces are exchanged (simq.dist.gather_greedy_actions), the target net (eval mode: chunking is immaterial) evaluates the next
+    states of THIS rank's transitions, and loss / backward / the two-bucket gradient all-reduce / clip + SGD follow as in train_step.
+    Rank 0's running statistics see state chunk 0 and compacted chunk 0, exactly replica 0's.  Fixture: tests/golden/dplit_*.npz
+    (oracle/gen_golden.py dp_literal, the reference's own modules replica by replica)."""
+    if process_group is None:
+        raise SimqError('train_step_dataparallel needs a torch.distributed process group')
+    import torch.distributed as tdist
+    world, rank = tdist.get_world_size(process_group), tdist.get_rank(process_group)
+    dev = policy_net.device_
+    g = assemble_batch(global_batch, dev)
+    gB = g.state.shape[0]
+    lo, hi = sdist.shard_bounds(gB, world, rank)
+    B = hi - lo
+    if B < 1:
+        raise SimqError('train_step_dataparallel: rank %d of %d has no rows of a %d-transition minibatch' % (rank, world, gB))
+    st = stream_ptr(dev)
+    n = policy_net.num_output_channels * W * W
+    st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
+    state = g.state[lo:hi]
+    q = policy_net._forward_raw(state, MODE_TRAIN)                                                   # train.py:114, rows of replica r
+    Nn = g.next_state.shape[0]
+    clo, chi = sdist.shard_bounds(Nn, world, rank)                                                   # torch.chunk piece r of the compacted tensor
+    best_chunk = torch.empty(chi - clo, dtype=torch.int64, device=dev)
+    if chi > clo:                                                                                    # train.py:121 on replica r
+        q_next = policy_net._forward_raw(g.next_state[clo:chi], MODE_TRAIN_NOGRAD)
+        lib.call('simq_q_argmax', ptr(q_next), chi - clo, n, ptr(best_chunk), None, st)
+    best = sdist.gather_greedy_actions(best_chunk, Nn, world, rank, process_group)
+    # the next states of THIS rank's transitions: compacted indices k0 .. k1-1 (positions are increasing)
+    pos = [i for i, m in enumerate(g.non_final_mask) if m]
+    k0 = sum(1 for p in pos if p < lo)
+    k1 = sum(1 for p in pos if p < hi)
+    nsv = torch.empty(B, dtype=torch.float32, device=dev)
+    vals = torch.empty(max(k1 - k0, 1), dtype=torch.float32, device=dev)
+    own_pos = torch.tensor([p - lo for p in pos[k0:k1]] or [0], dtype=torch.int32).to(dev)
+    if k1 > k0:
+        q_tgt = target_net._forward_raw(g.next_state[k0:k1], MODE_EVAL)                              # train.py:122
+        lib.call('simq_q_gather', ptr(q_tgt), k1 - k0, n, ptr(best[k0:k1].contiguous()), ptr(vals), st)
+    lib.call('simq_scatter_next_values', ptr(vals), ptr(own_pos), k1 - k0, ptr(nsv), B, st)
+    action, reward = g.action[lo:hi].contiguous(), g.reward[lo:hi].contiguous()
+    q_sa = torch.empty(B, dtype=torch.float32, device=dev)
+    y = torch.empty(B, dtype=torch.float32, device=dev)
+    td = torch.empty(B, dtype=torch.float32, device=dev)
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    lib.call('simq_td_huber', ptr(q), B, n, ptr(action), ptr(reward), ptr(nsv), float(discount_factor), 1.0 / gB, ptr(q_sa), ptr(y),
+             ptr(td), ptr(out4), None, st)
+    split = policy_net.grad_bucket_split
+    grads = policy_net._backward_onehot(action, q_sa, y, 1.0 / gB, B, phase=1)
+    works = [sdist.allreduce_async(grads[split:], process_group)]
+    policy_net._backward_onehot(action, q_sa, y, 1.0 / gB, B, phase=2)
+    works += [sdist.allreduce_async(grads[:split], process_group), sdist.allreduce_async(out4, process_group)]
+    for wk in works:
+        wk.wait()
+    lib.call('simq_clip_sgd_step', ptr(policy_net.flat_params), ptr(grads), ptr(st_opt.momentum), policy_net.plan.param_count,
+             float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0, lr, momentum, weight_decay,
+             0 if st_opt.initialised else 1, ptr(st_opt.scratch), ptr(st_opt.total_norm), st)
+    st_opt.initialised = True
+    policy_net.weights_dirty = True
+    policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q, 'best': best}
+    if not sync:
+        return out4
+    o = out4.tolist()
+    return {'td_error': o[1] / gB, 'loss': o[0] / gB}
+
+
 def train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_factor):
     """Drop-in for train.train (train.py:108-141).  `transform_fn` (policies.py:44-45) is
     accepted for signature compatibility; the HIP path reads the HWC states as they are."""

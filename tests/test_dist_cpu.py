@@ -103,3 +103,48 @@ def test_bench_launches_its_own_ranks_when_started_bare():
     assert r.returncode != 0
     assert 'needs an MI355X' in r.stderr and 'must be launched' not in r.stderr
     assert r.stderr.count('needs an MI355X') >= 2 or 'nproc' in r.stderr or 'ChildFailedError' in r.stderr      # both ranks ran
+
+
+def _literal_worker(rank, world, port, out_dir, name):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, 'spatial-intention-maps_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from simq import dist as sdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _, cin, cout, gB, w, wseed, dseed = [c for c in cases.DP_LITERAL_CASES if c[0] == name][0]
+        batch = cases.make_batch(cin, cout, gB, dseed)
+        st = cases.oracle_state(cin, cout, wseed)
+        nfns = torch.cat([olearner.apply_transform(s) for s in batch.next_state if s is not None])
+        n = nfns.size(0)
+        clo, chi = sdist.shard_bounds(n, world, rank)                 # torch.chunk piece `rank` of the COMPACTED next states
+        with torch.no_grad():
+            best_chunk = ofcn.fcn_forward(st, nfns[clo:chi], True).view(chi - clo, -1).max(1)[1] if chi > clo else torch.zeros(0, dtype=torch.long)
+        best = sdist.gather_greedy_actions(best_chunk, n, world, rank)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), best=best.numpy(), chunk=np.array([clo, chi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world', [('dplit_c5o2_b8_w2', 2), ('dplit_c5o2_b8_w4', 4)])
+def test_dataparallel_literal_scatter_of_the_compacted_next_states(tmp_path, golden_dir, name, world):
+    """nn.DataParallel scatters the tensor it is handed: for train.py:121 that is the COMPACTED non-final next-state tensor, in
+    torch.chunk pieces.  Ranks pick the greedy actions of their piece and exchange them (simq.dist.gather_greedy_actions); the result
+    is the fixture's (written from the reference's own modules, replica by replica), on every rank."""
+    from simq import dist as sdist
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    n = int(g['nonfinal'])
+    # the pieces are torch.chunk's
+    sizes = [t.numel() for t in torch.chunk(torch.arange(n), world)]
+    mine = [hi - lo for lo, hi in (sdist.shard_bounds(n, world, r) for r in range(world)) if hi > lo]
+    assert mine == sizes
+    port = _free_port()
+    mp.spawn(_literal_worker, args=(world, port, str(tmp_path), name), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / ('rank%d.npz' % r))
+        assert np.array_equal(got['best'], g['best']), (r, got['best'], g['best'])

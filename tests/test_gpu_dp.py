@@ -290,6 +290,67 @@ def test_dp_step_with_syncbn_equals_the_single_device_reference_step(tmp_path, g
     assert rel1(float(r0['total_norm']), float(g['total_norm64'])) < 5e-2
 
 
+def _literal_worker(rank, world, port, name, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import simq
+        from simq.learner import Transition, train_step_dataparallel
+        _, cin, cout, gB, w, wseed, dseed = [c for c in cases.DP_LITERAL_CASES if c[0] == name][0]
+        batch = cases.make_batch(cin, cout, gB, dseed)
+        policy, target = _make_nets(simq, cin, cout, wseed, 'fp32', dev)
+        info = train_step_dataparallel(policy, target, Transition(*batch), cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                                       dist.group.WORLD)
+        g, tn = _unclipped(policy)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), grad=g.numpy(), total_norm=tn, loss=info['loss'], td_error=info['td_error'],
+                 q_sa=policy._last['q_sa'].cpu().numpy(), y=policy._last['y'].cpu().numpy(), best=policy._last['best'].cpu().numpy(),
+                 bn=policy.bn_buffers.cpu().numpy(), params=policy.flat_params.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', [c[0] for c in cases.DP_LITERAL_CASES])
+def test_dataparallel_literal_step_against_reference_replicas(tmp_path, golden_dir, name):
+    """simq.train_step_dataparallel: the double-DQN forward scattered the way nn.DataParallel scatters it -- torch.chunk pieces of the
+    COMPACTED non-final next states, greedy actions exchanged between the ranks -- against tests/golden/dplit_*.npz (the reference's own
+    modules replica by replica, oracle/gen_golden.py dp_literal).  Ranks share the GPU over gloo."""
+    import simq
+    _, cin, cout, gB, world, wseed, dseed = [c for c in cases.DP_LITERAL_CASES if c[0] == name][0]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_literal_worker, args=(r, world, port, name, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert not p.is_alive() and p.exitcode == 0, 'a data-parallel rank failed (exit code %r)' % p.exitcode
+    ranks = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
+    r0 = ranks[0]
+    for r in ranks:
+        assert np.array_equal(r['best'], g['best'])                     # every rank holds the reference's greedy actions
+        assert np.array_equal(r0['params'], r['params']) and np.array_equal(r0['grad'], r['grad'])
+    rel1 = lambda a, b: abs(a - b) / abs(b)
+    assert rel1(float(r0['loss']), float(g['loss'])) < 1e-4 and rel1(float(r0['td_error']), float(g['td_error'])) < 1e-4
+    q_sa, y = np.concatenate([r['q_sa'] for r in ranks]), np.concatenate([r['y'] for r in ranks])
+    assert np.abs(q_sa - g['q_sa']).max() <= 1e-4 * np.abs(g['q_sa']).max()
+    assert np.abs(y - g['y']).max() <= 1e-4 * np.abs(g['y']).max()
+    want, got = g['bn_buffers_after'].astype(np.float64), r0['bn'].astype(np.float64)     # replica 0: state chunk 0, compacted chunk 0
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    err, worst_norm = _sampled_relerr(_reference_layout(simq, cin, cout, r0['grad']), g)
+    print('%s: sampled-gradient rel-L2 error %.3g (reference fp32 replicas: %.3g); slice sharding would give loss %.6g instead of %.6g'
+          % (name, err, float(g['ref_fp32_grad_relerr']), float(g['slice_sharding_loss']), float(g['loss'])))
+    assert err <= max(10 * float(g['ref_fp32_grad_relerr']), 5e-3), err
+    assert rel1(float(r0['total_norm']), float(g['total_norm64'])) < 5e-2
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two MI355X (RCCL refuses two ranks on one device)')
 
 
