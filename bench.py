@@ -292,6 +292,8 @@ def main():
         """nets: [(Cin, Cout)] -- one policy/target pair, optimiser state and replay ring per robot group (train.py:180-195);
         B: this rank's transitions per net and step."""
         gB = B * world
+        if replay_items < gB:
+            sys.exit('bench.py: the replay ring (%d transitions) is smaller than the global minibatch (%d); raise --replay' % (replay_items, gB))
         groups = []
         for gi, (cin, cout) in enumerate(nets):
             # random-init weights of the reference architecture with the reference's own initialisers (resnet.py:70-75,
