@@ -68,7 +68,8 @@ const char* simq_last_error(void);
 /* ---- plan: the network of networks.py:7-14 for (Cin, Cout); replaces FCN.__init__ ---------- */
 int simq_plan_create(int num_input_channels, int num_output_channels, simq_plan** out);   /* SIMQ_PREC_FP32 */
 int simq_plan_create_ex(int num_input_channels, int num_output_channels, int precision, simq_plan** out);
-/* What a plan computes WITH -- which algebraic form, storage precision and fusion each layer uses -- is fixed when the plan is
+/* (replaces networks.FCN.__init__, networks.py:7-14, like simq_plan_create: the reference has one arithmetic -- cuDNN's -- and no such
+ * choice.)  What a plan computes WITH -- which algebraic form, storage precision and fusion each layer uses -- is fixed when the plan is
  * created and is a property of the plan; the library never reads it from the process environment.  Every default below is what the
  * parity tests and the bench run; the other settings exist for A/B measurements and diagnostics and some of them change the
  * round-off of the results (noted per field).  Fill the struct with simq_plan_options_default, change fields, pass it to
@@ -322,7 +323,8 @@ int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w_ohwi, const float* d
                          void* stream);
 int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
                            int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream);
-/* the same with d_slab = simq_conv2d_wgrad_bf16_slab_bytes() of scratch: the image-tile weight-gradient kernel (3x3 on 24x24 maps, Cout %
+/* (the weight-gradient half of loss.backward(), train.py:132, of one nn.Conv2d.)  The same with d_slab =
+ * simq_conv2d_wgrad_bf16_slab_bytes() of scratch: the image-tile weight-gradient kernel (3x3 on 24x24 maps, Cout %
  * 256 == 0, Cin % 32 == 0, >= 2 images per block) then leaves per-block partial tiles there and a second launch adds them in a fixed
  * order (deterministic) instead of fp32 atomics -- the form the plans use.  d_slab = NULL: as simq_conv2d_wgrad_bf16. */
 int64_t simq_conv2d_wgrad_bf16_slab_bytes(void);
