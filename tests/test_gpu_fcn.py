@@ -554,7 +554,7 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     which one is luckier changes per batch, so: median HIP error <= 2 x median reference error, no case beyond 10 x the reference's
     error on that case (or its median), for the pre-clip gradient and for the first parameter update (sampled elements, not
     tensor norms); the second step's loss (which sees the first update) is held to the amplification the reference itself shows.
-    Measured (MI355X): medians 1.6e-3 (HIP) vs 2.0e-3 (reference fp32) for both gradient and update.
+    Measured (MI355X): medians 1.6e-3 .. 2.3e-3 (HIP, run to run) vs 2.0e-3 (reference fp32) for both gradient and update; B = 64: 3.7e-3 vs 2.7e-3.
     Second fixture (grad_study_b64.npz, six seeded batches of 64 = configs[3]'s per-GPU batch, where the fp32 plans pick their large-batch
     tiles and 36-plane Winograd problems): the same bars."""
     from oracle import learner as olearner
