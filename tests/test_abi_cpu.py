@@ -224,3 +224,31 @@ def test_winograd_transform_matrices_are_an_exact_restatement_of_the_convolution
     gf = g[::-1, ::-1]
     full = np.array([[(dyp[i:i + 3, j:j + 3] * gf).sum() for j in range(4)] for i in range(4)])
     assert np.allclose(full, dd_direct, atol=1e-13)
+
+
+def test_plan_options_are_a_property_of_the_plan_and_not_of_the_environment(L, monkeypatch):
+    """include/simq.h simq_plan_options: defaults, round trip through simq_plan_get_options, validation -- and the product library
+    neither reads SIMQ_* environment switches (it is built without SIMQ_ABLATIONS) nor is the ablation build."""
+    assert L.lib.build_flags == 0
+    for name in ('SIMQ_WINOGRAD', 'SIMQ_WINOGRAD_F4_GRAD', 'SIMQ_FP32_ACT_GRADS', 'SIMQ_NO_STEM16'):
+        monkeypatch.setenv(name, '0')                       # would have changed the arithmetic in round 2
+    d = L.Plan(4, 2).options
+    assert d == {'winograd': 1, 'winograd_min_cc': 128 * 128, 'winograd_f4_forward': 1, 'winograd_f4_min_tiles': 256, 'winograd_f4_grad': 2,
+                 'winograd_wgrad': 1, 'winograd_wgrad_f4': 1, 'stem_bf16': 1, 'bf16_act_grads': 1, 'keep_fp32_activations': 0,
+                 'fold_eval_bn_bf16': 1, 'fuse_bn_backward_sums': 1, 'fuse_stem_backward_sums': 1}
+    p = L.Plan(5, 1, 'bf16', options={'stem_bf16': 0, 'keep_fp32_activations': 1})
+    assert p.options['stem_bf16'] == 0 and p.options['keep_fp32_activations'] == 1 and p.options['winograd'] == 1
+    # the Winograd weight cache exists only when the option is on: the option changes the plan, not a global
+    assert L._c.simq_wcache_bytes(L.Plan(4, 2, options={'winograd': 0}).handle) < L._c.simq_wcache_bytes(L.Plan(4, 2).handle)
+    with pytest.raises(L.SimqError):
+        L.Plan(4, 2, options={'winograd_f4_grad': 3})
+    with pytest.raises(L.SimqError):
+        L.Plan(4, 2, options={'not_an_option': 1})
+    o = L.PlanOptions()
+    L._c.simq_plan_options_default(ctypes.byref(o))
+    o.struct_bytes = 8                                      # a caller compiled against another struct
+    h = ctypes.c_void_p()
+    assert L._c.simq_plan_create_opts(4, 2, 0, ctypes.byref(o), ctypes.byref(h)) != 0 and b'struct_bytes' in L._c.simq_last_error()
+    # the library binary carries no SIMQ_* switch names
+    blob = open(L.LIB_PATH, 'rb').read()
+    assert blob.count(b'SIMQ_WINOGRAD') == 0 and blob.count(b'SIMQ_BF16_') == 0 and blob.count(b'_DBG') == 0
