@@ -101,8 +101,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// DBG (timing ablations, libsimq_ablate.so only; results are wrong by construction): 1 no DMA in the loop, 8 no fragment reads, 16 no MFMAs,
-// 32 no atomics
+// DBG (timing ablations, libsimq_ablate.so only; results are wrong by construction): 1 no DMA in the loop, 8 no fragment reads, 16 no MFMAs
+// (compile time); p.dbg (run time): 32 no stores / atomics, 64 no main loop
 template <int DBG>
 __global__ void __launch_bounds__(NW * 64, 2) wgrad_bf16_img_kernel(const WgradImgArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -357,6 +357,7 @@ int try_conv_wgrad_bf16_img(const uint16_t* x, const uint16_t* dy, float* dw, co
                             hipStream_t stream, float* slab) {
     if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.Hin != HW || g.Win != HW || g.Hout != HW || g.Wout != HW) return 0;
     if (g.Cin % TJ != 0 || g.Cout % TI != 0) return 0;
+    if (g.Cin > 896) return 0;                           // (the patch-offset table holds image-relative byte offsets / 16 in 16 bits, 0xFFFF = halo)
     if (SIMQ_TUNE_INT("SIMQ_BF16_WGRAD_IMG", 1) == 0) return 0;
     WgradImgArgs p;
     p.x = x; p.dy = dy; p.dw = dw; p.Cin = g.Cin; p.Cout = g.Cout; p.K = g.K(); p.B = g.B;
