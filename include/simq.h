@@ -298,6 +298,10 @@ int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const flo
  * the operands gathered straight from the fp32 NHWC input -- the form plain-bf16 plans use (stem_conv_bf16.hip).  7 * cin <= 63,
  * win a multiple of 32, hin even.  d_y: bf16 [batch][hin/2][win/2][64] (pre-BatchNorm, rounded once from the fp32 accumulators);
  * d_stats: NULL or [2*64] zeroed (sum | sum of squares of the UNROUNDED outputs); d_scratch: 58 368 bytes (bf16 weight layout). */
+/* ... and in exact fp32 (v_mfma_f32_16x16x4_f32 fed by 16-byte runs of the NHWC input; what fp32 / split-bf16 plans run): 7 * cin <= 64,
+ * win a multiple of 32, hin even.  d_y: fp32 [batch][hin/2][win/2][64]; d_stats: NULL or [2*64] zeroed (sum | sum of squares). */
+int simq_conv2d_fwd_stem_f32(const float* d_x, const float* d_w_ohwi, float* d_y, int batch, int hin, int win, int cin, double* d_stats,
+                             void* stream);
 int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w_ohwi, uint16_t* d_y, int batch, int hin, int win, int cin,
                               double* d_stats, void* d_scratch, void* stream);
 /* Weight gradient of that convolution from the bf16 plane of dy (bf16 [batch][hin/2][win/2][64]): both operands staged transposed in

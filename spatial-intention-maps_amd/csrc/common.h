@@ -167,6 +167,9 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 // dz[b,y,x,c] (pre-relu BN output grad at HxW) from pooled-grad g at (H/2)x(W/2)
 // first convolution on the bf16 matrix cores, operands gathered straight from the fp32 NHWC input (stem_conv_bf16.hip)
 int stem_conv_bf16_wbytes();
+// stem_conv_f32.hip: the same convolution in exact fp32 on the matrix cores (fp32 / split-bf16 plans), weights straight from the OHWI parameters
+bool stem_conv_f32_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
+int launch_stem_conv_f32(const float* x, const float* w_ohwi, float* y, double* stats, int B, int H, int W, int C, hipStream_t stream);
 bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
 int launch_stem_weight_prep(const float* w, uint16_t* w16, int C, hipStream_t stream);
 int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, double* stats, int B, int H, int W, int C, hipStream_t stream);

@@ -404,6 +404,11 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(launch_stem_conv_bf16(x0.f, reinterpret_cast<const uint16_t*>(c.wc + c.W.stem16), reinterpret_cast<uint16_t*>(c.f(L.y0)),
                                  mode != SIMQ_MODE_EVAL ? c.red(p->stem_bn) : nullptr, B, 96, 96, p->cin, c.stream));
         if (mode != SIMQ_MODE_EVAL) RC(c.sync_reduce(c.red(p->stem_bn), 2 * (int64_t)p->stem_bn.C));
+    } else if (stem_conv_f32_eligible(96, 96, p->cin, p->stem.cout, p->stem.k, p->stem.stride, p->stem.pad)) {
+        // fp32 / split-bf16 plans: exact-fp32 matrix-core kernel fed by 16-byte runs of the NHWC input (stem_conv_f32.hip)
+        RC(launch_stem_conv_f32(x0.f, c.params + p->stem.w_off, c.f(L.y0), mode != SIMQ_MODE_EVAL ? c.red(p->stem_bn) : nullptr, B, 96, 96,
+                                p->cin, c.stream));
+        if (mode != SIMQ_MODE_EVAL) RC(c.sync_reduce(c.red(p->stem_bn), 2 * (int64_t)p->stem_bn.C));
     } else {
         RC(conv_bn(c, p->stem, p->stem_bn, mode, x0, c.f(L.y0), 96));
     }
@@ -1156,6 +1161,12 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_conv2d_fwd_stem_f32(const float* d_x, const float* d_w, float* d_y, int batch, int hin, int win, int cin, double* d_stats, void* stream) {
+    SIMQ_REQUIRE(d_x && d_w && d_y && batch >= 1, "conv2d_fwd_stem_f32: bad argument");
+    SIMQ_REQUIRE(stem_conv_f32_eligible(hin, win, cin, 64, 7, 2, 3), "conv2d_fwd_stem_f32: geometry not supported (7 * cin <= 64, win %% 32 == 0)");
+    return launch_stem_conv_f32(d_x, d_w, d_y, d_stats, batch, hin, win, cin, static_cast<hipStream_t>(stream));
 }
 
 int simq_conv2d_fwd_stem_bf16(const float* d_x, const float* d_w, uint16_t* d_y, int batch, int hin, int win, int cin, double* d_stats,

@@ -120,6 +120,7 @@ _SIGS = {
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_fwd_stem_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_wgrad_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'simq_forward_sync': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

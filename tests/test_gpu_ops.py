@@ -541,6 +541,34 @@ def test_conv_winograd_rejects_unsupported_geometry(L):
         L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(y), L.ptr(w), 1, 24, 24, 64, 64, L.ptr(scratch), L.stream_ptr())
 
 
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1), (32, 4), (2, 7)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1', 'cin4_b32', 'cin7'])
+def test_stem_conv_f32_matches_an_fp64_convolution(L, B, C):
+    """stem_conv_f32.hip (reference resnet.py:94: conv 7x7 s2 p3 -> 64, the form fp32 / split-bf16 plans run): 16-byte runs of the NHWC
+    input straight into v_mfma_f32_16x16x4_f32 (the K index of the MFMA permuted consistently on both operands), left / right / top / bottom
+    padding by masks, weights from the OHWI parameters.  Exact fp32 FMA chains: the fp32 bar (1e-4; measured ~1e-6) against an fp64
+    convolution; batch statistics 1e-5.  Large values on every image edge so that a wrong padding mask cannot hide."""
+    g = torch.Generator().manual_seed(43 + 7 * C + B)
+    x = torch.randn(B, 96, 96, C, generator=g)
+    x[:, 0, :, :] += 3.0; x[:, -1, :, :] -= 3.0; x[:, :, 0, :] += 5.0; x[:, :, -1, :] -= 5.0
+    w = torch.randn(64, 7, 7, C, generator=g) * (2.0 / (49 * C)) ** 0.5
+    xd, wd = x.cuda(), w.cuda()
+    y = torch.full((B, 48, 48, 64), float('nan'), device='cuda')
+    stats = torch.zeros(128, dtype=torch.float64, device='cuda')
+    L.lib.call('simq_conv2d_fwd_stem_f32', L.ptr(xd), L.ptr(wd), L.ptr(y), B, 96, 96, C, L.ptr(stats), L.stream_ptr())
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, stride=2, padding=3).permute(0, 2, 3, 1)
+    got = y.double().cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print('\nstem fp32 C=%d B=%d: max error vs fp64 %.3g of the output range' % (C, B, err))
+    assert err < 1e-5
+    sref = torch.cat([ref.reshape(-1, 64).sum(0), (ref * ref).reshape(-1, 64).sum(0)])
+    assert rel(stats.cpu(), sref) < 1e-5
+    # no statistics requested (eval mode): same outputs
+    y2 = torch.empty_like(y)
+    L.lib.call('simq_conv2d_fwd_stem_f32', L.ptr(xd), L.ptr(wd), L.ptr(y2), B, 96, 96, C, None, L.stream_ptr())
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1'])
 def test_stem_conv_bf16_matches_a_bf16_operand_convolution(L, B, C):
     """stem_conv_bf16.hip (reference resnet.py:94: conv 7x7 s2 p3 -> 64, the form plain-bf16 plans run): fragments gathered straight from
