@@ -168,6 +168,8 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 // first convolution on the bf16 matrix cores, operands gathered straight from the fp32 NHWC input (stem_conv_bf16.hip)
 int stem_conv_bf16_wbytes();
 // stem_conv_f32.hip: the same convolution in exact fp32 on the matrix cores (fp32 / split-bf16 plans), weights straight from the OHWI parameters
+// conv_img_f32.hip: image-tile fp32 3x3 convolution of the 64-input-channel layers; 1 = taken, 0 = shape not covered, < 0 error
+int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e, hipStream_t stream);
 bool stem_conv_f32_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
 int launch_stem_conv_f32(const float* x, const float* w_ohwi, float* y, double* stats, int B, int H, int W, int C, hipStream_t stream);
 bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad);

@@ -565,6 +565,9 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     const bool vec = (g.Cin % BK) == 0 && g.R * g.S <= 32;   // vector path: 16-channel chunks, tap validity kept as a 32-bit mask
     SIMQ_REQUIRE(vec || g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);
     int bm = 0, bn = 0;
+    if (!forced_tile(&bm, &bn)) {        // the 64-input-channel 3x3 layers on the 24x24 maps: image-tile kernel (conv_img_f32.hip)
+        if (int rc = try_conv_img_f32(x, w, y, g, e, stream)) return rc < 0 ? rc : 0;
+    }
     if (!forced_tile(&bm, &bn) || g.Cout % bn != 0 || (!vec && !(bn == 64 && (bm == 128 || bm == 64 || bm == 32)))) {
         double best = 1e300;
         for (const TileCfg& t : kMenu) {

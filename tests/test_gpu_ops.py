@@ -454,6 +454,40 @@ def test_conv_fp32_balanced_last_round(L, B, H):
     assert rel(y1, ref) < 1e-4
 
 
+@pytest.mark.parametrize('B,Cout,bias', [(1, 64, False), (3, 128, True), (32, 64, False), (29, 64, True)], ids=['b1', 'b3_to128_bias', 'b32', 'b29_bias'])
+def test_conv_fp32_image_tile_kernel_matches_implicit_gemm(L, B, Cout, bias):
+    """conv_img_f32.hip (three image rows x 64 output channels per block, halo patch in LDS) serves the 3x3 convolutions with 64 input
+    channels on the 24x24 maps; the implicit-GEMM kernel (forced 32x32 tile) computes the same exact-fp32 FMA products in another
+    order.  Output + fused bias + batch statistics against each other and against the fp64 convolution; borders carry large values
+    so that a wrong halo shows."""
+    Cin, k, H = 64, 3, 24
+    g = torch.Generator().manual_seed(4321 + B + Cout)
+    x = torch.randn(B, H, H, Cin, generator=g)
+    x[:, 0, :, :] *= 8.0; x[:, -1, :, :] *= 8.0; x[:, :, 0, :] *= 8.0; x[:, :, -1, :] *= 8.0
+    x = x.cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() if bias else None
+    st = L.stream_ptr()
+    outs = []
+    try:
+        for tile in ((0, 0), (32, 32)):
+            L.lib.call('simq_tune_force_tile', *tile)
+            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st)
+            outs.append((y, stats))
+    finally:
+        L.lib.call('simq_tune_force_tile', 0, 0)
+    (y0, s0), (y1, s1) = outs
+    assert torch.isfinite(y0).all()
+    assert rel(y0, y1) < 5e-6 and rel(s0, s1) < 1e-6
+    assert not torch.equal(y0, y1)                           # the image-tile kernel really ran (different summation order)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double() if bias else None, padding=1).permute(0, 2, 3, 1)
+    assert rel(y0, ref) < 2e-6
+    s_ref = ref.reshape(-1, Cout)
+    assert rel(s0[:Cout], s_ref.sum(0)) < 1e-5 and rel(s0[Cout:], (s_ref * s_ref).sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 12, 128, 256), (2, 8, 64, 64), (7, 24, 128, 128)],
                          ids=['l4', 'l4a', 'l3a_small_map', 'narrow', 'l2'])
 def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
