@@ -19,6 +19,8 @@ from oracle import cases
 from oracle import fcn as ofcn
 from simq import synth
 
+import step2_oracle
+
 pytestmark = pytest.mark.gpu
 
 
@@ -220,7 +222,11 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
         if g['grad64'][i][0] > 1e-3 * float(g['total_norm64']):          # tensors that carry gradient mass
             assert abs(mine[0] - g['grad64'][i][0]) <= 5e-2 * g['grad64'][i][0], k
     assert (num / den) ** 0.5 <= 5e-2, 'sampled-gradient rel-L2 error %.3g (reference fp32 itself: %.3g)' % ((num / den) ** 0.5, float(g['ref_fp32_grad_relerr']))
+    sd1, sd_target = step2_oracle.snapshot(policy), step2_oracle.snapshot(target)
     info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    # the second call per transition at 1e-4 against the fp64 oracle run from the HIP path's own post-step-1 state
+    # (tests/step2_oracle.py); against the golden trajectory -- chaotic on these synthetic problems -- only a sanity bound
+    step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)
     assert rel1(info2['loss'], float(g['loss'][1])) < 0.1 and rel1(info2['td_error'], float(g['td_error'][1])) < 0.1
     sd = policy.state_dict()
     assert all(int(sd[k]) == 4 for k in sd if k.endswith('num_batches_tracked'))

@@ -14,7 +14,7 @@ Bars:
          reference's own fp32 makes on the same elements (measured 1.2 x, 2.4 x, 2.1 x: 2.6e-3 / 2.9e-3 / 5.0e-3 against the reference's
          2.2e-3 / 1.2e-3 / 2.4e-3 -- single batches; the distribution over 13 batches is tests/test_gpu_fcn.py's gradient study);
          gradient norm 1e-3 (measured 1e-5 .. 5e-5); the second step per transition (q_sa, TD targets) at 1e-4 against the fp64 oracle run
-         from the HIP path's own post-step-1 state (second_step_against_the_oracle: the loss against the fp64 trajectory is chaotic,
+         from the HIP path's own post-step-1 state (tests/step2_oracle.py: the loss against the fp64 trajectory is chaotic,
          2-7 % between fp32 summation orders on the b64 fixture); post-second-step parameter norms 1e-4; BatchNorm buffers 1e-4 after step 1
          (against fp64), 5e-3 after step 2 (they have seen the first update).
   bf16   against fp64, calibrated by the reference under bf16 autocast AT THIS SIZE (the fixture's bf16cal_* fields): loss, td error,
@@ -44,6 +44,8 @@ from oracle import cases
 from oracle import fcn as ofcn
 from oracle import learner as olearner
 from simq import synth
+
+import step2_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -98,8 +100,7 @@ def run_two_steps(simq_mod, case, precision, profile=False):
     bnvec = lambda sd_: np.concatenate([sd_[k].detach().double().cpu().numpy().ravel() for k in sd_
                                         if k.endswith('running_mean') or k.endswith('running_var')])
     bn1 = bnvec(policy.state_dict())
-    sd1 = {k: v.detach().clone().cpu() for k, v in policy.state_dict().items()}
-    sd_target = {k: v.detach().clone().cpu() for k, v in target.state_dict().items()}
+    sd1, sd_target = step2_oracle.snapshot(policy), step2_oracle.snapshot(target)
     info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
     q_sa2, y2 = policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy()
     gs, ds = [], []
@@ -112,46 +113,8 @@ def run_two_steps(simq_mod, case, precision, profile=False):
     bn = bnvec(sd)
     return dict(info=[info1, info2], total_norm=tn, grad=np.stack(gs), dparam=np.stack(ds), gnorm=np.array([float(t.norm()) for t in grads]),
                 q_sa=q_sa, y=y, p2_l2=np.array([float(t.norm()) for t in p2]), bn=bn, bn1=bn1, kinds=kinds,
-                sd1=sd1, sd_target=sd_target, q_sa2=q_sa2, y2=y2,
+                sd1=sd1, sd_target=sd_target, q_sa2=q_sa2, y2=y2, batch=batch,
                 nbt=[int(sd[k]) for k in sd if k.endswith('num_batches_tracked')])
-
-
-def second_step_against_the_oracle(r, case, tol=1e-4):
-    """The SECOND train() call checked as what it is: one evaluation of train.py:114-129 from the state the first call left.  The fp64
-    oracle runs the three forwards from the HIP path's own post-step-1 state dict (parameters + buffers) on the fixture's batch;
-    q_sa and the TD targets of the second HIP step must match it per transition.  A TD target may differ only through a TIE of the
-    double-DQN greedy action (train.py:121): then the HIP value must be the target net's value at an action whose policy value is
-    within `tol` of the maximum.  (Comparing the second loss with the fp64 TRAJECTORY instead measures the chaos of the synthetic
-    problem, not the implementation: with nothing but the fp32 summation order of the convolutions changed -- the tile menu forced to
-    32x32 / 64x64 / 96x64 -- the b64 fixture's second loss moves by 2.2 .. 7.0 % of itself, tests/diag_step2_sensitivity.py.)
-    Returns (q error, worst TD-target error over the non-tied transitions, number of tied transitions)."""
-    name, cin, cout, B, wseed, dseed = case
-    batch = cases.make_batch(cin, cout, B, dseed)
-    f64 = lambda sd: {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
-    st, tg = f64(r['sd1']), f64(r['sd_target'])
-    state_b = torch.cat([olearner.apply_transform(s) for s in batch.state]).double()
-    act = torch.tensor(batch.action, dtype=torch.long)
-    rew = torch.tensor(batch.reward, dtype=torch.float64)
-    nf = torch.cat([olearner.apply_transform(s) for s in batch.next_state if s is not None]).double()
-    mask = np.array([s is not None for s in batch.next_state])
-    with torch.no_grad():
-        q = ofcn.fcn_forward(st, state_b, True).reshape(B, -1).gather(1, act.unsqueeze(1)).squeeze(1).numpy()
-        qp = ofcn.fcn_forward(st, nf, True).reshape(nf.size(0), -1).numpy()
-        qt = ofcn.fcn_forward(tg, nf, False).reshape(nf.size(0), -1).numpy()
-    e_q = float(np.abs(r['q_sa2'] - q).max() / np.abs(q).max())
-    v_hip = (r['y2'].astype(np.float64) - rew.numpy()) / cases.GAMMA
-    assert np.abs(v_hip[~mask]).max(initial=0.0) < 1e-6                      # terminal transitions: y = reward
-    best = qp.argmax(1)
-    v_or = qt[np.arange(len(best)), best]
-    scale_t, scale_p = np.abs(qt).max(), np.abs(qp).max()
-    err = np.abs(v_hip[mask] - v_or) / scale_t
-    ties = 0
-    for j in np.nonzero(err > tol)[0]:
-        cand = np.nonzero(np.abs(qt[j] - v_hip[mask][j]) <= tol * scale_t)[0]
-        assert len(cand) and (qp[j, cand] >= qp[j].max() - tol * scale_p).any(), \
-            'transition %d: TD target off by %.3g and not a tie of the greedy action' % (j, err[j])
-        ties += 1
-    return e_q, float(err[err <= tol].max(initial=0.0)), ties
 
 
 @pytest.mark.parametrize('case', cases.TRAIN_CASES_SIZED, ids=[c[0] for c in cases.TRAIN_CASES_SIZED])
@@ -176,13 +139,8 @@ def test_fp32_step_at_config_size_matches_the_reference(simq_mod, golden_dir, ca
     assert e['norm'] < 1e-3 and e['tensor_norms'] < 2e-2
     # the second step: per transition against the fp64 oracle started from the HIP path's own post-step-1 state, and the reported
     # loss against the Huber loss of those per-transition values (the loss against the fp64 TRAJECTORY is printed above only)
-    e_q2, e_y2, ties = second_step_against_the_oracle(r, case)
-    d = r['q_sa2'].astype(np.float64) - r['y2'].astype(np.float64)
-    huber = float(np.where(np.abs(d) < 1.0, 0.5 * d * d, np.abs(d) - 0.5).mean())
-    print('[%s fp32] step 2 against the oracle from the post-step-1 state: q_sa %.2g, TD targets %.2g (%d greedy-action ties), '
-          'loss vs Huber(q, y) %.2g' % (case[0], e_q2, e_y2, ties, abs(r['info'][1]['loss'] - huber) / huber))
-    assert e_q2 < 1e-4 and e_y2 <= 1e-4 and ties <= 2
-    assert abs(r['info'][1]['loss'] - huber) <= 1e-5 * huber
+    e_q2, e_y2, ties = step2_oracle.second_step_against_the_oracle(r['sd1'], r['sd_target'], r['batch'], r['q_sa2'], r['y2'], r['info'][1])
+    print('[%s fp32] step 2 against the oracle from the post-step-1 state: q_sa %.2g, TD targets %.2g (%d greedy-action ties)' % (case[0], e_q2, e_y2, ties))
     assert relmax(r['p2_l2'], g['param_summary_after2'][:, 1]) < 1e-4
     # running statistics: after the FIRST step (two train-mode forwards of the unmodified parameters) 1e-4 against fp64; after the
     # second they have seen the first update, whose fp32 error differs between implementations (the reference's included)
