@@ -247,6 +247,9 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.M % BM != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_IMG", 1);   // 0 = off
     if (mode == 0) return 0;
+#ifdef SIMQ_ABLATIONS      // SIMQ_BF16_IMG=2: the four-wave form (conv_igemm_bf16_img4.hip; measured slower) exists in libsimq_ablate.so only
+    if (mode == 2) { if (int rc = try_conv_igemm_bf16_img4(a, stream)) return rc; }
+#endif
     int fbm = 0, fbn = 0;
     const bool forced = tune_forced_tile(&fbm, &fbn);
     if (forced && !(fbm == BM && fbn == BN)) return 0;
