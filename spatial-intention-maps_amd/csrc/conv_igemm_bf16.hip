@@ -314,6 +314,10 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     // plain bf16: 64-deep K stages (two MFMA k-steps per barrier) whenever the channel count allows; split-bf16 keeps 32
     if (nplanes == 2) return dispatch<2, 32>(bm, bn, a, stream);
     {
+        const int took = try_conv_igemm_bf16_c64(a, stream);      // 64-input-channel 3x3 layers of large batches: both operands resident in LDS
+        if (took != 0) return took < 0 ? took : 0;
+    }
+    {
         const int took = try_conv_igemm_bf16_img(a, stream);      // 3x3 layers on the 24 x 24 maps: image-tile kernel with a halo patch in LDS
         if (took != 0) return took < 0 ? took : 0;
     }

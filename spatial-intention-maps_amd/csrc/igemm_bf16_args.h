@@ -26,6 +26,9 @@ int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream);
 
 // conv_igemm_bf16_img.hip: one 24 x 24 image x 128 output channels per block, halo patch staged once per channel chunk
 int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream);
+// conv_igemm_bf16_c64.hip: 64-input-channel 3x3 layers, half an image x 64 channels per block, both operands resident in LDS
+int try_conv_igemm_bf16_c64(const IgemmBfArgs& a, hipStream_t stream);
+
 // conv_igemm_bf16_img4.hip: the same block tile with four waves of 144 x 128 (one per SIMD, fragments double-buffered in registers)
 int try_conv_igemm_bf16_img4(const IgemmBfArgs& a, hipStream_t stream);
 

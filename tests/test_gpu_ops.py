@@ -313,16 +313,18 @@ def test_conv_bf16_register_staged_wgrad_at_config_batch_sizes(L, B, Cin, Cout):
 
 
 @pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256)),
-                                             (7, 64, 64, (144, 64)), (128, 256, 256, (576, 128)), (128, 64, 64, (144, 64))],
+                                             (7, 64, 64, (144, 64)), (128, 256, 256, (576, 128)), (128, 64, 64, (144, 64)),
+                                             (7, 64, 64, (288, 64)), (3, 64, 128, (288, 64)), (128, 64, 64, (288, 64))],
                          ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged', 'dma_144x64_layer1',
-                              'image_tile_l3_b128', 'dma_144x64_layer1_b128'])
+                              'image_tile_l3_b128', 'dma_144x64_layer1_b128', 'resident_c64_b7', 'resident_c64_to128_b3', 'resident_c64_b128'])
 def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile):
     """The two ping-pong bf16 kernels of the 3x3 layers on the 24x24 maps -- conv_igemm_bf16_img.hip (tile "576x128": one image x 128
     channels per block, halo patch staged once per 32-channel chunk, nine taps read shifted fragments) and conv_igemm_bf16_pp.hip
     (288x256 implicit-GEMM tile, 4-stage LDS-DMA ring) -- against the register-staged kernel on the same bf16 operands: same
     products, fp32 accumulation in a different K order, so outputs agree to fp32 round-off; bias + batch statistics through the
-    staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile.  Last case: the 144 x 64
-    LDS-DMA tile large-batch plans use for the 64-channel layer1 (conv_igemm_bf16_dma.hip)."""
+    staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile.  "144 x 64": the LDS-DMA tile of
+    the 64-channel layer1 (conv_igemm_bf16_dma.hip); "288 x 64": conv_igemm_bf16_c64.hip, which large-batch plans use for the
+    64-input-channel layers instead (half an image x 64 channels per block, patch and all nine taps of the weights resident in LDS)."""
     H, k = 24, 3
     g = torch.Generator().manual_seed(11 + Cin + Cout + B)
     x = torch.randn(B, H, H, Cin, generator=g).cuda()

@@ -10,7 +10,7 @@ os.environ.setdefault('SIMQ_LIBRARY', os.path.join(ROOT, 'spatial-intention-maps
 import torch
 from simq import _lib as L
 
-SHAPES = {'l4': (24, 512, 512, 3), 'l3': (24, 256, 256, 3), 'l3a': (24, 128, 256, 3), 'l4a': (24, 256, 512, 3), 'l4b': (24, 512, 256, 3)}
+SHAPES = {'l2': (24, 128, 128, 3), 'l4': (24, 512, 512, 3), 'l3': (24, 256, 256, 3), 'l3a': (24, 128, 256, 3), 'l4a': (24, 256, 512, 3), 'l4b': (24, 512, 256, 3)}
 st = L.stream_ptr()
 
 
