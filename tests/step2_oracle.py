@@ -31,6 +31,16 @@ def second_step_against_the_oracle(sd1, sd_target, batch, q_sa2, y2, info2, tol=
     rew = np.asarray(batch.reward, np.float64)
     nf = torch.cat([olearner.apply_transform(s) for s in batch.next_state if s is not None]).double()
     mask = np.array([s is not None for s in batch.next_state])
+    # (the GPU box's host reports 256 CPUs; MKL-DNN is at its best around 32 threads there and many times slower with all of them)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))
+    try:
+        return _second_step(st, tg, state_b, act, rew, nf, mask, B, q_sa2, y2, info2, tol, max_ties, double_dqn)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _second_step(st, tg, state_b, act, rew, nf, mask, B, q_sa2, y2, info2, tol, max_ties, double_dqn):
     with torch.no_grad():
         q = ofcn.fcn_forward(st, state_b, True).reshape(B, -1).gather(1, act.unsqueeze(1)).squeeze(1).numpy()
         qp = ofcn.fcn_forward(st, nf, True).reshape(nf.size(0), -1).numpy() if double_dqn else None
