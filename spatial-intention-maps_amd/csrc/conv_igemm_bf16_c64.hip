@@ -15,6 +15,11 @@
 // the 16-pixel tiles that wrap an image row lose two lanes to conflicts.  A DMA piece is 1 KB of that padded array: every lane
 // works out which (row, 16-byte slot) its 16 bytes are -- the pad slots and the patch border carry an out-of-range offset (zero fill).
 // 4 waves = 2 (pixel halves: nine 16-pixel tiles) x 2 (32 output channels): 18 accumulator tiles, 11 fragment reads per 18 MFMAs.
+// Measured (tools/c64_check.py, B = 128, 64 -> 64, per launch through the profiler's event pairs): 19.1 us against 26.1 (144 x 64 LDS-DMA
+// tile); 64 -> 128: 31.6 | 42.4.  Where the 19 us go (a throw-away build with runtime switches): an empty kernel with this LDS footprint
+// 6.7; + staging alone 0.8, + K loop alone 2.0, + epilogue alone 4.3; staging + K loop together 5.9 (12.6 - 6.7) -- one block per CU:
+// nothing overlaps the three phases, and the 64-byte row segments of the 144 x 32 wave tiles make the epilogue the longest of them.
+// Starting every block's weight staging at a different piece (L2 channel camping on the shared 83 KB) changed nothing.
 // Arithmetic: v_mfma_f32_16x16x32_bf16 on the same bf16 operands as the other plain-bf16 kernels, fp32 accumulation, K order (tap,
 // channel); epilogue igemm_epilogue.h (staged form).
 #include <cstdlib>
