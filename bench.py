@@ -321,17 +321,17 @@ def main():
 
         def step():
             # train.py:252-258: per robot group one minibatch draw (host-side picks + index upload + HBM gather) and one train().
-            # The draw a group needs NEXT step is issued while this step's kernels run and BEFORE its loss is read back (the
-            # reference's .item() sync), so the host-side sampler is hidden behind the GPU instead of idling it; picks, their
-            # order per group and the work per step are unchanged (the replay ring is static during the benchmark).
+            # train_step returns the loss as train.py:137-139 does (loss.item()), but waits only for the copy of the four sums the
+            # library issues right behind the TD / Huber launch -- not for backward + SGD -- so the draw and the launches of the next
+            # step are enqueued while this step still runs (a full stream synchronisation per step left the device idle for 70-90 us
+            # at every step boundary: tools/idle_gaps.sh).  Picks, their order per group and the work per step are unchanged; the
+            # timed region ends with a device synchronisation.
             info = None
             for g in groups:
                 batch = g['drawn'] if g['drawn'] is not None else draw(g)
-                out4 = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
-                                  opt_state=g['opt'], process_group=pg, global_batch=gB, sync=False, comm=comm)
+                info = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
+                                  opt_state=g['opt'], process_group=pg, global_batch=gB, sync=True, comm=comm)
                 g['drawn'] = draw(g)
-                o = out4.tolist()                                   # train.py:138-139
-                info = {'td_error': o[1] / gB, 'loss': o[0] / gB}
                 if not np.isfinite(info['loss']):
                     sys.exit('bench: non-finite loss %r' % (info,))
             return info

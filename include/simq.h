@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 300            /* 0.3.0 */
+#define SIMQ_VERSION 301            /* 0.3.1 */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -240,8 +240,14 @@ typedef struct simq_train_args {
                                   * summed over the ranks while layers 3..1 + stem are still being differentiated, then the rest
                                   * and out4; every rank applies the identical clip + SGD.  num_nonfinal may then be 0 (a shard
                                   * whose transitions are all terminal still has to join the collectives). */
+    float* loss_host;            /* NULL, or 4 floats of PINNED host memory: out4 is copied there as soon as it is final (behind the
+                                  * TD / Huber launch -- behind the all-reduce with `comm`), on the library's own copy stream.  The
+                                  * host then calls simq_train_loss_wait() instead of synchronising the stream: train.py:137-139's
+                                  * loss.item() without waiting for backward + SGD, so that the next step is enqueued while this one runs */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
+/* blocks until the loss_host copy of the calling thread's last simq_train_step on the current device has landed */
+int simq_train_loss_wait(void);
 
 /* ---- gradient exchange between data-parallel ranks (replaces the reduce-add of nn.DataParallel, policies.py:39) --------------
  * One process per GPU; RCCL (librccl.so.1, bound at run time) over xGMI.  Rank 0 obtains a SIMQ_COMM_ID_BYTES identifier and

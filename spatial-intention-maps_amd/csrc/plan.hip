@@ -996,6 +996,45 @@ int simq_backward(const simq_plan* plan, int batch, const float* d_params, const
     return simq_backward_phase(plan, batch, d_params, d_wcache, d_dq, d_grads, d_workspace, 0, stream);
 }
 
+namespace {
+// out4 -> pinned host memory without a stream synchronisation: per device and host thread one copy stream + two events
+struct LossCopy { hipStream_t copy = nullptr; hipEvent_t ready = nullptr, done = nullptr; bool pending = false; };
+thread_local LossCopy g_loss_copy[64];
+
+int loss_copy(const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream) {
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+    LossCopy& c = g_loss_copy[dev];
+    if (!c.copy) {
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
+    hipStream_t s = producer;
+    if (own_stream) {                       // the copy must not queue behind the backward pass that follows on `producer`
+        SIMQ_CHECK_HIP(hipEventRecord(c.ready, producer));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(c.copy, c.ready, 0));
+        s = c.copy;
+    }
+    SIMQ_CHECK_HIP(hipMemcpyAsync(h_out4, d_out4, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+    SIMQ_CHECK_HIP(hipEventRecord(c.done, s));
+    c.pending = true;
+    return 0;
+}
+}  // namespace
+
+int simq_train_loss_wait(void) {
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_loss_wait: device index %d out of range", dev);
+    LossCopy& c = g_loss_copy[dev];
+    SIMQ_REQUIRE(c.pending, "train_loss_wait: no simq_train_step with loss_host on this thread and device");
+    SIMQ_CHECK_HIP(hipEventSynchronize(c.done));
+    c.pending = false;
+    return 0;
+}
+
 int simq_train_step(const simq_train_args* a) {
     SIMQ_REQUIRE(a && a->plan, "train_step: NULL argument");
     SIMQ_REQUIRE(a->params && a->wcache && a->bnbuf && a->grads && a->momentum_buf && a->ws_train && a->ws_tmp && a->t_params &&
@@ -1061,6 +1100,7 @@ int simq_train_step(const simq_train_args* a) {
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
+    if (a->loss_host && !a->comm) RC(loss_copy(a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         return simq_backward_sync(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync);
@@ -1077,6 +1117,7 @@ int simq_train_step(const simq_train_args* a) {
         RC(comm_allreduce(a->comm, a->grads, split, SIMQ_COMM_F32, main));
         RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
         RC(comm_wait(a->comm, main));
+        if (a->loss_host) RC(loss_copy(a->out4, a->loss_host, main, false));            // (summed over the ranks)
     }
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135

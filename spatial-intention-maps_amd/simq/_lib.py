@@ -61,7 +61,7 @@ class TrainArgs(ctypes.Structure):
                     't_params', 't_wcache', 't_bnbuf', 't_ws',
                     'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
                     'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
-                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('reserved3_', c_int), ('comm', c_void_p)]
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('reserved3_', c_int), ('comm', c_void_p), ('loss_host', c_void_p)]
 
 
 _SIGS = {
@@ -90,6 +90,7 @@ _SIGS = {
     'simq_backward_phase': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_grad_bucket_split': (c_int64, [c_void_p]),
     'simq_train_step': (c_int, [c_void_p]),
+    'simq_train_loss_wait': (c_int, []),
     'simq_backward_onehot': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

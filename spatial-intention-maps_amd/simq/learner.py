@@ -89,6 +89,39 @@ def assemble_batch(batch, device, allow_all_final=False):
     return DeviceBatch(state, action, reward, next_state, pos, mask)
 
 
+_PACK_RINGS = {}        # device -> [pinned uint8 buffers, events, position]
+
+
+def _upload_packed(device, arrays, slots=4):
+    """numpy arrays -> device tensors of the same dtypes through ONE asynchronous H2D copy out of a small ring of pinned host buffers
+    (a buffer is reused only after the copy that last read it has finished).  Non-CUDA devices: plain copies."""
+    if device.type != 'cuda':
+        return tuple(torch.from_numpy(a).to(device) for a in arrays)
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    total = max(total, 16)
+    ring = _PACK_RINGS.get(device)
+    if ring is None or ring[0][0].numel() < total:
+        ring = _PACK_RINGS[device] = [[torch.empty(max(total, 1 << 16), dtype=torch.uint8).pin_memory() for _ in range(slots)], [None] * slots, 0]
+    bufs, events, i = ring
+    ring[2] = (i + 1) % slots
+    if events[i] is not None:
+        events[i].synchronize()
+    host = bufs[i].numpy()
+    for a, o in zip(arrays, offs):
+        if a.size:
+            host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    devbuf = torch.empty(total, dtype=torch.uint8, device=device)
+    devbuf.copy_(bufs[i][:total], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    events[i] = ev
+    kinds = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
+    return tuple(devbuf[o:o + a.nbytes].view(kinds[a.dtype]) for a, o in zip(arrays, offs))
+
+
 class _DeviceObs:
     """One observation resident in an HBM ring slot, standing where the reference keeps the ndarray itself
     (`random.choice(replay_buffers[i].buffer).state`, train.py:294): converts to the [96,96,C] float32 array on demand
@@ -209,20 +242,22 @@ class DeviceReplayBuffer:
         B = len(recs)
         dev = self.device
         st = stream_ptr(dev)
-        index = torch.tensor([int(r.state) for r in recs], dtype=torch.int64).to(dev, non_blocking=True)
-        state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
-        lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
         mask = [r.next_state is not None for r in recs]
         nf = [int(r.next_state) for r in recs if r.next_state is not None]
         if not nf and not allow_all_final:
             raise SimqError('sample: no non-final next state in the batch (train.py:112 would raise)')
+        # the five small per-batch arrays travel as ONE asynchronous copy out of pinned memory: a copy from pageable memory makes the
+        # host wait for everything already on the stream -- the whole previous step -- and the device then idles while the host
+        # issues the rest (kernel trace: a 70-80 us hole between two copy kernels at the start of every step)
+        index, nindex, action, reward, pos = _upload_packed(dev, (
+            np.asarray([int(r.state) for r in recs], np.int64), np.asarray(nf, np.int64),
+            np.asarray([r.action for r in recs], np.int64), np.asarray([r.reward for r in recs], np.float32),
+            np.asarray([i for i, m in enumerate(mask) if m], np.int32)))
+        state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
+        lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
         next_state = torch.empty((len(nf), W, W, self.C), dtype=torch.float32, device=dev)
         if nf:
-            nindex = torch.tensor(nf, dtype=torch.int64).to(dev, non_blocking=True)
             lib.call('simq_replay_gather', ptr(self.next_states), self.item, ptr(nindex), len(nf), ptr(next_state), st)
-        action = torch.tensor([r.action for r in recs], dtype=torch.long).to(dev, non_blocking=True)
-        reward = torch.tensor([r.reward for r in recs], dtype=torch.float32).to(dev, non_blocking=True)
-        pos = torch.tensor([i for i, m in enumerate(mask) if m], dtype=torch.int32).to(dev, non_blocking=True)
         return DeviceBatch(state, action, reward, next_state, pos, mask)
 
     def sample(self, batch_size):
@@ -530,6 +565,14 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
         setattr(a, k, None if t is None else t.data_ptr())
     a.stream = main.cuda_stream
     a.side_stream = side.cuda_stream if side is not None else None
+    loss_host = None
+    if sync:
+        # train.py:137-139 (loss.item()) without synchronising the stream: the library copies the four sums to pinned memory as soon as
+        # they are final (behind the TD / Huber launch) and the host waits for THAT copy -- the next step is enqueued while this one runs
+        loss_host = getattr(policy_net, '_loss_host', None)
+        if loss_host is None:
+            loss_host = policy_net._loss_host = torch.empty(4, dtype=torch.float32).pin_memory()
+        a.loss_host = loss_host.data_ptr()
     import ctypes
     lib.call('simq_train_step', ctypes.byref(a))
     if side is not None:
@@ -546,7 +589,8 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q.view(B, policy_net.num_output_channels, W, W)}
     if not sync:
         return out4
-    o = out4.tolist()                                                       # train.py:138-139 (.item() host sync)
+    lib.call('simq_train_loss_wait')
+    o = loss_host.tolist()                                                  # train.py:138-139 (.item())
     return {'td_error': o[1] / gB, 'loss': o[0] / gB}
 
 
