@@ -280,6 +280,40 @@ def test_vanilla_dqn_and_no_clip(simq_mod):
     assert all(int(sd[k]) == 1 for k in sd if k.endswith('num_batches_tracked'))     # vanilla DQN: one train fwd
 
 
+def test_train_returns_the_loss_without_a_stream_synchronisation(simq_mod):
+    """train() hands back loss / td_error of train.py:137-139 through the library's early copy (simq_train_args.loss_host +
+    simq_train_loss_wait: issued right behind the TD / Huber launch, not behind backward + SGD).  The floats are the device-side sums
+    of the same step, two nets trained alternately keep their own values, the sampler's packed asynchronous upload delivers the same
+    minibatch as plain copies, and a wait without a pending copy is an error."""
+    from simq import learner
+    from simq._lib import lib
+    cin, B = 5, 6
+    nets = []
+    for cout, seed in ((2, 31), (1, 33)):
+        policy, target = make_net(simq_mod, cin, cout, seed, True), make_net(simq_mod, cin, cout, seed + 1, False)
+        ring = simq_mod.DeviceReplayBuffer(64, cin)
+        for t in synth.make_transitions(40, cin, cout, seed + 2, terminal_frac=0.2):
+            ring.push(*t)
+        nets.append((policy, target, ring))
+    for step in range(3):
+        for policy, target, ring in nets:
+            idx = ring.sample_indices(B)
+            batch = ring.gather(idx)
+            # the packed upload against the records themselves
+            recs = [ring.buffer[i] for i in idx]
+            assert batch.action.tolist() == [r.action for r in recs]
+            assert np.allclose(batch.reward.cpu().numpy(), np.asarray([r.reward for r in recs], np.float32), rtol=0, atol=0)
+            assert batch.nonfinal_pos.tolist() == [i for i, r in enumerate(recs) if r.next_state is not None]
+            assert batch.action.dtype == torch.int64 and batch.reward.dtype == torch.float32 and batch.nonfinal_pos.dtype == torch.int32
+            info = learner.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP)
+            q_sa, y = policy._last['q_sa'].double().cpu().numpy(), policy._last['y'].double().cpu().numpy()
+            d = q_sa - y
+            huber = float(np.where(np.abs(d) < 1.0, 0.5 * d * d, np.abs(d) - 0.5).mean())
+            assert abs(info['loss'] - huber) <= 1e-5 * huber and abs(info['td_error'] - np.abs(d).mean()) <= 1e-5 * np.abs(d).mean()
+    torch.cuda.synchronize()
+    assert lib.c.simq_train_loss_wait() != 0 and 'no simq_train_step' in simq_mod._lib.last_error()
+
+
 def test_policy_step_golden(simq_mod, golden_dir):
     g = np.load('%s/policy_step.npz' % golden_dir)
     cfg = types.SimpleNamespace(robot_config=[{'lifting_robot': 2}, {'pushing_robot': 1}], num_input_channels=4,
