@@ -20,6 +20,9 @@
 // Measured alone (tools/imgf32_check.py, us per launch, image-tile | best implicit-GEMM tile): B = 32 64->64 22.7 | 27.6, 64->128 32.7 | 35.8;
 // B = 29 20.6 | 26.6 and 30.0 | 34.6; B = 128 63.8 | 59.5 and 107.8 | 95.8 -- with many rounds of blocks the 64x32 / 64x64 tiles
 // amortise their re-fetches and win, so the launcher takes this kernel for up to two blocks per CU only.
+// On the whole fp32 step (tools/ab_step.py, six alternating pairs): 3211.8 tr/s without, 3216.7 with this kernel -- neutral: in the step its
+// launches share the device with the side stream's forward, and 512-thread blocks with 68 KB of LDS find fewer free CUs than 256-thread
+// blocks with 8 KB (40 us per launch in the step's trace against 33 us for the 32x32 tile).
 // Arithmetic: exact fp32 FMA chains as in conv_igemm.hip (the fp32 parity bars apply unchanged); K order (tap, channel) instead of
 // (channel chunk, tap).  Epilogue: igemm_epilogue.h (bias, BN statistics, folded BN, residual, ReLU, fused BN-backward sums).
 #include <cstdint>

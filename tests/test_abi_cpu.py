@@ -200,6 +200,21 @@ def test_checkpoint_written_here_loads_in_a_reference_style_main_script(tmp_path
     assert type(simq.load_checkpoint(path2)['replay_buffers'][0]) is learner.ReplayBuffer
 
 
+def test_sampler_arrays_pack_and_unpack_unchanged():
+    """learner._upload_packed: the per-batch host arrays of DeviceReplayBuffer.gather (ring slots, next-state slots, actions, rewards,
+    positions) come back as tensors of the same dtype and content -- here through the non-CUDA path, which the gloo data-parallel
+    tests use as well; empty arrays (an all-terminal shard) stay empty."""
+    import numpy as np
+    import torch
+    from simq import learner
+    arrays = (np.arange(7, dtype=np.int64) * 3, np.asarray([], np.int64), np.asarray([5, 0, 9], np.int64),
+              np.asarray([0.5, -1.25, 3.0], np.float32), np.asarray([0, 2], np.int32))
+    out = learner._upload_packed(torch.device('cpu'), arrays)
+    assert [t.dtype for t in out] == [torch.int64, torch.int64, torch.int64, torch.float32, torch.int32]
+    for a, t in zip(arrays, out):
+        assert t.numel() == a.size and np.array_equal(t.numpy(), a)
+
+
 def test_winograd_transform_matrices_are_an_exact_restatement_of_the_convolution():
     """The matrices conv_winograd.hip hard-codes (F(2x2,3x3): B^T, G, A^T and the transposes its weight gradient uses), in
     fp64 numpy: Y = A^T[(G g G^T) . (B^T d B)]A is the 3x3 correlation of a 4x4 patch, and dMt = A dY A^T, dU = dMt . V,

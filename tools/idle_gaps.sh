@@ -28,7 +28,7 @@ for a, b in zip(ends[:-1], ends[1:]):
     for nm, s, e in ks[1:]:
         if s > cur_e:
             busy += cur_e - cur_s; gaps.append(s - cur_e)
-            if s - cur_e > 20000: big.append('%.0f us between %s and %s' % ((s - cur_e) / 1e3, last_name.split('(')[0][-40:], nm.split('(')[0][-40:]))
+            if s - cur_e > 20000: big.append('%.0f us between %s and %s' % ((s - cur_e) / 1e3, last_name.replace('simq::(anonymous namespace)::', '').replace('void ', '').split('(')[0][-40:], nm.replace('simq::(anonymous namespace)::', '').replace('void ', '').split('(')[0][-40:]))
             cur_s, cur_e = s, e
             last_name = nm
         else:
@@ -50,7 +50,7 @@ for a, b in zip(ends[:-1], ends[1:]):
         i0 = a + 1 + best[1]
         t0 = rows4[i0][1]
         for r in rows4[max(i0 - 8, 0):i0 + 8]:
-            print('      %+9.1f us  %7.1f us  stream %s  %s' % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3], r[0].split('(')[0][-60:]))
+            print('      %+9.1f us  %7.1f us  stream %s  %s' % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3], r[0].replace('simq::(anonymous namespace)::', '').replace('void ', '').split('(')[0][-60:]))
 P
 rm -rf $O
 cat $R/gpurun_out/${name}_idle.txt

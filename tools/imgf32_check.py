@@ -42,5 +42,5 @@ for B in (32, 29, 128):
         row = []
         for tile in ((0, 0), (32, 32), (64, 32), (64, 64), (96, 64)):
             us = bench(B, Cout, tile, True)
-            row.append('%s %6.1f us (%5.1f TF/s)' % ('img' if tile == (0, 0) else '%dx%d' % tile, us, gf / us * 1e-3))
+            row.append('%s %6.1f us (%5.1f TF/s)' % ('img' if tile == (0, 0) else '%dx%d' % tile, us, gf / us * 1e3))
         print('B=%3d 64->%3d  %.2f GFLOP: ' % (B, Cout, gf) + ' | '.join(row))
