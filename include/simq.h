@@ -82,6 +82,10 @@ typedef struct simq_plan_options {
     int winograd_f4_forward;      /* 1: the forwards nothing is differentiated through (target net, greedy next action, step()) in F(4x4,3x3) */
     int winograd_f4_min_tiles;    /* 256: ... from this many 4x4 tiles (B*36) */
     int winograd_f4_grad;         /* 2: dgrads in F(4x4,3x3); 1: the grad-mode forward too (doubles the median gradient error); 0: neither */
+    int winograd_f4_fwd_grad_min_cc; /* 512*512 (0 = never).  With winograd_f4_grad = 2: the GRAD-MODE forward of the layers with Cin*Cout >= this
+                                   * value runs in F(4x4,3x3) as well -- layer4's three 512->512 convolutions, 66 % of the grad-mode forward's
+                                   * matrix flops.  Their round-off passes through no further residual block: the gradient study (19 batches
+                                   * against fp64) is unchanged by it, while 256*512 and below raise the gradient's error */
     int winograd_wgrad;           /* 1: weight gradients of the Winograd layers through the transform domain */
     int winograd_wgrad_f4;        /* 1: ... in F(4x4,3x3) where the tile count allows */
     /* bf16 plans: storage */

@@ -297,7 +297,9 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
         c.wplanes(cv, false, wsp);
         return launch_conv_igemm_bf16(xs, wsp, c.p->np(), y, g, e, c.stream);
     }
-    if ((nograd || c.p->opt.winograd_f4_grad == 1) && cv.wu4_off >= 0 && c.L.wino >= 0 && c.p->opt.winograd_f4_forward &&
+    const bool f4_grad_fwd = c.p->opt.winograd_f4_grad == 1 ||
+                             (c.p->opt.winograd_f4_fwd_grad_min_cc > 0 && (long)g.Cin * g.Cout >= c.p->opt.winograd_f4_fwd_grad_min_cc);
+    if ((nograd || f4_grad_fwd) && cv.wu4_off >= 0 && c.L.wino >= 0 && c.p->opt.winograd_f4_forward &&
         winograd_f4_forward(g, c.p->opt.winograd_f4_min_tiles))
         return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream);
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
@@ -737,7 +739,7 @@ void simq_plan_options_default(simq_plan_options* o) {
     if (!o) return;
     o->struct_bytes = (int)sizeof(simq_plan_options);
     o->winograd = 1; o->winograd_min_cc = 128 * 128; o->winograd_f4_forward = 1; o->winograd_f4_min_tiles = 256;
-    o->winograd_f4_grad = 2; o->winograd_wgrad = 1; o->winograd_wgrad_f4 = 1;
+    o->winograd_f4_grad = 2; o->winograd_f4_fwd_grad_min_cc = 512 * 512; o->winograd_wgrad = 1; o->winograd_wgrad_f4 = 1;
     o->stem_bf16 = 1; o->bf16_act_grads = 1; o->keep_fp32_activations = 0; o->fold_eval_bn_bf16 = 1;
     o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
 }

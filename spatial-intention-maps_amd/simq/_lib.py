@@ -46,7 +46,7 @@ class PlanOptions(ctypes.Structure):
     """simq_plan_options of include/simq.h: the algebraic forms / storage precisions / fusions of a plan (fixed at creation)."""
     _fields_ = [(n, c_int) for n in (
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
-        'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
+        'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
         'fuse_bn_backward_sums', 'fuse_stem_backward_sums')]
 
 

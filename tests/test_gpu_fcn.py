@@ -592,7 +592,7 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     the same 16 sampled elements per tensor).  fp32 gradients of these batches are 1e-4 .. 1e-2 accurate for any implementation and
     which one is luckier changes per batch, so: median HIP error <= 2 x median reference error, no case beyond 10 x the reference's
     error on that case (or its median), for the pre-clip gradient and for the first parameter update (sampled elements, not
-    tensor norms); the second step's loss (which sees the first update) is held to the amplification the reference itself shows.
+    tensor norms); the second call is checked per transition against the fp64 oracle run from the post-step-1 state.
     Measured (MI355X): medians 1.6e-3 .. 2.3e-3 (HIP, run to run) vs 2.0e-3 (reference fp32) for both gradient and update; B = 64: 3.7e-3 vs 2.7e-3.
     Second fixture (grad_study_b64.npz, six seeded batches of 64 = configs[3]'s per-GPU batch, where the fp32 plans pick their large-batch
     tiles and 36-plane Winograd problems): the same bars."""
@@ -609,7 +609,10 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
         coef = min(1.0, cases.CLIP / (tn + 1e-6))
         grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
         p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
+        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < 3 or B <= 8 else (None, None)
         info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+        if sd1 is not None:     # the second call per transition against the fp64 oracle run from the post-step-1 state (tests/step2_oracle.py)
+            step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)
         gs, ds = [], []
         for t, a, b in zip(grads, p0, p1):
             idx = torch.tensor(cases.sample_indices(t.numel()))
@@ -635,13 +638,13 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
         assert med(k) <= 2.0 * med(rk), (k, med(k), med(rk))
         for r in rows:
             assert r[k] <= 10.0 * max(r[rk], med(rk)), (k, r)
-    # The second step's loss is the first update's error seen through the network once more: in the fixture the reference's own
-    # fp32 second-step loss is off by up to 15 x its update error (0.10 on gs_b8_03), with a heavy tail (13 samples: 2e-5 .. 1e-1).
-    # Held to: that amplification (x 2), and a median within 4 x the reference's median.
-    amp_ref = max(float(g[n + '.ref_loss_err'][1]) / float(g[n + '.ref_dparam_err']) for n, *_ in case_list)
+    # The second step's loss against the fp64 TRAJECTORY is the first update's error seen through a chaotic synthetic problem: in the
+    # fixture the reference's own fp32 second-step loss is off by up to 15 x its update error (0.10 on gs_b8_03), with a heavy tail
+    # (13 samples: 2e-5 .. 1e-1), and one summation order against another moves it by several per cent (tests/diag_step2_sensitivity.py).
+    # What "the second call is right" means is checked above per transition against the oracle (every B = 8 case and the first three of
+    # each fixture); the trajectory keeps a distribution bar: median within 4 x the reference's median, no case beyond 25 %.
     assert med('loss2') <= 4.0 * med('ref_loss2'), (med('loss2'), med('ref_loss2'))
-    for r in rows:
-        assert r['loss2'] <= 2.0 * amp_ref * r['dparam'] + 1e-4, (r, amp_ref)
+    assert all(r['loss2'] < 0.25 for r in rows), [r['loss2'] for r in rows]
 
 
 def test_optimizer_state_is_interchangeable_with_the_reference_layout(simq_mod, tmp_path):

@@ -3,7 +3,9 @@
 can be A/B-ed at the level that counts -- bench.py itself runs the product library only.  One process = one setting (the switches are
 read once); alternate the settings from a shell loop and compare on the same box:
     for i in 1 2 3; do SIMQ_IMG_F32=0 python tools/ab_step.py; SIMQ_IMG_F32=1 python tools/ab_step.py; done
+Plan options (simq_plan_options fields) can be A/B-ed the same way: SIMQ_AB_OPTIONS='{"winograd_min_cc": 8192}'.
 usage: ab_step.py [configs1|configs2] [steps]   -> one line: transitions/s, ms per step"""
+import json
 import os
 import sys
 import time
@@ -20,9 +22,10 @@ workload = sys.argv[1] if len(sys.argv) > 1 else 'configs1'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 cin, cout, B, precision = {'configs1': (4, 2, 32, 'fp32'), 'configs2': (5, 2, 128, 'bf16')}[workload]
 dev = torch.device('cuda:0')
+options = json.loads(os.environ.get('SIMQ_AB_OPTIONS', '{}')) or None
 torch.manual_seed(20260928)
-policy = simq.FCN(cin, cout, device=dev, precision=precision)
-target = simq.FCN(cin, cout, device=dev, precision=precision)
+policy = simq.FCN(cin, cout, device=dev, precision=precision, options=options)
+target = simq.FCN(cin, cout, device=dev, precision=precision, options=options)
 target.copy_state_from(policy)
 policy.train()
 target.eval()
@@ -45,5 +48,5 @@ for _ in range(steps):
     info = step()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-tag = ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith('SIMQ_') and k != 'SIMQ_LIBRARY')
+tag = ' '.join('%s=%s' % (k, v) for k, v in sorted(os.environ.items()) if k.startswith('SIMQ_') and k not in ('SIMQ_LIBRARY',))
 print('%s %s: %.1f tr/s  %.3f ms/step  loss %.4f  [%s]' % (workload, precision, B * steps / dt, dt / steps * 1e3, info['loss'], tag))
