@@ -604,6 +604,12 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     // (tools/probes/wino_gemm_probe.py: 104-107 TF/s at K = 256..512), 96x64 when the rows do not fill 64-row tiles evenly
     // (64x32 / 32x32 tiles for the few-block transform-domain weight gradients -- 256 blocks of a 256 x 256 x 16 problem -- measured
     // slower than one 64x64 block per CU: 0.181 vs 0.150 ms)
+#ifdef SIMQ_ABLATIONS      // tile A/B for the transform-domain GEMMs (tools/ab_step.py): SIMQ_GEMM_BATCHED_TILE=96 | 128 (rows; 64 columns).
+    // Whole fp32 step, three alternating runs each: 64 rows 3320 tr/s, 96 rows 3267, 128 rows 3269 -- the 64x64 tile stays.
+    static const int bt = SIMQ_TUNE_INT("SIMQ_GEMM_BATCHED_TILE", 64);
+    if (bt == 96 && M % 96 == 0) return run<96, 64, true, true>(a, stream, batch);
+    if (bt == 128 && M % 128 == 0) return run<128, 64, true, true>(a, stream, batch);
+#endif
     return run<64, 64, true, true>(a, stream, batch);
 }
 
