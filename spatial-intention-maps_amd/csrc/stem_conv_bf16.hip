@@ -10,7 +10,7 @@
 //     rows above / below the image are skipped per tile), converts to bf16 and feeds the matrix core.  No LDS for activations, no
 //     packed copy of x.  k-groups that lie entirely behind the 7*Cin real values are not loaded (their weights are zero).
 //   * The weights (64 x 7 x 64 bf16, rows padded to 456 elements: conflict-free ds_read_b128) sit in LDS for the lifetime of a block;
-//     blocks are persistent (grid-stride over 32-pixel wave tiles), so the weights are staged and the BatchNorm batch statistics of the
+//     blocks are persistent (grid-stride over 16-pixel wave tiles, nine waves per block: 58 -> 42 us per launch at B = 128 against pairs of tiles on eight waves), so the weights are staged and the BatchNorm batch statistics of the
 //     block (fp32 per lane -> fp64 per block) are pushed with atomics ONCE per block.
 //   * Output: the pre-BatchNorm map as bf16 (like every other matrix-core convolution of a plain-bf16 plan; statistics from the fp32
 //     accumulators).
@@ -35,16 +35,29 @@ struct StemArgs {
     unsigned x_bytes;
 };
 
-constexpr int NWAVE = 8;                               // waves per block (they share the LDS copy of the weights)
+constexpr int NWAVE = 9;                               // waves per block (they share the LDS copy of the weights): 9 x 512 blocks = one
+                                                       // 16-pixel tile per wave and trip, 4.5 waves per SIMD hide each other's load latency
 
 __global__ void __launch_bounds__(NWAVE * 64, 2) stem_conv_bf16_kernel(const StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
     double* red = reinterpret_cast<double*>(smem + SMEM_W);          // [NWAVE][64][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // weights -> LDS (the prepared layout is already [cout][WROW])
-    for (int i = tid; i < COUT * WROW / 8; i += NWAVE * 64)
-        reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.w16)[i];
+    // weights -> LDS (the prepared layout is already [cout][WROW]); all of a thread's loads before its first store
+    {
+        constexpr int NV = COUT * WROW / 8, TRIPS = (NV + NWAVE * 64 - 1) / (NWAVE * 64);
+        uint4 v[TRIPS];
+#pragma unroll
+        for (int u = 0; u < TRIPS; ++u) {
+            const int i = tid + u * NWAVE * 64;
+            v[u] = i < NV ? reinterpret_cast<const uint4*>(p.w16)[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < TRIPS; ++u) {
+            const int i = tid + u * NWAVE * 64;
+            if (i < NV) reinterpret_cast<uint4*>(wl)[i] = v[u];
+        }
+    }
     __syncthreads();
 
     const long total = (long)p.B * p.H * p.W * p.C;                  // floats in x
@@ -53,105 +66,82 @@ __global__ void __launch_bounds__(NWAVE * 64, 2) stem_conv_bf16_kernel(const Ste
     const int kreal = R * p.C;                                       // real k per filter row
     const int tiles_per_row = p.Wo / 16;
     const int ntiles = p.B * p.Ho * tiles_per_row;                   // 16-pixel tiles
-    const int npairs = (ntiles + 1) / 2;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     const uint16_t* wfrag = wl + fi * WROW + kg * 8;                  // + j * 16 * WROW + ky * KROW + s * 32
 
-    for (int pair = blockIdx.x * NWAVE + wave; pair < npairs; pair += gridDim.x * NWAVE) {
-        floatx4 acc[2][4];
+    // One wave = one 16-pixel x 64-channel tile at a time (round 3; a wave used to own a PAIR of tiles with every (filter row, k-step)
+    // an exposed load latency: 58 us per launch at B = 128)
+    for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+        floatx4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int ox0 = (tile % tiles_per_row) * 16;
+        const int r = tile / tiles_per_row;
+        const int oy = r % p.Ho, b = r / p.Ho;
+        // per lane: pointer to the first float of its k-group at filter row 0 (may lie outside the tensor: rows above / below the image
+        // are skipped before it is used); per k-step whether some lane's 8-float fragment touches the left / right padding (ballot)
+        const int e_lo = (2 * (ox0 + fi) - 3) * p.C + kg * 8;
+        const float* prow = p.x + ((long)(b * p.H + 2 * oy - 3) * rowf + e_lo);
+        bool side[2], real[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        // per tile: output row, image; per lane: pointer to the first float of its k-group at filter row 0 (may lie outside the tensor:
-        // rows above / below the image are skipped before it is used), and for both k-steps how many leading / trailing elements of
-        // its 8-float fragment fall outside the image row (left / right padding) -- none of this depends on the filter row
-        int oy[2], b[2];
-        const float* prow[2];
-        int e_lo[2];
-        bool live[2];
-        unsigned long long border[2][2];                             // lanes whose fragment needs masking, per tile and k-step (ballot)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int tile = pair * 2 + t;
-            live[t] = tile < ntiles;
-            const int tt = live[t] ? tile : 0;
-            const int ox0 = (tt % tiles_per_row) * 16;
-            const int r = tt / tiles_per_row;
-            oy[t] = r % p.Ho; b[t] = r / p.Ho;
-            e_lo[t] = (2 * (ox0 + fi) - 3) * p.C + kg * 8;
-            prow[t] = p.x + ((long)(b[t] * p.H + 2 * oy[t] - 3) * rowf + e_lo[t]);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int e = e_lo[t] + s * 32;
-                border[t][s] = __builtin_amdgcn_ballot_w64((e < 0 || e + 8 > rowf) && s * 32 + kg * 8 < kreal);
-            }
+        for (int s = 0; s < 2; ++s) {
+            const int e = e_lo + s * 32;
+            real[s] = s * 32 + kg * 8 < kreal;                       // k-groups entirely behind the 7*Cin real values are not loaded
+            side[s] = __builtin_amdgcn_ballot_w64((e < 0 || e + 8 > rowf) && real[s]) != 0;
         }
-        // fragment (t, s) of filter row ky as 8 floats: straight from global memory, padding masked
-        auto load_frag = [&](int t, int s, int ky, float (&v)[8]) {
-            const int k0 = s * 32 + kg * 8;                           // this lane's first k inside the filter row
-            const int iy = 2 * oy[t] + ky - 3;
-            const bool rowok = live[t] && (unsigned)iy < (unsigned)p.H;               // wave-uniform per tile
-            // the first row of the first image and the last row of the last: a fragment may reach outside the tensor
-            const bool tensor_edge = (b[t] == 0 && iy == 0) || (b[t] == p.B - 1 && iy == p.H - 1);   // wave-uniform
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = 0.f;
-            if (rowok && k0 < kreal) {
-                const float* src = prow[t] + (ky * rowf + s * 32);
-                if (!tensor_edge) {
-                    // dword-aligned 16-byte loads: the window starts at (2 ox - 3) * C floats, 16-byte aligned only for C % 4 == 0
-                    // (buffer loads need natural alignment; global loads do not)
-                    const floatx4_a4 lo = *reinterpret_cast<const floatx4_a4*>(src), hi = *reinterpret_cast<const floatx4_a4*>(src + 4);
-                    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-                } else {
-                    const long g0 = src - p.x;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (g0 + q >= 0 && g0 + q < total) ? src[q] : 0.f;
-                }
-                if (border[t][s]) {                                    // wave-uniform: some lane touches the left / right padding
-                    const int e = e_lo[t] + s * 32;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = ((unsigned)(e + q) < (unsigned)rowf) ? v[q] : 0.f;
-                }
-            }
-        };
-        // (measured at B = 128: 8 waves per block 43 us, 4 waves 60 us -- the loop is a chain of load latencies, occupancy hides them;
-        // requesting row ky + 1 before the MFMAs of row ky costs 50 registers and one resident wave per SIMD: 57 us; fully unrolled
-        // it spills: 93 us)
 #pragma unroll 1
         for (int ky = 0; ky < R; ++ky) {
+            const int iy = 2 * oy + ky - 3;
+            if ((unsigned)iy >= (unsigned)p.H) continue;                                      // wave-uniform: a padding row
+            // the first row of the first image and the last row of the last: a fragment may reach outside the tensor
+            const bool tensor_edge = (b == 0 && iy == 0) || (b == p.B - 1 && iy == p.H - 1);   // wave-uniform
+            float v[2][8];
+            // fragments of both k-steps: 8 consecutive floats of x each, straight from global memory (dword-aligned 16-byte loads: the
+            // window starts at (2 ox - 3) * C floats), all four loads issued before the first mask
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 af[2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float v[8];
-                    load_frag(t, s, ky, v);
+                for (int q = 0; q < 8; ++q) v[s][q] = 0.f;
+                if (real[s]) {
+                    const float* src = prow + (ky * rowf + s * 32);
+                    if (!tensor_edge) {
+                        const floatx4_a4 lo = *reinterpret_cast<const floatx4_a4*>(src), hi = *reinterpret_cast<const floatx4_a4*>(src + 4);
+                        v[s][0] = lo[0]; v[s][1] = lo[1]; v[s][2] = lo[2]; v[s][3] = lo[3];
+                        v[s][4] = hi[0]; v[s][5] = hi[1]; v[s][6] = hi[2]; v[s][7] = hi[3];
+                    } else {
+                        const long g0 = src - p.x;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) af[t][q] = (__bf16)v[q];
+                        for (int q = 0; q < 8; ++q) v[s][q] = (g0 + q >= 0 && g0 + q < total) ? src[q] : 0.f;
+                    }
                 }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (side[s]) {                                         // wave-uniform: some lane touches the left / right padding
+                    const int e = e_lo + s * 32;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[s][q] = ((unsigned)(e + q) < (unsigned)rowf) ? v[s][q] : 0.f;
+                }
+                bf16x8 af;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) af[q] = (__bf16)v[s][q];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wfrag + j * 16 * WROW + ky * KROW + s * 32);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc[t][j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
                 }
             }
         }
-        // ---- store (bf16) + statistics: lane holds column fi of N-tile j, rows 4 kg + r of tile t
+        // ---- store (bf16) + statistics: lane holds column fi of N-tile j, rows 4 kg + r of the tile
+        const size_t m0 = (size_t)tile * 16;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (!live[t]) continue;
-            const size_t m0 = (size_t)(pair * 2 + t) * 16;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[t][j][r];
-                    s0[j] += v; s1[j] += v * v;
-                    p.y[(m0 + 4 * kg + r) * COUT + j * 16 + fi] = __builtin_bit_cast(uint16_t, (__bf16)v);
-                }
-        }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float val = acc[j][r4];
+                s0[j] += val; s1[j] += val * val;
+                p.y[(m0 + 4 * kg + r4) * COUT + j * 16 + fi] = __builtin_bit_cast(uint16_t, (__bf16)val);
+            }
     }
     if (!p.stats) return;
 #pragma unroll
@@ -360,8 +350,8 @@ int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, doub
     p.x = x; p.w16 = w16; p.y = y; p.stats = stats;
     p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = H / 2; p.Wo = W / 2;
     p.x_bytes = (unsigned)xb;
-    const int npairs = (B * p.Ho * (p.Wo / 16) + 1) / 2;
-    int blocks = (npairs + NWAVE - 1) / NWAVE;
+    const int ntiles = B * p.Ho * (p.Wo / 16);
+    int blocks = (ntiles + NWAVE - 1) / NWAVE;
     if (blocks > 512) blocks = 512;                                   // two persistent blocks per CU
     static bool attr_set = false;
     const int smem = SMEM_W + NWAVE * COUT * 2 * (int)sizeof(double);
