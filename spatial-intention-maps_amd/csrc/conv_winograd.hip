@@ -54,9 +54,10 @@ __global__ void __launch_bounds__(256) wino_weight_kernel(const float* __restric
 // 36 products per 4x4 outputs: 1.78x fewer matrix FLOPs than F(2x2,3x3) and 2.25x instead of 4x transform volume.  Interpolation
 // points {0, 1, -1, 1/2, -2, inf} (Cook-Toom; the symmetric textbook set {0, +-1, +-2} loses 2.4x more accuracy): measured / simulated
 // fp32 error 3.6e-6 of the output range per layer against 6e-7 for F(2x2,3x3) -- ~1e-5 on the Q-map after the eight wide layers,
-// a tenth of the 1e-4 parity bar.  It is used only where NOTHING is differentiated through the result (the forwards that produce
-// the TD target's bootstrap value and the greedy next action, train.py:119-124); the grad-mode forward, whose activations the
-// backward walk re-reads, and every dgrad stay on F(2x2,3x3).
+// a tenth of the 1e-4 parity bar.  First used only where NOTHING is differentiated through the result (the forwards that produce
+// the TD target's bootstrap value and the greedy next action, train.py:119-124); since then also by the dgrads and by the grad-mode
+// forward of layer4's 512->512 convolutions (simq_plan_options.winograd_f4_grad / winograd_f4_fwd_grad_min_cc, further down) --
+// the rest of the grad-mode forward stays on F(2x2,3x3): its round-off is the gradient's error.
 //   A^T = [[1,1,1,1,1,0],[0,1,-1,1/2,-2,0],[0,1,1,1/4,4,0],[0,1,-1,1/8,-8,1]]
 //   G   = [[1,0,0],[1/3,1/3,1/3],[-1/3,1/3,-1/3],[-16/15,-8/15,-4/15],[1/15,-2/15,4/15],[0,0,1]]
 //   B^T = [[1,-3/2,-2,3/2,1,0],[0,-1,1/2,5/2,1,0],[0,1,-5/2,1/2,1,0],[0,-2,-1,2,1,0],[0,1/2,-1,-1/2,1,0],[0,1,-3/2,-2,3/2,1]]
