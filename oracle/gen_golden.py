@@ -808,6 +808,7 @@ if __name__ == '__main__':
             'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
             'dp': gen_dp, 'dp_literal': gen_dp_literal, 'bf16_calibration': gen_bf16_calibration,
             'grad_study': gen_grad_study,
-            'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz')}
+            'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz'),
+            'grad_study_b32': lambda: gen_grad_study(cases.GRAD_STUDY_B32_CASES, 'grad_study_b32.npz')}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box, not collected by pytest): what F(4x4,3x3) in the GRAD-MODE forward of the widest layers does to the gradient's
-error.  Runs the gradient study of tests/test_gpu_fcn.py::test_gradient_parity_distribution (13 batches of 8 / 32 and six of 64
+error.  Runs the gradient study of tests/test_gpu_fcn.py::test_gradient_parity_distribution (13 batches of 8 / 32, six of 64 and twelve of 32
 against the fp64 oracle's gradient, with the reference's own fp32 error on the same elements) for several values of
 simq_plan_options.winograd_f4_fwd_grad_min_cc: 0 = F(2x2,3x3) everywhere (default), 262144 = the 512->512 convolutions, 131072 = + 256->512,
 65536 = + layer3, 16384 = every Winograd layer.   usage: python tests/diag_f4_grad_layers.py [threshold ...]"""
@@ -22,7 +22,8 @@ rl2 = lambda a, b: float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
 for thr in [int(a) for a in sys.argv[1:]] or [0, 262144, 131072, 65536, 16384]:
     _lib.DEFAULT_PLAN_OPTIONS.clear()
     _lib.DEFAULT_PLAN_OPTIONS['winograd_f4_fwd_grad_min_cc'] = thr
-    for fixture, case_list in (('grad_study.npz', cases.GRAD_STUDY_CASES), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES)):
+    for fixture, case_list in (('grad_study.npz', cases.GRAD_STUDY_CASES), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES),
+                               ('grad_study_b32.npz', cases.GRAD_STUDY_B32_CASES)):
         g = np.load(os.path.join(ROOT, 'tests', 'golden', fixture))
         rows = []
         for name, cin, cout, B, wseed, dseed in case_list:

@@ -583,8 +583,9 @@ def test_onehot_backward_equals_dense_backward(simq_mod, cout):
     assert num < 1e-4, num
 
 
-@pytest.mark.parametrize('fixture,case_list', [('grad_study.npz', cases.GRAD_STUDY_CASES), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES)],
-                         ids=['b8_b32', 'b64'])
+@pytest.mark.parametrize('fixture,case_list', [('grad_study.npz', cases.GRAD_STUDY_CASES), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES),
+                                               ('grad_study_b32.npz', cases.GRAD_STUDY_B32_CASES)],
+                         ids=['b8_b32', 'b64', 'b32x12'])
 def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     """SURVEY section 0's criterion for gradients, err_build <= k * err_reference-fp32, judged as a DISTRIBUTION (fixture
     tests/golden/grad_study.npz, written by oracle/gen_golden.py from the imported reference: 10 seeded B=8 and 3 seeded B=32 batches,
@@ -595,7 +596,9 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     tensor norms); the second call is checked per transition against the fp64 oracle run from the post-step-1 state.
     Measured (MI355X): medians 1.6e-3 .. 2.3e-3 (HIP, run to run) vs 2.0e-3 (reference fp32) for both gradient and update; B = 64: 3.7e-3 vs 2.7e-3.
     Second fixture (grad_study_b64.npz, six seeded batches of 64 = configs[3]'s per-GPU batch, where the fp32 plans pick their large-batch
-    tiles and 36-plane Winograd problems): the same bars."""
+    tiles and 36-plane Winograd problems): the same bars.  Third fixture (grad_study_b32.npz, twelve seeded batches of the headline workload's
+    own shape -- 32 transitions, Cin 4, Cout 2): the same bars; it is the sample the choice of F(4x4,3x3) for the grad-mode forward of
+    layer4's 512->512 convolutions rests on (tests/diag_f4_grad_layers.py)."""
     from oracle import learner as olearner
     g = np.load('%s/%s' % (golden_dir, fixture))
     rows = []
