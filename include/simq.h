@@ -96,6 +96,13 @@ typedef struct simq_plan_options {
     /* every precision: fusions (0 = separate reduction launches, same arithmetic in a different summation order) */
     int fuse_bn_backward_sums;    /* 1 */
     int fuse_stem_backward_sums;  /* 1 */
+    /* train-mode "conv -> BatchNorm -> ReLU -> conv" chains with ONE consumer (bn1 of every BasicBlock, resnet.py:34-40; bn1 of the head,
+     * networks.py:18-20): the activation in between is never stored.  Same arithmetic (the fma / max bn_apply performs), bit-identical results. */
+    int fuse_bn1_apply;           /* 1 (fp32 plans): the consuming convolution applies scale*y+shift -> ReLU while it stages its operand (Winograd input
+                                   * transforms, image-tile / implicit-GEMM loaders), its weight gradient and the BatchNorm backward recompute the
+                                   * activation / its mask from the saved pre-BN output.  Needs fuse_bn_backward_sums. */
+    int bn1_mask_from_preact;     /* 1 (plain-bf16 plans): the backward pass takes that ReLU mask from the saved pre-BN output (scale*y+shift > 0)
+                                   * instead of reading the activation's plane -- one bf16 plane less in bn_bwd_apply and in the dgrad epilogue */
 } simq_plan_options;
 void simq_plan_options_default(simq_plan_options* options);
 int simq_plan_create_opts(int num_input_channels, int num_output_channels, int precision, const simq_plan_options* options,
@@ -304,6 +311,19 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const floa
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                               int batch, int hin, int win, int cin, int cout,
                               double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+/* conv( relu( y_pre * in_scale[ci] + in_shift[ci] ) ): the second convolution of a train-mode "conv -> BatchNorm -> ReLU -> conv" chain
+ * (reference resnet.py:34-40, networks.py:18-20) consuming the FIRST convolution's pre-BatchNorm output -- the BatchNorm + ReLU in
+ * between is applied while the operand is staged and the activation is never stored (simq_plan_options.fuse_bn1_apply; fp32).
+ * Zero padding applies to the activation.  form 0: implicit GEMM / image tile (any r x s, cin % 16 == 0); 1: Winograd F(2x2,3x3);
+ * 2: Winograd F(4x4,3x3) (3x3 / stride 1 / pad 1 geometries of simq_conv2d_fwd_winograd / _winograd4, same d_scratch; NULL for form 0). */
+int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_w_ohwi,
+                              const float* d_bias, float* d_y, int batch, int hin, int win, int cin, int cout, int r, int s, int stride,
+                              int pad, int form, float* d_scratch, void* stream);
+/* ... and that convolution's weight gradient, dW = dY^T * relu(y_pre * in_scale + in_shift) (the activation recomputed on load).
+ * form 0: direct (cin % 64 == 0); 1: transform domain (geometry / d_scratch of simq_conv2d_wgrad_winograd). */
+int simq_conv2d_wgrad_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_dy, float* d_dw,
+                                int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
+                                float* d_scratch, void* stream);
 /* The encoder's first convolution (reference resnet.py:94: 7x7, stride 2, pad 3, cin -> 64, no bias) on the bf16 matrix cores with
  * the operands gathered straight from the fp32 NHWC input -- the form plain-bf16 plans use (stem_conv_bf16.hip).  7 * cin <= 63,
  * win a multiple of 32, hin even.  d_y: bf16 [batch][hin/2][win/2][64] (pre-BatchNorm, rounded once from the fp32 accumulators);

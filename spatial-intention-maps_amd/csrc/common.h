@@ -67,9 +67,18 @@ struct ConvEpilogue {
     // optionally against a second (downsample-branch) BN that shares the mask.  See igemm_epilogue.h.
     const float* bnr_mask = nullptr;
     const uint16_t* bnr_mask16 = nullptr;   // the same mask as a bf16 plane (used when bnr_mask is NULL)
+    // neither: the mask is RECOMPUTED from the saved pre-BN output, mask = (bnr_y1 * bnr_mscale[n] + bnr_mshift[n] > 0) -- the
+    // activation relu(bn1(y1)) of a BasicBlock / the head that the forward pass never stored (InBn below)
+    const float* bnr_mscale = nullptr; const float* bnr_mshift = nullptr;
     const float* bnr_y1 = nullptr; const float* bnr_mean1 = nullptr; const float* bnr_invstd1 = nullptr; double* bnr_red1 = nullptr;
     const float* bnr_y2 = nullptr; const float* bnr_mean2 = nullptr; const float* bnr_invstd2 = nullptr; double* bnr_red2 = nullptr;
 };
+
+// A convolution input that is still the PRE-BatchNorm output y of the producing convolution: the consumer applies
+// relu(y * scale[c] + shift[c]) -- the fma / max sequence of bn_apply -- while it stages its operand, so the train-mode
+// "conv -> bn -> relu -> conv" chain of resnet.py:34-40 (and networks.py:18-20) never writes the activation in between.
+// scale / shift: per input channel, from launch_bn_finalize.  Zero padding applies to the ACTIVATION (out-of-image taps stay 0).
+struct InBn { const float* scale = nullptr; const float* shift = nullptr; };
 
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
 void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
@@ -78,7 +87,7 @@ void tune_force_tile(int bm, int bn);   // conv_igemm.hip: force one tile of the
 void tune_tail_split(int on);           // conv_igemm.hip: balanced last round on / off
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
-                      hipStream_t stream);
+                      hipStream_t stream, const InBn& in = InBn());
 // conv_igemm.hip: `batch` independent row-major GEMMs y_g = x_g * w_g^T in one launch
 // ping-pong LDS-DMA form (gemm_f32_pp.hip): 1 = launch taken, 0 = shape not covered, < 0 error
 int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
@@ -93,17 +102,18 @@ constexpr int kWinoWeightTableCap = 72;   // 18 convolutions x 4 forms (every 3x
 struct WinoWeightTable { WinoWeightDesc d[kWinoWeightTableCap]; int n; };
 int launch_wino_weight_all(const float* params, const float* wt, float* ubase, const WinoWeightTable& t, hipStream_t stream);
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
-                         hipStream_t stream);
+                         hipStream_t stream, const InBn& in = InBn());
 // F(4x4,3x3) form for forwards nothing is differentiated through (U4: 36 planes [Cout][Cin])
 bool winograd_f4_forward(const ConvGeom& g, int min_tiles);
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
-                          hipStream_t stream);
-int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream);
+                          hipStream_t stream, const InBn& in = InBn());
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in = InBn());
 // conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
 int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
 bool winograd_wgrad_eligible(const ConvGeom& g);
 bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4);
-int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4 = true);
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4 = true,
+                               const InBn& in = InBn());
 int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
 int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,
@@ -145,6 +155,8 @@ struct BnRef {
     float* rvar = nullptr;
     float* save_mean = nullptr;
     float* save_invstd = nullptr;
+    float* save_scale = nullptr;     // optional: the consumer's scale / shift kept for a backward pass that recomputes the ReLU mask
+    float* save_shift = nullptr;     // from the pre-BN output (bn_bwd_apply's mscale / mshift)
     double rows = 0.0, inv_rows = 0.0;
     int C = 0;
 };
@@ -154,6 +166,9 @@ struct BnEvalTable { BnEvalDesc d[24]; int n; };
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream);
 // running mean / var <- momentum update from [sum | sum of squares] over `rows` rows (no normalisation: simq_forward_sync_null)
 int launch_bn_running_update(const double* stats, float* rmean, float* rvar, double rows, int C, hipStream_t stream);
+// scale / shift of a train-mode BatchNorm whose application is fused into its consumer (InBn): one small block forms them from the
+// producing convolution's [sum | sum of squares], saves mean / invstd for backward and commits the running statistics
+int launch_bn_finalize(const BnRef& bn, float* scale, float* shift, hipStream_t stream);
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
 // y_bf16: `y` points at bf16 values (uint16_t), see ConvEpilogue::y_bf16
@@ -169,7 +184,7 @@ int launch_stem_pool_fwd(const float* y, const BnRef& bn, float* pooled, uint8_t
 int stem_conv_bf16_wbytes();
 // stem_conv_f32.hip: the same convolution in exact fp32 on the matrix cores (fp32 / split-bf16 plans), weights straight from the OHWI parameters
 // conv_img_f32.hip: image-tile fp32 3x3 convolution of the 64-input-channel layers; 1 = taken, 0 = shape not covered, < 0 error
-int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e, hipStream_t stream);
+int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e, hipStream_t stream, const InBn& in = InBn());
 bool stem_conv_f32_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
 int launch_stem_conv_f32(const float* x, const float* w_ohwi, float* y, double* stats, int B, int H, int W, int C, hipStream_t stream);
 bool stem_conv_bf16_eligible(int H, int W, int C, int cout, int k, int stride, int pad);
@@ -188,7 +203,8 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
                         const float* invstd, const float* gamma, const double* red, float* dy, float* dz_out,
                         float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t stream, Planes pl = Planes(),
                         const uint16_t* mask16 = nullptr, int y_bf16 = 0, double global_rows = 0.0, float dparam_scale = 1.f,
-                        int g_bf16 = 0);   // g_bf16: g (and dz_out) are bf16 behind the float pointers
+                        int g_bf16 = 0,    // g_bf16: g (and dz_out) are bf16 behind the float pointers
+                        const float* mscale = nullptr, const float* mshift = nullptr);   // no mask tensor: mask = (y * mscale + mshift > 0)
 // out[c] = sum_rows x[r][c]   (conv bias gradient)
 int launch_colsum(const float* x, double* red_scratch, float* out, int64_t rows, int C, hipStream_t stream);
 int launch_colsum_rep(const float* x, double* red_scratch, float* out, int64_t rows, int C, int replicas, hipStream_t stream);   // scratch: replicas * C doubles

@@ -58,6 +58,7 @@ struct ImgF32Args {
     EpiArgs epi;
     int M, Cout, tilesN;
     unsigned x_bytes, w_bytes;
+    const float* xscale; const float* xshift;   // XBN: x is a pre-BatchNorm output; the patch becomes relu(x * xscale[ci] + xshift[ci]) in LDS (common.h InBn)
 };
 
 template <int N>
@@ -85,6 +86,7 @@ __device__ __forceinline__ floatx4 lds_read16(int addr) {
     return v;
 }
 
+template <bool XBN>
 __global__ void __launch_bounds__(NW * 64, 2) conv_img_f32_kernel(const ImgF32Args p) {
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,6 +152,27 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_img_f32_kernel(const ImgF32Ar
     for (int t = 0; t < LEAD; ++t) issue_weights(t, t);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (XBN) {
+        // the patch holds the producing convolution's pre-BatchNorm output: one pass over it in LDS turns the in-image pixels into the
+        // activation (the zero border is the ACTIVATION's padding and stays).  130 pixels x 16 channel quads over 512 threads; a lane
+        // keeps its quad (512 % 16 == 0), so its eight coefficients are loaded once.
+        const int slot = tid & 15;
+        floatx4 sc, sh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sc[c] = p.xscale[slot * 4 + c]; sh[c] = p.xshift[slot * 4 + c]; }
+        for (int pix = tid >> 4; pix < PR * PW; pix += NW * 4) {
+            const int prow = pix / PW, pcol = pix - prow * PW;
+            const int iy = y0 - 1 + prow, ix = pcol - 1;
+            if ((unsigned)iy < (unsigned)HW && (unsigned)ix < (unsigned)HW) {
+                floatx4* q = reinterpret_cast<floatx4*>(smem + pix * PPITCH + slot * 16);
+                floatx4 v = *q;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(__builtin_fmaf(v[c], sc[c], sh[c]), 0.f);
+                *q = v;
+            }
+        }
+        __syncthreads();
+    }
 
     // K-step s = (tap, 16-channel chunk), 36 of them, unrolled.  TMW = this wave's real tiles (3 / 2).
     auto run = [&](auto TMW_C) {
@@ -198,7 +221,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_img_f32_kernel(const ImgF32Ar
 }  // namespace
 
 // returns 1 when the launch was taken, 0 when the shape is not covered, < 0 on error
-int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e, hipStream_t stream) {
+int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e, hipStream_t stream, const InBn& in) {
     if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.Hin != HW || g.Win != HW || g.Hout != HW || g.Wout != HW) return 0;
     if (g.Cin != CIN || g.Cout % BN != 0) return 0;
     static const int mode = SIMQ_TUNE_INT("SIMQ_IMG_F32", 1);    // 0 = off (ablation build)
@@ -209,10 +232,12 @@ int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g
     p.x = x; p.w = w; p.epi = make_epi(y, e);
     p.M = g.M(); p.Cout = g.Cout; p.tilesN = g.Cout / BN;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.xscale = in.scale; p.xshift = in.shift;
     const unsigned blocks = (unsigned)(g.B * (HW / ROWS) * p.tilesN);
     if (blocks > 512) return 0;                                  // more rounds: the implicit-GEMM tiles win (see the header)
     prof_launch_begin(2, 2.0 * p.M * p.Cout * TAPS * CIN, 4.0 * ((double)p.M * CIN + (double)p.Cout * TAPS * CIN + (double)p.M * p.Cout), stream);
-    hipLaunchKernelGGL(conv_img_f32_kernel, dim3(blocks), dim3(NW * 64), 0, stream, p);
+    if (in.scale) hipLaunchKernelGGL(conv_img_f32_kernel<true>, dim3(blocks), dim3(NW * 64), 0, stream, p);
+    else hipLaunchKernelGGL(conv_img_f32_kernel<false>, dim3(blocks), dim3(NW * 64), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 1;

@@ -31,11 +31,13 @@ struct WgradArgs {
     int tilesI, tilesJ, rows_per_split;
     unsigned x_bytes, dy_bytes;
     long gx, gdy, gdw;   // batched launch (blockIdx.y = g): element offsets of the g-th x / dy / dw (conv_winograd.hip)
+    const float* xscale; const float* xshift;   // XBN: x is a pre-BatchNorm output, the operand is relu(x * xscale[ci] + xshift[ci]) (common.h InBn)
 };
 
-template <int TI, int TJ, int WI, int WJ, bool VEC>
+template <int TI, int TJ, int WI, int WJ, bool VEC, bool XBN = false>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     static_assert(WI * WJ == 4, "4 waves per block");
+    static_assert(VEC || !XBN, "the BatchNorm-on-load form exists for the vector loader only");
     constexpr int NI = TI / WI / 32, NJ = TJ / WJ / 32;
     static_assert(NI >= 1 && NJ >= 1, "wave tile must be a multiple of 32x32");
     constexpr int STAGE = BR * (TI + TJ);
@@ -84,6 +86,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int X_PASSES_S = BR * TJ / 256;
     float4 vy[2][Y_PASSES], vx[2][VEC ? X_PASSES_V : 1];
     float sx[2][VEC ? 1 : X_PASSES_S];
+    // XBN: which of a register set's rows were real pixels (padding taps / rows past the end must stay 0 behind the BatchNorm + ReLU),
+    // and this lane's four channels' coefficients (256 % (TJ / 4) == 0: the same channel quad in every pass)
+    unsigned xok[2] = {0u, 0u};
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (XBN) {
+        const int ch = cj0 + (tid % (TJ / 4)) * 4;
+        xsc = make_float4(p.xscale[ch], p.xscale[ch + 1], p.xscale[ch + 2], p.xscale[ch + 3]);
+        xsh = make_float4(p.xshift[ch], p.xshift[ch + 1], p.xshift[ch + 2], p.xshift[ch + 3]);
+    }
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + blockIdx.y * p.gx), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + blockIdx.y * p.gdy), 0, p.dy_bytes, 0x00020000);
 
@@ -111,6 +122,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
             vy[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yr, voff, 0, 0));
         }
         if constexpr (VEC) {
+            if constexpr (XBN) xok[SET] = 0u;
 #pragma unroll
             for (int ps = 0; ps < X_PASSES_V; ++ps) {
                 const int idx = tid + 256 * ps;
@@ -123,6 +135,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                                 (unsigned)ix < (unsigned)p.Win;
                 const unsigned voff = ok ? (unsigned)(((xb[ps] * p.Hin + iy) * p.Win + ix) * p.Cin + cj0 + c4 * 4) * 4u : 0xFFFFFFFFu;
                 vx[SET][ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
+                if constexpr (XBN) xok[SET] |= ok ? (1u << ps) : 0u;
                 xox[ps] += BR;
                 while (xox[ps] >= p.Wout) { xox[ps] -= p.Wout; ++xoy[ps]; }
                 if (xoy[ps] >= p.Hout) { xoy[ps] -= p.Hout; ++xb[ps]; }
@@ -154,7 +167,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int ps = 0; ps < X_PASSES_V; ++ps) {
                 int idx = tid + 256 * ps;
-                if (X_F4 % 256 == 0 || idx < X_F4) *reinterpret_cast<float4*>(Xs + idx * 4) = vx[SET][ps];
+                float4 v = vx[SET][ps];
+                if constexpr (XBN) {
+                    const bool ok = (xok[SET] >> ps) & 1u;
+                    v.x = ok ? fmaxf(__builtin_fmaf(v.x, xsc.x, xsh.x), 0.f) : 0.f; v.y = ok ? fmaxf(__builtin_fmaf(v.y, xsc.y, xsh.y), 0.f) : 0.f;
+                    v.z = ok ? fmaxf(__builtin_fmaf(v.z, xsc.z, xsh.z), 0.f) : 0.f; v.w = ok ? fmaxf(__builtin_fmaf(v.w, xsc.w, xsh.w), 0.f) : 0.f;
+                }
+                if (X_F4 % 256 == 0 || idx < X_F4) *reinterpret_cast<float4*>(Xs + idx * 4) = v;
             }
         } else {
 #pragma unroll
@@ -228,6 +247,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 
 template <int TI, int TJ, int WI, int WJ, bool VEC>
 int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
+    static_assert(256 % (TJ / 4) == 0, "a lane keeps its channel quad across the passes of the x loader");
     WgradArgs p = a;
     p.tilesI = p.Cout / TI;
     p.tilesJ = VEC ? p.R * p.S * (p.Cin / TJ) : (p.K + TJ - 1) / TJ;
@@ -257,7 +277,12 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+    if constexpr (VEC) {
+        if (p.xscale) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC, true>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+    }
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -265,9 +290,11 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
 
 }  // namespace
 
-int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream) {
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in) {
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
+    a.xscale = in.scale; a.xshift = in.shift;
+    SIMQ_REQUIRE(!in.scale || g.Cin % 64 == 0, "conv_wgrad: BatchNorm-on-load needs Cin %% 64 == 0 (Cin=%d)", g.Cin);
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K();
@@ -304,6 +331,7 @@ int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int 
     a.M = M; a.K = K;
     a.tilesI = a.tilesJ = a.rows_per_split = 0;
     a.gx = (long)M * K; a.gdy = (long)M * N; a.gdw = (long)N * K;
+    a.xscale = a.xshift = nullptr;
     const double xb = 4.0 * M * K, yb = 4.0 * M * N;
     SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "wgrad_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;

@@ -86,6 +86,27 @@ __device__ __forceinline__ void w4f_at(const floatx4 (&m)[6], floatx4 (&y)[4]) {
     y[3] = d + 0.125f * m[3] - 8.f * m[4] + m[5];
 }
 
+// operand load of the input transforms: the activation itself, or (XBN) the saved pre-BatchNorm output with the BatchNorm + ReLU
+// of the layer in between applied on the way in (common.h InBn: the fma / max sequence of bn_apply, so the transform sees the
+// values bn_apply would have stored).  Out-of-image positions stay 0 either way.
+template <bool XBN>
+__device__ __forceinline__ floatx4 ld_in(const float* __restrict__ q, const floatx4& sc, const floatx4& sh) {
+    floatx4 v = *reinterpret_cast<const floatx4*>(q);
+    if constexpr (XBN) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(__builtin_fmaf(v[c], sc[c], sh[c]), 0.f);
+    }
+    return v;
+}
+template <bool XBN>
+__device__ __forceinline__ void ld_inbn(const float* __restrict__ isc, const float* __restrict__ ish, int c, floatx4& sc, floatx4& sh) {
+    sc = floatx4{1.f, 1.f, 1.f, 1.f}; sh = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (XBN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sc[k] = isc[c + k]; sh[k] = ish[c + k]; }
+    }
+}
+
 // every eligible convolution's U in one launch: blockIdx.y = table entry (source: the OHWI weight in the parameter buffer, or
 // its flipped / transposed dgrad form in the weight cache)
 __global__ void __launch_bounds__(256) wino_weight_all_kernel(const float* __restrict__ params, const float* __restrict__ wt,
@@ -141,13 +162,16 @@ __global__ void __launch_bounds__(256) wino_weight_all_kernel(const float* __res
 
 // ---- V[g][t][c] = (B^T d B)[g / 4][g % 4],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] ----
 // One thread: one tile x 4 channels (float4); the C/4 lanes of a tile read / write full contiguous rows of C floats.
+template <bool XBN>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C,
-                                                         int T) {
+                                                         int T, const float* __restrict__ isc, const float* __restrict__ ish) {
     const int lanes = C >> 2;                       // float4 lanes per tile
     const int tpb = 256 / lanes;                    // tiles per block iteration
     const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
     const int th = H >> 1, tw = W >> 1;
     const size_t gstride = (size_t)T * C;
+    floatx4 bsc, bsh;
+    ld_inbn<XBN>(isc, ish, cl * 4, bsc, bsh);
     for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
         const int b = t / (th * tw), r = t - b * (th * tw);
         const int ty = r / tw, tx = r - ty * tw;
@@ -159,7 +183,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
             for (int j = 0; j < 4; ++j) {
                 const int yy = y0 + i, xx = x0 + j;
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    d[i][j] = *reinterpret_cast<const floatx4*>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4);
+                    d[i][j] = ld_in<XBN>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4, bsc, bsh);
                 else
                     d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
@@ -194,12 +218,13 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
     const size_t gstride = (size_t)T * C;
     const int n = cl * 4;
     const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
-    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias, msc = bias, msh = bias;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (p.bias) bias[c] = p.bias[n + c];
         if (p.scale) { sc[c] = p.scale[n + c]; sh[c] = p.shift[n + c]; }
         if (bnr) { mu1[c] = p.bnr_mean1[n + c]; is1[c] = p.bnr_invstd1[n + c]; }
+        if (bnr && p.bnr_mscale) { msc[c] = p.bnr_mscale[n + c]; msh[c] = p.bnr_mshift[n + c]; }
         if (bnr2) { mu2[c] = p.bnr_mean2[n + c]; is2[c] = p.bnr_invstd2[n + c]; }
     }
     floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -230,16 +255,19 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
                 *reinterpret_cast<floatx4*>(p.y + o) = v;
                 if (bnr) {
                     floatx4 dz;
+                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
                     if (p.bnr_mask) {
                         const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
-                    } else {
+                    } else if (p.bnr_mask16) {
                         const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
                         dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
                         dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
+                    } else {                         // the activation was never stored: its sign from the pre-BN output (common.h InBn)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = __builtin_fmaf(y1[c], msc[c], msh[c]) > 0.f ? v[c] : 0.f;
                     }
-                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
                     s0 += dz;
                     s1 += dz * ((y1 - mu1) * is1);
                     if (bnr2) {
@@ -276,11 +304,15 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 
 // ---- F(4x4,3x3) forward transforms (no-grad forwards) --------------------------------------------------------------------
 // V4[g][t][c] = (B^T d B)[g / 6][g % 6] over 6x6 patches at stride 4; one thread = one tile x 4 channels
-__global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int T) {
+template <bool XBN>
+__global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int T,
+                                                           const float* __restrict__ isc, const float* __restrict__ ish) {
     const int lanes = C >> 2, tpb = 256 / lanes;
     const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
     const int th = H >> 2, tw = W >> 2;
     const size_t gstride = (size_t)T * C;
+    floatx4 bsc, bsh;
+    ld_inbn<XBN>(isc, ish, cl * 4, bsc, bsh);
     for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
         const int b = t / (th * tw), r = t - b * (th * tw);
         const int ty = r / tw, tx = r - ty * tw;
@@ -293,7 +325,7 @@ __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restri
             for (int i = 0; i < 6; ++i) {
                 const int yy = y0 + i, xx = x0 + j;
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    a[i] = *reinterpret_cast<const floatx4*>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4);
+                    a[i] = ld_in<XBN>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4, bsc, bsh);
                 else
                     a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
@@ -321,12 +353,13 @@ __global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restr
     const size_t gstride = (size_t)T * C;
     const int n = cl * 4;
     const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
-    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias;
+    floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias, msc = bias, msh = bias;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (p.bias) bias[c] = p.bias[n + c];
         if (p.scale) { sc[c] = p.scale[n + c]; sh[c] = p.shift[n + c]; }
         if (bnr) { mu1[c] = p.bnr_mean1[n + c]; is1[c] = p.bnr_invstd1[n + c]; }
+        if (bnr && p.bnr_mscale) { msc[c] = p.bnr_mscale[n + c]; msh[c] = p.bnr_mshift[n + c]; }
         if (bnr2) { mu2[c] = p.bnr_mean2[n + c]; is2[c] = p.bnr_invstd2[n + c]; }
     }
     floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -359,16 +392,19 @@ __global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restr
                 *reinterpret_cast<floatx4*>(p.y + o) = v;
                 if (bnr) {
                     floatx4 dz;
+                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
                     if (p.bnr_mask) {
                         const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
-                    } else {
+                    } else if (p.bnr_mask16) {
                         const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
                         dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
                         dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
+                    } else {                         // the activation was never stored: its sign from the pre-BN output (common.h InBn)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = __builtin_fmaf(y1[c], msc[c], msh[c]) > 0.f ? v[c] : 0.f;
                     }
-                    const floatx4 y1 = *reinterpret_cast<const floatx4*>(p.bnr_y1 + o);
                     s0 += dz;
                     s1 += dz * ((y1 - mu1) * is1);
                     if (bnr2) {
@@ -438,14 +474,18 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 // K-contiguous batched GEMM over K = T for the implicit-GEMM kernel (long K, no split / atomics).  A block covers 32 tiles x 32
 // channels: reads are 128-B channel segments, the 16 transform elements go through an LDS tile [4 g][32 c][32 t] four at a time
 // and leave as 128-B rows of 32 consecutive tiles.  DY = false: x -> (B^T d B)^T layout; DY = true: dy -> (A dY A^T).
-template <bool DY>
-__global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T) {
+template <bool DY, bool XBN = false>
+__global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T,
+                                                      const float* __restrict__ isc = nullptr, const float* __restrict__ ish = nullptr) {
+    static_assert(!(DY && XBN), "the BatchNorm-on-load form is for the activation operand");
     __shared__ float tbuf[4][32][33];
     const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
     const int cblocks = C >> 5;
     const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
     const int t = t0 + tl, c = c0 + cq * 4;
     const int th = H >> 1, tw = W >> 1;
+    floatx4 bsc, bsh;
+    ld_inbn<XBN>(isc, ish, c, bsc, bsh);
     floatx4 v[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) v[g] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -474,7 +514,7 @@ __global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ 
                 for (int j = 0; j < 4; ++j) {
                     const int yy = y0 + i, xx = x0 + j;
                     if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                        d[i][j] = *reinterpret_cast<const floatx4*>(src + ((size_t)(b * H + yy) * W + xx) * C + c);
+                        d[i][j] = ld_in<XBN>(src + ((size_t)(b * H + yy) * W + xx) * C + c, bsc, bsh);
                     else
                         d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -533,14 +573,18 @@ __device__ __forceinline__ void w4_a(const floatx4 (&y)[4], floatx4 (&r)[6]) {  
     r[5] = y[3];
 }
 
-template <bool DY>
-__global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T) {
+template <bool DY, bool XBN = false>
+__global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T,
+                                                       const float* __restrict__ isc = nullptr, const float* __restrict__ ish = nullptr) {
+    static_assert(!(DY && XBN), "the BatchNorm-on-load form is for the activation operand");
     __shared__ float tbuf[4][32][33];
     const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
     const int cblocks = C >> 5;
     const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
     const int t = t0 + tl, c = c0 + cq * 4;
     const int th = H >> 2, tw = W >> 2;
+    floatx4 bsc, bsh;
+    ld_inbn<XBN>(isc, ish, c, bsc, bsh);
     floatx4 v[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -572,7 +616,7 @@ __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__
                 for (int i = 0; i < 6; ++i) {
                     const int yy = y0 + i, xx = x0 + j;
                     if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                        a[i] = *reinterpret_cast<const floatx4*>(src + ((size_t)(b * H + yy) * W + xx) * C + c);
+                        a[i] = ld_in<XBN>(src + ((size_t)(b * H + yy) * W + xx) * C + c, bsc, bsh);
                     else
                         a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -707,7 +751,7 @@ int launch_wino_weight_all(const float* params, const float* wt, float* ubase, c
 
 // scratch: winograd_scratch_floats(g) floats (V | Mt), 16-byte aligned
 int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
-                         hipStream_t stream) {
+                         hipStream_t stream, const InBn& in) {
     SIMQ_REQUIRE(winograd_eligible(g), "conv_winograd: geometry not supported (3x3 s1 p1, even map, Cin %% 16, Cout %% 64)");
     const int T = g.B * (g.Hin / 2) * (g.Win / 2);
     SIMQ_REQUIRE((double)T * 16 * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4.0 < 68719476736.0, "conv_winograd: batch too large");
@@ -716,7 +760,8 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
     int bin = (T + tpb_in - 1) / tpb_in;
     if (bin > 4096) bin = 4096;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T);
+    if (in.scale) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
+    else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
     int bout = (T + tpb_out - 1) / tpb_out;
@@ -747,7 +792,7 @@ bool winograd_f4_forward(const ConvGeom& g, int min_tiles) {      // (simq_plan_
 // (19 batches) unchanged, +4.4 % on the step; from 256->512 down the study's tail grows (tests/diag_f4_grad_layers.py).
 
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
-                          hipStream_t stream) {
+                          hipStream_t stream, const InBn& in) {
     SIMQ_REQUIRE(winograd_eligible(g) && g.Hin % 4 == 0 && g.Win % 4 == 0, "conv_winograd4: geometry not supported");
     SIMQ_REQUIRE(!e.y_bf16, "conv_winograd4: fp32 outputs only");
     const int T4 = g.B * (g.Hin / 4) * (g.Win / 4);
@@ -756,7 +801,8 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
     int bin = (T4 + tpb_in - 1) / tpb_in;
     if (bin > 4096) bin = 4096;
-    hipLaunchKernelGGL(wino4f_input_kernel, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4);
+    if (in.scale) hipLaunchKernelGGL(wino4f_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in.scale, in.shift);
+    else hipLaunchKernelGGL(wino4f_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, nullptr, nullptr);
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream)) return rc;
     int bout = (T4 + tpb_out - 1) / tpb_out;
@@ -784,7 +830,8 @@ bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4) {
     return (long)g.Cin * g.Cout >= ((allow_f4 && winograd_wgrad_f4(g)) ? 128L * 256 : 256L * 256);
 }
 
-int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4) {
+int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4,
+                               const InBn& in) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
     const int T = g.B * (g.Hin / 2) * (g.Win / 2);
     float* Vt = scratch;                                   // [16][Cin][T]
@@ -797,8 +844,9 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][Cout][T4]
         float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][Cout][Cin]
         const int tb = (T4 + 31) / 32;
-        hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4);
-        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4);
+        if (in.scale) hipLaunchKernelGGL((wino4_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in.scale, in.shift);
+        else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, nullptr, nullptr);
+        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, nullptr, nullptr);
         SIMQ_CHECK_LAUNCH();
         if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, T4, 36, stream)) return rc;
         int blocks4 = (g.Cout * g.Cin + 255) / 256;
@@ -813,7 +861,8 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         int bin = (T + tpb_in - 1) / tpb_in, bout = (T + tpb_out - 1) / tpb_out;
         if (bin > 4096) bin = 4096;
         if (bout > 4096) bout = 4096;
-        hipLaunchKernelGGL(wino_input_kernel, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T);
+        if (in.scale) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
+        else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
         hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
         SIMQ_CHECK_LAUNCH();
         SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
@@ -821,8 +870,9 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
     } else {
         // tile index contiguous: dU[g] = dMt[g] (Cout x T) * Vt[g]^T (T x Cin) is a K-contiguous GEMM with K = T
         const int tb = (T + 31) / 32;
-        hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T);
-        hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
+        if (in.scale) hipLaunchKernelGGL((wino_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
+        else hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
+        hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T, nullptr, nullptr);
         SIMQ_CHECK_LAUNCH();
         if (int rc = launch_gemm_batched(dMt, Vt, dU, g.Cout, g.Cin, T, 16, stream)) return rc;
     }

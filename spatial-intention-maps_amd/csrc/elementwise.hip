@@ -63,6 +63,7 @@ __device__ __forceinline__ void bn_commit(const BnRef& b) {
         bn_coeff(b, c, sc, sh, m, i, md, vd);
         b.save_mean[c] = m;
         b.save_invstd[c] = i;
+        if (b.save_scale) { b.save_scale[c] = sc; b.save_shift[c] = sh; }
         const double unbiased = b.rows > 1.0 ? vd * b.rows / (b.rows - 1.0) : vd;
         b.rmean[c] = (float)(BN_MOMENTUM * md + (1.0 - BN_MOMENTUM) * (double)b.rmean[c]);
         b.rvar[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)b.rvar[c]);
@@ -84,6 +85,18 @@ __global__ void bn_eval_coeff_kernel(BnEvalTable t, const float* __restrict__ pa
         aux[d.aux_off + c] = sc;
         aux[d.aux_off + d.C + c] = sh;
     }
+}
+
+// train mode, BatchNorm applied inside its consumer (common.h InBn): scale / shift for that consumer (and for the backward pass, which
+// recomputes the activation and its ReLU mask from the saved pre-BN output with the SAME two numbers), mean / invstd for backward, the
+// running-statistics update -- what bn_apply's prologue + bn_commit do, as one small block
+__global__ void __launch_bounds__(256) bn_finalize_kernel(BnRef bn, float* __restrict__ scale, float* __restrict__ shift) {
+    for (int c = threadIdx.x; c < bn.C; c += blockDim.x) {
+        float sc, sh, m, i; double md, vd;
+        bn_coeff(bn, c, sc, sh, m, i, md, vd);
+        scale[c] = sc; shift[c] = sh;
+    }
+    bn_commit(bn);
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -222,7 +235,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const double* __restrict__ red, uint16_t* __restrict__ dy,
                                                              uint16_t* __restrict__ dz_out, float* dgamma, float* dbeta, size_t total8, int C8,
-                                                             float inv_rows, float dparam_scale) {
+                                                             float inv_rows, float dparam_scale, const float* __restrict__ mscale,
+                                                             const float* __restrict__ mshift) {
     const int C = C8 * 8;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -233,11 +247,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     const int c = (int)(i0 % C8) * 8;
     // the expression of bn_bwd_apply_kernel with the per-channel factors (gamma*invstd, dbeta/rows, dgamma/rows) formed once
-    float ka[8], mu[8], is[8], db[8], dg[8];
+    // mask16 == NULL: the ReLU mask is recomputed from the pre-BN output, (y * mscale + mshift > 0) (the activation was not stored, or
+    // need not be read: one plane less)
+    float ka[8], mu[8], is[8], db[8], dg[8], ms[8], mh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c + k]; is[k] = invstd[c + k]; ka[k] = gamma[c + k] * is[k];
         db[k] = (float)red[c + k] * inv_rows; dg[k] = (float)red[C + c + k] * inv_rows;
+        ms[k] = mask16 ? 0.f : mscale[c + k]; mh[k] = mask16 ? 0.f : mshift[c + k];
     }
     auto one = [&](uint4 gr, uint4 mr, uint4 yr, uint4& dzr) {
         F8 gv = unpack8(gr), yv = unpack8(yr), o;
@@ -246,7 +263,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const short m = (short)(k & 1 ? mw[k >> 1] >> 16 : mw[k >> 1] & 0xffffu);
-            const bool pos = m > 0;
+            const bool pos = mask16 ? m > 0 : fmaf(yv.v[k], ms[k], mh[k]) > 0.f;
             if (!pos) zw[k >> 1] &= (k & 1) ? 0x0000ffffu : 0xffff0000u;
             const float dz = pos ? gv.v[k] : 0.f;
             o.v[k] = ka[k] * (dz - db[k] - (yv.v[k] - mu[k]) * is[k] * dg[k]);
@@ -257,7 +274,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     size_t i = i0;
     for (; i + stride < total8; i += 2 * stride) {
         const uint4 g0 = ld16(g, i), g1 = ld16(g, i + stride);
-        const uint4 m0 = ld16(mask16, i), m1 = ld16(mask16, i + stride);
+        const uint4 zz = make_uint4(0, 0, 0, 0);
+        const uint4 m0 = mask16 ? ld16(mask16, i) : zz, m1 = mask16 ? ld16(mask16, i + stride) : zz;
         const uint4 y0 = ld16(y, i), y1 = ld16(y, i + stride);
         uint4 z0, z1;
         st16(dy, i, one(g0, m0, y0, z0));
@@ -266,7 +284,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     }
     if (i < total8) {
         uint4 z0;
-        st16(dy, i, one(ld16(g, i), ld16(mask16, i), ld16(y, i), z0));
+        st16(dy, i, one(ld16(g, i), mask16 ? ld16(mask16, i) : make_uint4(0, 0, 0, 0), ld16(y, i), z0));
         if (dz_out) st16(dz_out, i, z0);
     }
 }
@@ -477,7 +495,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ red, float* __restrict__ dy,
                                     float* __restrict__ dz_out, float* dgamma, float* dbeta, Planes pl, size_t rows, int C4,
-                                    int y_bf16, float inv_rows, float dparam_scale, int g_bf16) {
+                                    int y_bf16, float inv_rows, float dparam_scale, int g_bf16, const float* __restrict__ mscale,
+                                    const float* __restrict__ mshift) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -490,6 +509,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     const int c = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) % C4) * 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         float4 dz = ld4y(g, i, g_bf16);
+        const float4 yv = ld4y(y, i, y_bf16);
         if (mask) {
             float4 m = ld4(mask + i * 4);
             dz.x = m.x > 0.f ? dz.x : 0.f; dz.y = m.y > 0.f ? dz.y : 0.f;
@@ -498,12 +518,16 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
             const ushort4 m = *reinterpret_cast<const ushort4*>(mask16 + i * 4);
             dz.x = (short)m.x > 0 ? dz.x : 0.f; dz.y = (short)m.y > 0 ? dz.y : 0.f;
             dz.z = (short)m.z > 0 ? dz.z : 0.f; dz.w = (short)m.w > 0 ? dz.w : 0.f;
+        } else if (mscale) {                 // the activation was never stored: its sign from the pre-BN output (common.h InBn)
+            const float4 a = fma4(yv, ld4(mscale + c), ld4(mshift + c));
+            dz.x = a.x > 0.f ? dz.x : 0.f; dz.y = a.y > 0.f ? dz.y : 0.f;
+            dz.z = a.z > 0.f ? dz.z : 0.f; dz.w = a.w > 0.f ? dz.w : 0.f;
         }
         if (dz_out) {
             if (g_bf16) *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(dz_out) + i * 4) = make_ushort4((uint16_t)(__float_as_uint(dz.x) >> 16), (uint16_t)(__float_as_uint(dz.y) >> 16), (uint16_t)(__float_as_uint(dz.z) >> 16), (uint16_t)(__float_as_uint(dz.w) >> 16));   // (exact: dz is a bf16 value or 0)
             else st4(dz_out + i * 4, dz);
         }
-        float4 yv = ld4y(y, i, y_bf16), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
+        const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
         float db[4] = {(float)red[c], (float)red[c + 1], (float)red[c + 2], (float)red[c + 3]};
         float dg[4] = {(float)red[C + c], (float)red[C + c + 1], (float)red[C + c + 2], (float)red[C + c + 3]};
         float4 o;
@@ -689,6 +713,13 @@ int launch_bn_running_update(const double* stats, float* rmean, float* rvar, dou
     return 0;
 }
 
+int launch_bn_finalize(const BnRef& bn, float* scale, float* shift, hipStream_t stream) {
+    SIMQ_REQUIRE(bn.stats && scale && shift && bn.C >= 1, "bn_finalize: train-mode BatchNorm with scale / shift outputs expected");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, stream, bn, scale, shift);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream) {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(t.n), dim3(256), 0, stream, t, params, bnbuf, aux);
     SIMQ_CHECK_LAUNCH();
@@ -768,21 +799,22 @@ int launch_bn_bwd_reduce(const float* g, const float* mask, const float* y, cons
 int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const float* mean, const float* invstd,
                         const float* gamma, const double* red, float* dy, float* dz_out, float* dgamma, float* dbeta,
                         int64_t rows, int C, hipStream_t stream, Planes pl, const uint16_t* mask16, int y_bf16, double global_rows,
-                        float dparam_scale, int g_bf16) {
+                        float dparam_scale, int g_bf16, const float* mscale, const float* mshift) {
     SIMQ_REQUIRE(dy || pl.hi, "bn_bwd_apply: no output requested");
     SIMQ_REQUIRE(C % 4 == 0 && 256 % (C / 4) == 0, "bn_bwd_apply: C=%d unsupported", C);
-    if (g_bf16 && y_bf16 && mask16 && !mask && !dy && pl.hi && !pl.lo && C % 8 == 0 && 256 % (C / 8) == 0) {   // all-bf16 form
+    SIMQ_REQUIRE(!mscale || (mshift && !mask && !mask16), "bn_bwd_apply: the recomputed mask (mscale / mshift) excludes a mask tensor");
+    if (g_bf16 && y_bf16 && (mask16 || mscale) && !mask && !dy && pl.hi && !pl.lo && C % 8 == 0 && 256 % (C / 8) == 0) {   // all-bf16 form
         size_t total8 = (size_t)rows * (C / 8);
         hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
                            reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
-                           total8, C / 8, (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale);
+                           total8, C / 8, (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale, mscale, mshift);
         SIMQ_CHECK_LAUNCH();
         return 0;
     }
     size_t total4 = (size_t)rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, g, mask, mask16, y, mean, invstd,
                        gamma, red, dy, dz_out, dgamma, dbeta, pl, (size_t)rows, C / 4, y_bf16,
-                       (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale, g_bf16);
+                       (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale, g_bf16, mscale, mshift);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -31,6 +31,7 @@ struct EpiArgs {
     // fused BN-backward reduction (dgrad launches only)
     const float* bnr_mask;
     const uint16_t* bnr_mask16;
+    const float* bnr_mscale; const float* bnr_mshift;   // neither mask: recomputed as bnr_y1 * mscale[n] + mshift[n] > 0
     const float* bnr_y1; const float* bnr_mean1; const float* bnr_invstd1; double* bnr_red1;
     const float* bnr_y2; const float* bnr_mean2; const float* bnr_invstd2; double* bnr_red2;
 };
@@ -39,7 +40,7 @@ inline EpiArgs make_epi(float* y, const ConvEpilogue& e) {
     EpiArgs a;
     a.y = y; a.bias = e.bias; a.stats = e.stats; a.scale = e.scale; a.shift = e.shift; a.addend = e.addend; a.relu = e.relu;
     a.y_bf16 = e.y_bf16; a.bnr_y_bf16 = e.bnr_y_bf16; a.addend_bf16 = e.addend_bf16;
-    a.bnr_mask = e.bnr_mask; a.bnr_mask16 = e.bnr_mask16;
+    a.bnr_mask = e.bnr_mask; a.bnr_mask16 = e.bnr_mask16; a.bnr_mscale = e.bnr_mscale; a.bnr_mshift = e.bnr_mshift;
     a.bnr_y1 = e.bnr_y1; a.bnr_mean1 = e.bnr_mean1; a.bnr_invstd1 = e.bnr_invstd1; a.bnr_red1 = e.bnr_red1;
     a.bnr_y2 = e.bnr_y2; a.bnr_mean2 = e.bnr_mean2; a.bnr_invstd2 = e.bnr_invstd2; a.bnr_red2 = e.bnr_red2;
     return a;
@@ -64,8 +65,9 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
         const float bias = p.bias ? p.bias[n] : 0.f;
         const float sc = p.scale ? p.scale[n] : 1.f;
         const float sh = p.scale ? p.shift[n] : 0.f;
-        float mu1 = 0.f, is1 = 0.f, mu2 = 0.f, is2 = 0.f;
+        float mu1 = 0.f, is1 = 0.f, mu2 = 0.f, is2 = 0.f, msc = 0.f, msh = 0.f;
         if (bnr) { mu1 = p.bnr_mean1[n]; is1 = p.bnr_invstd1[n]; }
+        if (bnr && p.bnr_mscale) { msc = p.bnr_mscale[n]; msh = p.bnr_mshift[n]; }
         if (bnr2) { mu2 = p.bnr_mean2[n]; is2 = p.bnr_invstd2[n]; }
         // the global loads of four rows first (addend, ReLU mask, pre-BN outputs: up to 4 per element), then their arithmetic and
         // stores in the original order: element by element the loop is latency-bound (the store of one element may alias the
@@ -82,8 +84,8 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& p, floatx4 (&acc)[
                     const size_t o = (size_t)(m < M ? m : M - 1) * Cout + n;
                     adv[r] = !p.addend ? 0.f : p.addend_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.addend)[o]) : p.addend[o];
                     if (bnr) {
-                        posv[r] = p.bnr_mask ? p.bnr_mask[o] > 0.f : (short)p.bnr_mask16[o] > 0;
                         y1v[r] = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y1)[o]) : p.bnr_y1[o];
+                        posv[r] = p.bnr_mask ? p.bnr_mask[o] > 0.f : p.bnr_mask16 ? (short)p.bnr_mask16[o] > 0 : __builtin_fmaf(y1v[r], msc, msh) > 0.f;
                         if (bnr2) y2v[r] = p.bnr_y_bf16 ? epi_from_bf16(reinterpret_cast<const uint16_t*>(p.bnr_y2)[o]) : p.bnr_y2[o];
                     }
                 }
@@ -177,17 +179,19 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
     const int rl = lane / LPR;
     const int n = n0 + wn * WTN + cl;
     floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    floatx4 mu1 = sh, is1 = sh, mu2 = sh, is2 = sh;
+    floatx4 mu1 = sh, is1 = sh, mu2 = sh, is2 = sh, msc = sh, msh = sh;
+    const bool mfy = bnr && !p.bnr_mask && !p.bnr_mask16;   // the mask is recomputed from the pre-BN output
     // per-channel vectors: scalar loads (parameter tensors are only 4-byte aligned inside the flat buffer)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (p.bias) bias[c] = p.bias[n + c];
         if (p.scale) { sc[c] = p.scale[n + c]; sh[c] = p.shift[n + c]; }
         if (bnr) { mu1[c] = p.bnr_mean1[n + c]; is1[c] = p.bnr_invstd1[n + c]; }
+        if (mfy) { msc[c] = p.bnr_mscale[n + c]; msh[c] = p.bnr_mshift[n + c]; }
         if (bnr2) { mu2[c] = p.bnr_mean2[n + c]; is2[c] = p.bnr_invstd2[n + c]; }
     }
     floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    const bool batch = BATCH && bnr && !p.stats && p.y_bf16 && p.bnr_mask16 && p.bnr_y_bf16 && (!p.addend || p.addend_bf16);
+    const bool batch = BATCH && bnr && !p.stats && p.y_bf16 && (p.bnr_mask16 || mfy) && p.bnr_y_bf16 && (!p.addend || p.addend_bf16);
 #pragma unroll
     for (int ig = 0; ig < TM / RT; ++ig) {
 #pragma unroll
@@ -212,7 +216,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                     const int m = m0 + wm * (TM * 16) + ig * ROWS + (kg * KB + u) * RPI + rl;
                     off[u] = (size_t)(m < M ? m : M - 1) * Cout + n;
                     if (ad16) ha[u] = *reinterpret_cast<const ushort4*>(ad16 + off[u]);
-                    hm[u] = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + off[u]);
+                    if (!mfy) hm[u] = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + off[u]);
                     h1[u] = *reinterpret_cast<const ushort4*>(y116 + off[u]);
                     if (bnr2) h2[u] = *reinterpret_cast<const ushort4*>(y216 + off[u]);
                 }
@@ -228,9 +232,14 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                         if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         *reinterpret_cast<ushort4*>(out16 + off[u]) = make_ushort4(epi_to_bf16(v[0]), epi_to_bf16(v[1]), epi_to_bf16(v[2]), epi_to_bf16(v[3]));
                         floatx4 dz;
-                        dz[0] = (short)hm[u].x > 0 ? v[0] : 0.f; dz[1] = (short)hm[u].y > 0 ? v[1] : 0.f;
-                        dz[2] = (short)hm[u].z > 0 ? v[2] : 0.f; dz[3] = (short)hm[u].w > 0 ? v[3] : 0.f;
                         const floatx4 y1 = {epi_from_bf16(h1[u].x), epi_from_bf16(h1[u].y), epi_from_bf16(h1[u].z), epi_from_bf16(h1[u].w)};
+                        if (mfy) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dz[c] = __builtin_fmaf(y1[c], msc[c], msh[c]) > 0.f ? v[c] : 0.f;
+                        } else {
+                            dz[0] = (short)hm[u].x > 0 ? v[0] : 0.f; dz[1] = (short)hm[u].y > 0 ? v[1] : 0.f;
+                            dz[2] = (short)hm[u].z > 0 ? v[2] : 0.f; dz[3] = (short)hm[u].w > 0 ? v[3] : 0.f;
+                        }
                         s0 += dz;
                         s1 += dz * ((y1 - mu1) * is1);
                         if (bnr2) {
@@ -269,22 +278,25 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                     *reinterpret_cast<floatx4*>(p.y + o) = v;
                 }
                 if (bnr) {
-                    floatx4 dz;
-                    if (p.bnr_mask) {
-                        const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
-                    } else {
-                        const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
-                        dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
-                        dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
-                    }
                     auto ldy = [&](const float* q) -> floatx4 {
                         if (!p.bnr_y_bf16) return *reinterpret_cast<const floatx4*>(q + o);
                         const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(q) + o);
                         return floatx4{epi_from_bf16(h.x), epi_from_bf16(h.y), epi_from_bf16(h.z), epi_from_bf16(h.w)};
                     };
                     const floatx4 y1 = ldy(p.bnr_y1);
+                    floatx4 dz;
+                    if (p.bnr_mask) {
+                        const floatx4 mk = *reinterpret_cast<const floatx4*>(p.bnr_mask + o);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = mk[c] > 0.f ? v[c] : 0.f;
+                    } else if (p.bnr_mask16) {
+                        const ushort4 mk = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + o);
+                        dz[0] = (short)mk.x > 0 ? v[0] : 0.f; dz[1] = (short)mk.y > 0 ? v[1] : 0.f;
+                        dz[2] = (short)mk.z > 0 ? v[2] : 0.f; dz[3] = (short)mk.w > 0 ? v[3] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = __builtin_fmaf(y1[c], msc[c], msh[c]) > 0.f ? v[c] : 0.f;
+                    }
                     s0 += dz;
                     s1 += dz * ((y1 - mu1) * is1);
                     if (bnr2) {

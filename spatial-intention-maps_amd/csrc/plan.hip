@@ -272,6 +272,15 @@ struct Ctx {
     // for FCN.saved_activation / tests/diag; the unfused BatchNorm-backward reductions read them too)
     bool planes_only() const { return mc() && !p->opt.keep_fp32_activations && p->opt.fuse_bn_backward_sums; }
     Act block_act(int64_t off, int64_t poff, int64_t elems) const { Act a = act(off, poff, elems); a.fv = !planes_only(); return a; }
+    // fp32 plans: BatchNorm 1 of every BasicBlock and of the head is applied by the CONSUMING convolution while it stages its operand
+    // (common.h InBn); the activation between the two convolutions is never stored, backward recomputes it / its mask from the pre-BN output
+    bool lazy1() const { return !mc() && p->opt.fuse_bn1_apply && p->opt.fuse_bn_backward_sums; }
+    // ... plain-bf16 plans still store that activation (their convolutions DMA operands straight into LDS), but backward takes its ReLU
+    // mask from the saved pre-BN output instead of reading the plane again
+    bool mask1_from_y() const {
+        return lazy1() || (p->precision == SIMQ_PREC_BF16 && p->opt.bn1_mask_from_preact && planes_only());
+    }
+    InBn inbn(const BnL& b) const { InBn in; in.scale = aux(b, 0); in.shift = aux(b, 1); return in; }
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
         uint16_t* base = reinterpret_cast<uint16_t*>(wc + (transposed ? W.wtpl : W.wpl));
@@ -290,8 +299,11 @@ ConvGeom geom(const ConvL& c, int B, int hin) {
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // `nograd`: nothing will be differentiated through this forward (eval / train-no-grad modes): the Winograd layers may use F(4x4,3x3)
-int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e, bool nograd = false) {
+// `in`: x is the pre-BatchNorm output of the producing convolution, the BatchNorm + ReLU in between is applied on load (fp32 plans)
+int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e, bool nograd = false,
+             const InBn& in = InBn()) {
     if (c.mc() && cv.wp_off >= 0) {
+        SIMQ_REQUIRE(!in.scale, "conv_fwd: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* wsp[2];
         c.wplanes(cv, false, wsp);
@@ -301,20 +313,20 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
                              (c.p->opt.winograd_f4_fwd_grad_min_cc > 0 && (long)g.Cin * g.Cout >= c.p->opt.winograd_f4_fwd_grad_min_cc);
     if ((nograd || f4_grad_fwd) && cv.wu4_off >= 0 && c.L.wino >= 0 && c.p->opt.winograd_f4_forward &&
         winograd_f4_forward(g, c.p->opt.winograd_f4_min_tiles))
-        return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream);
+        return launch_conv_winograd4(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu4_off, y, g, e, c.f(c.L.wino), c.stream, in);
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_eligible(g))
-        return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream);
-    return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream);
+        return launch_conv_winograd(x.f, reinterpret_cast<const float*>(c.wc + c.W.wu) + cv.wu_off, y, g, e, c.f(c.L.wino), c.stream, in);
+    return launch_conv_igemm(x.f, c.params + cv.w_off, y, g, e, c.stream, in);
 }
 
 // conv (+bias); in train modes its epilogue accumulates the BatchNorm batch statistics of `bn`
-int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x, float* y, int hin) {
+int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x, float* y, int hin, const InBn& in = InBn()) {
     ConvGeom g = geom(cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
     e.y_bf16 = c.ybf(cv);
-    RC(conv_fwd(c, cv, x, y, g, e, mode != SIMQ_MODE_TRAIN));
+    RC(conv_fwd(c, cv, x, y, g, e, mode != SIMQ_MODE_TRAIN, in));
     if (mode != SIMQ_MODE_EVAL) RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));     // SyncBN: [sum | sum of squares] over all ranks
     return 0;
 }
@@ -326,6 +338,7 @@ BnRef bnref(const Ctx& c, const BnL& bn, int mode, int64_t rows) {
     r.gamma = c.params + bn.g_off; r.beta = c.params + bn.b_off;
     r.rmean = c.bnbuf + bn.buf_off; r.rvar = c.bnbuf + bn.buf_off + bn.C;
     r.save_mean = c.aux(bn, 2); r.save_invstd = c.aux(bn, 3);
+    if (mode != SIMQ_MODE_EVAL) { r.save_scale = c.aux(bn, 0); r.save_shift = c.aux(bn, 1); }     // (backward: mask1_from_y)
     r.rows = c.bn_rows(rows); r.inv_rows = 1.0 / r.rows; r.C = bn.C;
     return r;
 }
@@ -453,9 +466,15 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
             continue;
         }
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
+        if (c.lazy1()) {                                      // bn1 + ReLU inside conv2's operand staging: a1 is never written
+            RC(launch_bn_finalize(bnref(c, b.b1, mode, rows), c.aux(b.b1, 0), c.aux(b.b1, 1), c.stream));
+            Act y1; y1.f = c.f(o.y1);
+            RC(conv_bn(c, b.c2, b.b2, mode, y1, c.f(o.y2), 24, c.inbn(b.b1)));
+        } else {
         RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.fv ? a1.f : nullptr, rows, b.planes, c.stream, a1.pl,
                            Planes(), c.ybf()));
         RC(conv_bn(c, b.c2, b.b2, mode, a1, c.f(o.y2), 24));
+        }
         if (b.has_ds) {
             RC(conv_bn(c, b.ds, b.bds, mode, cur, c.f(o.yd), 24));
             const BnRef rd = bnref(c, b.bds, mode, rows);
@@ -483,14 +502,20 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(conv_bn_folded(c, p->h1, p->hb1, cur, a1.f, 24, nullptr, 1));
     } else {
         RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-        RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
+        if (c.lazy1()) RC(launch_bn_finalize(bnref(c, p->hb1, mode, rows), c.aux(p->hb1, 0), c.aux(p->hb1, 1), c.stream));
+        else RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
     }
     {
         ConvGeom g2 = geom(p->h2, c.B, 24);
         ConvEpilogue e2;
         if (p->h2.b_off >= 0) e2.bias = c.params + p->h2.b_off;
         if (folded) { e2.scale = c.aux(p->hb2, 0); e2.shift = c.aux(p->hb2, 1); }     // eval: the affine map commutes with the upsample too
-        RC(conv_fwd(c, p->h2, a1, z2, g2, e2, mode != SIMQ_MODE_TRAIN));
+        if (!folded && c.lazy1()) {                            // (head bn1 + ReLU inside conv2's operand staging, as in the blocks)
+            Act yh1; yh1.f = c.f(L.yh1);
+            RC(conv_fwd(c, p->h2, yh1, z2, g2, e2, mode != SIMQ_MODE_TRAIN, c.inbn(p->hb1)));
+        } else {
+            RC(conv_fwd(c, p->h2, a1, z2, g2, e2, mode != SIMQ_MODE_TRAIN));
+        }
     }
     if (folded) {
         RC(launch_upsample2x_fwd(z2, c.f(L.ah2), B, 24, 24, 32, c.stream, Planes(), nullptr, 1));          // ... the ReLU does not
@@ -518,9 +543,11 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
 // `dy.fv == false`: only the planes of dy are written
 // `y_bf16`: y is the bf16 pre-BN output of a matrix-core convolution (Ctx::ybf)
 // `g_bf16`: g (and dz_out) are bf16 behind the float pointers (Ctx::gbf: the activation gradients of plain-bf16 plans)
+// `mask_from_y`: no mask tensor -- the activation's sign is recomputed from y with the scale / shift the forward pass saved (Ctx::mask1_from_y)
 int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const float* y, const Act& dy, float* dz_out, int64_t rows,
-           bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1, int g_bf16 = 0) {
+           bool reduced = false, const uint16_t* mask16 = nullptr, int y_bf16 = -1, int g_bf16 = 0, bool mask_from_y = false) {
     if (y_bf16 < 0) y_bf16 = c.ybf();
+    SIMQ_REQUIRE(!mask_from_y || (reduced && !mask && !mask16), "bn_bwd: the recomputed mask needs the fused reduction and no mask tensor");
     if (!reduced) {
         if (bn.C <= 128) {                                   // (blocks finish together: replicated slots)
             double* rep = reinterpret_cast<double*>(c.ws + c.L.colsum);
@@ -534,20 +561,22 @@ int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const
     RC(c.sync_reduce(c.red(bn), 2 * (int64_t)bn.C));                                   // SyncBN: [sum dz | sum dz*xhat] over all ranks
     return launch_bn_bwd_apply(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), c.params + bn.g_off, c.red(bn), dy.fv ? dy.f : nullptr, dz_out,
                                c.grads + bn.g_off, c.grads + bn.b_off, rows, bn.C, c.stream, dy.pl, mask16, y_bf16,
-                               c.sync ? c.bn_rows(rows) : 0.0, c.sync ? 1.f / (float)c.sync->world_size : 1.f, g_bf16);
+                               c.sync ? c.bn_rows(rows) : 0.0, c.sync ? 1.f / (float)c.sync->world_size : 1.f, g_bf16,
+                               mask_from_y ? c.aux(bn, 0) : nullptr, mask_from_y ? c.aux(bn, 1) : nullptr);
 }
 
-int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin) {
+int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin, const InBn& in = InBn()) {
     ConvGeom g = geom(cv, c.B, hin);
     if (c.mc() && cv.wp_off >= 0) {
+        SIMQ_REQUIRE(!in.scale, "conv_wgrad: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream, c.L.wslab >= 0 ? c.f(c.L.wslab) : nullptr);
     }
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && c.p->opt.winograd_wgrad &&
         winograd_wgrad_pays(g, c.p->opt.winograd_wgrad_f4 != 0))
-        return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream, c.p->opt.winograd_wgrad_f4 != 0);
-    return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream);
+        return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream, c.p->opt.winograd_wgrad_f4 != 0, in);
+    return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream, in);
 }
 
 // dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
@@ -616,19 +645,26 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
         RC(launch_colsum_rep(t2.f, cs, c.grads + p->h2.b_off, rows, 32, kStatReplicas, c.stream));   // (the bilinear weights of a pixel sum to 1)
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
-        RC(conv_wgrad(c, p->h2, a1, t2, 24));
+        if (c.lazy1()) {                                             // (a1 was never stored: conv2's weight gradient re-applies bn1 + ReLU to yh1)
+            Act yh1; yh1.f = c.f(L.yh1);
+            RC(conv_wgrad(c, p->h2, yh1, t2, 24, c.inbn(p->hb1)));
+        } else {
+            RC(conv_wgrad(c, p->h2, a1, t2, 24));
+        }
         ConvEpilogue fh;                                             // ... whose epilogue also leaves BatchNorm 1's backward sums
         // (fp32 plans: 35 us of reduction pass saved.  The matrix-core plans keep the pass: their K = 32 dgrad runs the register-staged
         // kernel, whose scalar epilogue makes the fused form 108 us against 30 + 61 us at B = 128.)
         const bool fuse_hb1 = !no_fuse_head && !c.mc();
         if (fuse_hb1) {
-            fh.bnr_mask = c.f(L.ah1); fh.bnr_y1 = c.f(L.yh1); fh.bnr_y_bf16 = c.ybf();
+            if (c.lazy1()) { fh.bnr_mscale = c.aux(p->hb1, 0); fh.bnr_mshift = c.aux(p->hb1, 1); }
+            else fh.bnr_mask = c.f(L.ah1);
+            fh.bnr_y1 = c.f(L.yh1); fh.bnr_y_bf16 = c.ybf();
             fh.bnr_mean1 = c.aux(p->hb1, 2); fh.bnr_invstd1 = c.aux(p->hb1, 3); fh.bnr_red1 = c.red(p->hb1);
         }
         RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24, fh));         // gradient w.r.t. a1
         hb1_fused = fuse_hb1;
     }
-    RC(bn_bwd(c, p->hb1, S[2], c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused));
+    RC(bn_bwd(c, p->hb1, S[2], c.lazy1() ? nullptr : c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused, nullptr, -1, 0, c.lazy1()));
     RC(launch_colsum_rep(S[0], cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, c.stream));
     RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
     }
@@ -667,20 +703,27 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         const bool po = c.planes_only();
         T0.fv = T1.fv = !po;
         const float* m_out = po ? nullptr : c.f(o.out);
-        const float* m_a1 = po ? nullptr : c.f(o.a1);
+        const bool mfy = c.mask1_from_y() && !no_fuse;       // bn1's ReLU mask from y1 (fp32: a1 does not exist; bf16: one plane less to read)
+        const float* m_a1 = (po || mfy) ? nullptr : c.f(o.a1);
         const uint16_t* m16_out = po ? c.planes(o.p_out, rows * b.planes).hi : nullptr;
-        const uint16_t* m16_a1 = po ? c.planes(o.p_a1, rows * b.planes).hi : nullptr;
+        const uint16_t* m16_a1 = (po && !mfy) ? c.planes(o.p_a1, rows * b.planes).hi : nullptr;
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
         RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out, -1, gb));
         if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out, -1, gb));
-        RC(conv_wgrad(c, b.c2, a1, T0, 24));
+        if (c.lazy1()) {                                     // (a1 was never stored: the weight gradient re-applies bn1 + ReLU to y1)
+            Act y1; y1.f = c.f(o.y1);
+            RC(conv_wgrad(c, b.c2, y1, T0, 24, c.inbn(b.b1)));
+        } else {
+            RC(conv_wgrad(c, b.c2, a1, T0, 24));
+        }
         ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
         if (!no_fuse) {
         f1.bnr_y_bf16 = c.ybf();
+        if (mfy) { f1.bnr_mscale = c.aux(b.b1, 0); f1.bnr_mshift = c.aux(b.b1, 1); }
         f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1, gb));
-        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1, -1, gb));
+        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1, -1, gb, mfy));
         RC(conv_wgrad(c, b.c1, xin, T0, 24));
         const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {
@@ -742,6 +785,7 @@ void simq_plan_options_default(simq_plan_options* o) {
     o->winograd_f4_grad = 2; o->winograd_f4_fwd_grad_min_cc = 512 * 512; o->winograd_wgrad = 1; o->winograd_wgrad_f4 = 1;
     o->stem_bf16 = 1; o->bf16_act_grads = 1; o->keep_fp32_activations = 0; o->fold_eval_bn_bf16 = 1;
     o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
+    o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1;
 }
 
 int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out) {
@@ -854,7 +898,12 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
     int ch = 0;
     if (n == "stem.conv") { off = L.y0; ch = 64; cnt = (int64_t)batch * 2304 * 64; }
     else if (n == "stem.pool") { off = L.pooled; ch = 64; cnt = (int64_t)batch * 576 * 64; }
-    else if (n == "head.a1") { off = L.ah1; ch = 128; cnt = (int64_t)batch * 576 * 128; }
+    else if (n == "head.a1") {
+        SIMQ_REQUIRE(plan->precision != SIMQ_PREC_FP32 || !plan->opt.fuse_bn1_apply || !plan->opt.fuse_bn_backward_sums,
+                     "workspace_tensor: head.a1 is not stored by this plan (simq_plan_options.fuse_bn1_apply: the head's BatchNorm 1 + ReLU is "
+                     "applied inside conv2's operand staging); create the plan with fuse_bn1_apply = 0 to inspect it");
+        off = L.ah1; ch = 128; cnt = (int64_t)batch * 576 * 128;
+    }
     else if (n == "head.a2") { off = L.ah2; ch = 32; cnt = (int64_t)batch * 2304 * 32; }
     else {
         int li = 0, bi = 0;
@@ -1204,6 +1253,50 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_w, const float* d_bias,
+                              float* d_y, int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
+                              float* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_y_pre && d_in_scale && d_in_shift && d_w && d_y && batch >= 1, "conv2d_fwd_bnrelu_in: bad argument");
+    SIMQ_REQUIRE(form >= 0 && form <= 2 && (form == 0 || d_scratch), "conv2d_fwd_bnrelu_in: form %d (0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3) with scratch)", form);
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    ConvEpilogue e;
+    e.bias = d_bias;
+    InBn in; in.scale = d_in_scale; in.shift = d_in_shift;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 0) {
+        SIMQ_REQUIRE(cin % 16 == 0, "conv2d_fwd_bnrelu_in: cin %% 16 == 0 (cin=%d)", cin);
+        return launch_conv_igemm(d_y_pre, d_w, d_y, g, e, st, in);
+    }
+    SIMQ_REQUIRE(winograd_eligible(g) && (form == 1 || (hin % 4 == 0 && win % 4 == 0)), "conv2d_fwd_bnrelu_in: geometry not supported by the Winograd forms");
+    WinoWeightTable t;
+    t.n = 1;
+    t.d[0] = WinoWeightDesc{0, 0, cout, cin, 0, form == 2 ? 1 : 0};
+    RC(launch_wino_weight_all(d_w, nullptr, d_scratch, t, st));
+    const size_t planes = form == 2 ? 36 : 16;
+    if (form == 2) return launch_conv_winograd4(d_y_pre, d_scratch, d_y, g, e, d_scratch + planes * cout * cin, st, in);
+    return launch_conv_winograd(d_y_pre, d_scratch, d_y, g, e, d_scratch + planes * cout * cin, st, in);
+}
+
+int simq_conv2d_wgrad_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_dy, float* d_dw,
+                                int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
+                                float* d_scratch, void* stream) {
+    SIMQ_REQUIRE(d_y_pre && d_in_scale && d_in_shift && d_dy && d_dw && batch >= 1, "conv2d_wgrad_bnrelu_in: bad argument");
+    SIMQ_REQUIRE(form == 0 || (form == 1 && d_scratch), "conv2d_wgrad_bnrelu_in: form %d (0 direct, 1 transform domain with scratch)", form);
+    ConvGeom g;
+    g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
+    g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
+    InBn in; in.scale = d_in_scale; in.shift = d_in_shift;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 1) {
+        SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv2d_wgrad_bnrelu_in: geometry not supported (even map, cin %% 128, cout %% 128)");
+        return launch_conv_wgrad_winograd(d_y_pre, d_dy, d_dw, g, d_scratch, st, true, in);
+    }
+    SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
+    return launch_conv_wgrad(d_y_pre, d_dy, d_dw, g, st, in);
 }
 
 int simq_conv2d_fwd_stem_f32(const float* d_x, const float* d_w, float* d_y, int batch, int hin, int win, int cin, double* d_stats, void* stream) {

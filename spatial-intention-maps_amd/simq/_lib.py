@@ -47,7 +47,7 @@ class PlanOptions(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
         'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
-        'fuse_bn_backward_sums', 'fuse_stem_backward_sums')]
+        'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'bn1_mask_from_preact')]
 
 
 class TrainArgs(ctypes.Structure):
@@ -121,6 +121,8 @@ _SIGS = {
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_fwd_bnrelu_in': (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
+    'simq_conv2d_wgrad_bnrelu_in': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_stem_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_wgrad_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
