@@ -80,6 +80,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='override: transitions per GPU (and net) per step (tools only)')
     ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
+    ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
+    ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo only to debug the rank logic on one GPU)')
     return ap.parse_args()
@@ -98,12 +100,48 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+class Watchdog:
+    """A collective that never completes would hold the whole GPU lease: every phase of a multi-rank run is bracketed by a timer
+    that, on expiry, prints WHICH rank is stuck WHERE (phase, step, libsimq's count of enqueued / completed collectives) and ends the
+    process with a non-zero status, so the launcher tears the other ranks down."""
+
+    def __init__(self, rank, seconds, enabled, progress=None):
+        self.rank, self.seconds, self.enabled, self.progress = rank, seconds, enabled, progress
+        self.label, self.timer = None, None
+
+    def _fire(self):
+        extra = ''
+        if self.progress is not None:
+            try:
+                extra = ' | ' + self.progress()
+            except Exception as ex:        # noqa: BLE001
+                extra = ' | (no progress report: %r)' % (ex,)
+        print('bench WATCHDOG: rank %d made no progress for %d s in [%s]%s -- exiting' % (self.rank, self.seconds, self.label, extra),
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def arm(self, label):
+        self.disarm()
+        if not self.enabled:
+            return
+        import threading
+        self.label = label
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def cpu_baseline(cin, cout, batch):
     """The oracle (CPU restatement, pinned bit-exact to the reference in the build container) running the SAME step on this
-    box's host cores.  Bounded sample (~10-30 s): per thread count of the sweep 1 warm-up + up to 2 timed train() calls at the
-    GPU workload's batch size (capped at 32; the rate is flat in the batch); the best count is reported.  A count whose
-    warm-up call is already 3x slower than the best so far is not timed further (oversubscribing a 256-thread host made MKL-DNN
-    30x slower)."""
+    box's host cores.  Bounded sample (~20-30 s): a sweep over thread counts (1 warm-up + 1 timed train() call each, at the GPU
+    workload's batch size capped at 32 -- the rate is flat in the batch), then THREE more timed calls at the winning
+    count; `value` is the rate over those three.  A count whose warm-up call is already 3x slower than the best so far is not
+    timed further (oversubscribing a 256-thread host made MKL-DNN 30x slower)."""
     import torch
     from oracle import cases, fcn as ofcn, learner as olearner
     from simq import synth
@@ -116,33 +154,40 @@ def cpu_baseline(cin, cout, batch):
     spec = ofcn.state_spec(cin, cout)
     trs = synth.make_transitions(batch, cin, cout, 3, terminal_frac=0.1)
     b = olearner.Transition(*zip(*trs))
+
+    def fresh():
+        return (ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 1)), ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 2)),
+                [None] * len(olearner.grad_keys(spec)))
+
+    def call(st, tg, mom):
+        t0 = time.perf_counter()
+        olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
+        return time.perf_counter() - t0
+
     results, best_call = [], None
     t_all = time.perf_counter()
     for nthreads in sweep:
-        if time.perf_counter() - t_all > 25:
+        if time.perf_counter() - t_all > 20:
             break
         torch.set_num_threads(nthreads)
-        st = ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 1))
-        tg = ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 2))
-        mom = [None] * len(olearner.grad_keys(spec))
-        t0 = time.perf_counter()
-        olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
-        warm = time.perf_counter() - t0
+        st, tg, mom = fresh()
+        warm = call(st, tg, mom)
         if best_call is not None and warm > 3 * best_call:
-            results.append((batch / warm, nthreads, 0, warm, warm))
+            results.append((batch / warm, nthreads))
             continue
-        steps = 2 if warm < 6 else 1
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            olearner.train_step(cfg, st, tg, spec, mom, b, GAMMA, LR, MOMENTUM, WD)
-        dt = time.perf_counter() - t0
-        best_call = dt / steps if best_call is None else min(best_call, dt / steps)
-        results.append((batch * steps / dt, nthreads, steps, warm, dt))
-    rate, nthreads, steps, warm, dt = max(results)
-    return {'value': round(rate, 3), 'unit': 'transitions/s', 'cores': nthreads, 'kind': 'port',
-            'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), Cin %d, batch %d, 1 warm-up (%.1f s) + '
-                      '%d timed calls (%.1f s) at the best thread count; sweep %s tr/s; host reports %d CPUs (%d usable)'
-                      % (cin, batch, warm, steps, dt, ', '.join('%d thr: %.1f' % (n, r) for r, n, _, _, _ in results),
+        dt = call(st, tg, mom)
+        best_call = dt if best_call is None else min(best_call, dt)
+        results.append((batch / dt, nthreads))
+    rate_sweep, nthreads = max(results)
+    torch.set_num_threads(nthreads)
+    st, tg, mom = fresh()
+    warm = call(st, tg, mom)
+    calls = [call(st, tg, mom) for _ in range(3)]
+    rate = 3 * batch / sum(calls)
+    return {'value': round(rate, 3), 'unit': 'transitions/s', 'cores': nthreads, 'kind': 'port', 'timed_calls': 3,
+            'sample': 'oracle train_step (== reference train.py:108-141 on torch-CPU/MKL-DNN fp32), Cin %d, batch %d: thread-count sweep (1 warm-up + 1 timed '
+                      'call each: %s tr/s), then 1 warm-up (%.1f s) + 3 timed calls (%s s) at the best count = `cores`; host reports %d CPUs (%d usable)'
+                      % (cin, batch, ', '.join('%d thr: %.1f' % (n, r) for r, n in results), warm, ' / '.join('%.2f' % c for c in calls),
                          os.cpu_count() or 0, avail)}
 
 
@@ -251,12 +296,15 @@ def main():
     if pg is not None:
         transport = 'torch.distributed (%s)' % args.backend
         if args.backend == 'nccl' and os.environ.get('SIMQ_BENCH_COMM', '1') != '0':
+            boot = Watchdog(rank, args.watchdog_seconds, args.watchdog_seconds > 0)
+            boot.arm('simq_comm construction (RCCL identifier broadcast + ncclCommInitRank)')
             try:
                 comm = sdist.Comm(pg, dev)
             except Exception as ex:            # noqa: BLE001  (collective failure: every rank is here)
                 if rank == 0:
                     print('bench: simq_comm unavailable (%r); using torch.distributed collectives' % (ex,), file=sys.stderr)
                 comm = None
+            boot.arm('simq_comm probe all-reduce against torch.distributed')
             if comm is not None:
                 probe = torch.arange(1024, dtype=torch.float32, device=dev) * (rank + 1)
                 want = probe.clone()
@@ -282,11 +330,23 @@ def main():
                 else:
                     transport = 'libsimq simq_comm (RCCL, library-owned stream)'
                     comm_world = comm.world_size()
+            boot.disarm()
 
-    def barrier():
+    # multi-rank runs: a phase that makes no progress for --watchdog-seconds ends the process with a diagnosis (a hang would hold the lease)
+    def comm_progress():
+        if comm is None:
+            return 'transport %s' % transport
+        pr = comm.progress()
+        return 'simq_comm: %d collectives enqueued, %d completed, last = %s' % (pr['enqueued'], pr['completed'], pr['last'])
+
+    dog = Watchdog(rank, args.watchdog_seconds, world > 1 and args.watchdog_seconds > 0, comm_progress)
+
+    def barrier(label='barrier'):
+        dog.arm(label)
         if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
+        dog.disarm()
 
     def run_workload(nets, B, precision, steps, warmup, replay_items):
         """nets: [(Cin, Cout)] -- one policy/target pair, optimiser state and replay ring per robot group (train.py:180-195);
@@ -336,17 +396,43 @@ def main():
                     sys.exit('bench: non-finite loss %r' % (info,))
             return info
 
-        for _ in range(warmup):
+        for i in range(warmup):
+            dog.arm('%s warm-up step %d of %d' % (precision, i + 1, warmup))
             info = step()
-        barrier()
+        barrier('barrier behind the warm-up')
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            dog.arm('%s timed step %d of %d' % (precision, i + 1, steps))
             info = step()
-        barrier()
+        barrier('barrier behind the timed steps')
         dt = time.perf_counter() - t0
         if pg is not None:
             dt = sdist.max_over_ranks(dt, dev, pg)
         value = gB * len(groups) * steps / dt
+
+        # sustained leg (extra key, never `value`): the driver's 20 steps are ~0.2 s -- on a power-managed part that is a cold-clock
+        # number.  The same step for >= --sustained-seconds more, in windows of ~0.5 s (a device synchronisation between windows only).
+        sustained = None
+        if args.sustained_seconds > 0:
+            per = max(1, int(round(0.5 / (dt / steps))))
+            rates, n_done, t_s0 = [], 0, time.perf_counter()
+            while time.perf_counter() - t_s0 < args.sustained_seconds or len(rates) < 2:
+                t_w = time.perf_counter()
+                for i in range(per):
+                    dog.arm('%s sustained window %d step %d' % (precision, len(rates) + 1, i + 1))
+                    info_s = step()
+                barrier('barrier behind a sustained window')
+                dw = time.perf_counter() - t_w
+                if pg is not None:
+                    dw = sdist.max_over_ranks(dw, dev, pg)
+                rates.append(gB * len(groups) * per / dw)
+                n_done += per
+                if len(rates) >= 64:
+                    break
+            total = time.perf_counter() - t_s0
+            sustained = {'transitions_per_s': round(gB * len(groups) * n_done / total, 1), 'seconds': round(total, 2), 'steps': n_done,
+                         'window_steps': per, 'windows': len(rates), 'window_min': round(min(rates), 1), 'window_max': round(max(rates), 1),
+                         'vs_timed_window': round(gB * len(groups) * n_done / total / value, 4), 'last_loss': info_s['loss']}
 
         # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
         # backward only -- no next-state forwards, all-reduce, clip or SGD.  Reported beside the full-step `value`, never instead of it.
@@ -377,7 +463,8 @@ def main():
             dt_m1 = time.perf_counter() - t2
             if pg is not None:
                 dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
-        return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'B': B, 'gB': gB, 'n_nets': len(groups),
+        dog.disarm()
+        return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'B': B, 'gB': gB, 'n_nets': len(groups), 'sustained': sustained,
                 'm1': None if args.no_m1 else gB * len(groups) * steps / dt_m1, 'groups': groups}
 
     def roofline_pass(step_fn, steps, precision, ms_per_step, per_gpu_rate):
@@ -450,7 +537,7 @@ def main():
         ranks_roof = per_rank(roof)
         if ranks_roof is not None:
             roof['per_rank'] = ranks_roof
-    m1, dt_m1, n_nets = w['m1'], w['dt_m1'], w['n_nets']
+    m1, dt_m1, n_nets, sustained = w['m1'], w['dt_m1'], w['n_nets'], w['sustained']
     release(w)
 
     cpu = None
@@ -474,7 +561,8 @@ def main():
                       'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / args.steps * 1e3, 3),
                       'steps': args.steps, 'warmup': args.warmup, 'scaling': xl['scaling'],
                       'fwd_bwd_only_transitions_per_s': None if e['m1'] is None else round(e['m1'], 1),
-                      'fwd_bwd_only_ms_per_step': None if e['m1'] is None else round(e['dt_m1'] / args.steps * 1e3, 3), 'last_loss': e['info']['loss']}
+                      'fwd_bwd_only_ms_per_step': None if e['m1'] is None else round(e['dt_m1'] / args.steps * 1e3, 3), 'last_loss': e['info']['loss'],
+                      'sustained': e['sustained']}
             if not args.no_roofline:
                 roof_x = roofline_pass(e['step'], args.steps, xl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
             release(e)
@@ -502,8 +590,17 @@ def main():
                        'gradient_transport': transport, 'simq_comm_world_size': comm_world, 'backend': args.backend if world > 1 else None,
                        'flop_per_transition': flop_m2, 'flop_per_transition_fwd_bwd_only': flop_m1,
                        'last_loss': info['loss'], 'last_td_error': info['td_error']},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained,
         }
+        # BASELINE.md publishes no number for this metric (BASELINE.json "published": {}), so `vs_baseline` stays null by the bench
+        # contract; what exists is north_star's TARGET -- ">= 10k Q-map forward+backward transitions/sec ... at 1 GPU" -- and `vs_target`
+        # is the ratio to it.  The target is a forward+backward (M1) rate; fp32 arithmetic cannot reach it on this part (the direct-
+        # convolution fp32 MFMA ceiling is 4.04 k tr/s), the bf16 leg is the one that does.
+        target = 10000.0
+        vs_target = {'target': 'north_star: >= 10 000 Q-map forward+backward transitions/s on synthetic 96x96xC batches at 1 GPU', 'target_value': target,
+                     'applies_to': 'per-GPU forward+backward rate (value_fwd_bwd_only / n_gpus)',
+                     'this_workload_fwd_bwd': None if m1 is None else round(m1 / world / target, 4),
+                     'this_workload_full_step': round(value / world / target, 4)}
         if extras is not None:
             key = 'bf16_configs2' if extra_name == 'configs2' else extra_name
             line[key] = extras
@@ -511,10 +608,17 @@ def main():
             for k in ('full_step_transitions_per_s', 'fwd_bwd_only_transitions_per_s', 'ms_per_step'):
                 if k in extras:
                     line['config'][key + '_' + k] = extras[k]
+            if extras.get('fwd_bwd_only_transitions_per_s') is not None:
+                vs_target[key + '_fwd_bwd'] = round(extras['fwd_bwd_only_transitions_per_s'] / world / target, 4)
+                vs_target[key + '_full_step'] = round(extras['full_step_transitions_per_s'] / world / target, 4)
+            if extras.get('sustained'):
+                line['config'][key + '_sustained_transitions_per_s'] = extras['sustained']['transitions_per_s']
             if roof_x is not None and roof is not None:
                 for k in ('achieved', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step',
                           'whole_step_executed_frac', 'wgrad_frac', 'all_gemm_tiles_frac'):
                     line['roofline'][key + '_' + k] = roof_x[k]
+        line['vs_target'] = vs_target
+        line['vs_baseline_note'] = 'null: BASELINE.md holds no published number for this metric; see vs_target for the ratio to the north_star target'
         print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()

@@ -278,6 +278,10 @@ int simq_comm_rank(const simq_comm* comm);
 int simq_comm_allreduce(simq_comm* comm, void* d_buf, int64_t count, int dtype, void* producer_stream);
 int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, void* producer_stream);
 int simq_comm_wait(simq_comm* comm, void* consumer_stream);
+/* Hang diagnosis (no reference counterpart: nn.DataParallel lives in one process): out = {collectives enqueued by this rank,
+ * collectives the device has completed (event queries, no synchronisation), kind of the last one (0 all-reduce fp32, 1 all-reduce fp64,
+ * 2 broadcast), its element / byte count}.  Safe to call from a watchdog thread while another thread waits on the device. */
+int simq_comm_progress(simq_comm* comm, int64_t out[4]);
 int simq_comm_destroy(simq_comm* comm);
 
 /* ---- intention-prediction head (train_intention, train.py:143-158; step_intention, policies.py:97-117) ----------

@@ -81,6 +81,11 @@ struct simq_comm {
     hipEvent_t ready[kEvents] = {};        // producer stream -> comm stream (ring: one per collective in flight)
     hipEvent_t done = nullptr;             // comm stream -> consumer stream
     int next = 0;
+    // progress accounting for hang diagnosis (simq_comm_progress): every collective records `fin` behind itself on the comm stream
+    hipEvent_t fin[kEvents] = {};
+    int64_t enqueued = 0, completed = 0;
+    int last_kind = -1;                    // 0 all-reduce fp32, 1 all-reduce fp64, 2 broadcast
+    int64_t last_count = 0;
 };
 
 namespace simq {
@@ -95,8 +100,12 @@ int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_
     c->next = (c->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, producer));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+    const int slot = (int)(c->enqueued % kEvents);
+    c->last_kind = dtype == SIMQ_COMM_F32 ? 0 : 1; c->last_count = count;
+    ++c->enqueued;
     SIMQ_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == SIMQ_COMM_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->comm,
                                      c->stream));
+    SIMQ_CHECK_HIP(hipEventRecord(c->fin[slot], c->stream));
     return 0;
 }
 
@@ -143,6 +152,8 @@ int simq_comm_init(const void* id, int world_size, int rank, simq_comm** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { simq::set_error("comm_init: stream creation failed"); return fail(-2); }
     for (int i = 0; i < kEvents; ++i)
         if (hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) != hipSuccess) { simq::set_error("comm_init: event creation failed"); return fail(-2); }
+    for (int i = 0; i < kEvents; ++i)
+        if (hipEventCreateWithFlags(&c->fin[i], hipEventDisableTiming) != hipSuccess) { simq::set_error("comm_init: event creation failed"); return fail(-2); }
     if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) { simq::set_error("comm_init: event creation failed"); return fail(-2); }
     *out = c;
     return 0;
@@ -161,7 +172,23 @@ int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, v
     comm->next = (comm->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, static_cast<hipStream_t>(producer_stream)));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(comm->stream, ev, 0));
+    const int slot = (int)(comm->enqueued % kEvents);
+    comm->last_kind = 2; comm->last_count = bytes;
+    ++comm->enqueued;
     SIMQ_CHECK_RCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclInt8, root, comm->comm, comm->stream));
+    SIMQ_CHECK_HIP(hipEventRecord(comm->fin[slot], comm->stream));
+    return 0;
+}
+
+// Hang diagnosis (bench.py's watchdog, tools/mgpu_selftest.py): how many collectives this rank has enqueued, how many of them the
+// device has finished (event queries, no synchronisation), and what the last one was.  Callable from any host thread while another
+// is blocked in a synchronisation.  out = {enqueued, completed, last kind (0 all-reduce fp32, 1 all-reduce fp64, 2 broadcast), last count}
+int simq_comm_progress(simq_comm* comm, int64_t out[4]) {
+    SIMQ_REQUIRE(comm && out, "comm_progress: NULL argument");
+    if (comm->enqueued - comm->completed > kEvents) comm->completed = comm->enqueued - kEvents;   // (older events were re-recorded)
+    while (comm->completed < comm->enqueued && hipEventQuery(comm->fin[comm->completed % kEvents]) == hipSuccess) ++comm->completed;
+    (void)hipGetLastError();                                                                       // (hipErrorNotReady is not an error here)
+    out[0] = comm->enqueued; out[1] = comm->completed; out[2] = comm->last_kind; out[3] = comm->last_count;
     return 0;
 }
 
@@ -177,6 +204,8 @@ int simq_comm_destroy(simq_comm* comm) {
     if (comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
     for (int i = 0; i < kEvents; ++i)
         if (comm->ready[i]) (void)hipEventDestroy(comm->ready[i]);
+    for (int i = 0; i < kEvents; ++i)
+        if (comm->fin[i]) (void)hipEventDestroy(comm->fin[i]);
     if (comm->done) (void)hipEventDestroy(comm->done);
     if (comm->stream) (void)hipStreamDestroy(comm->stream);
     delete comm;

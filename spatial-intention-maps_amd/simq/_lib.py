@@ -138,6 +138,7 @@ _SIGS = {
     'simq_comm_allreduce': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'simq_comm_broadcast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'simq_comm_wait': (c_int, [c_void_p, c_void_p]),
+    'simq_comm_progress': (c_int, [c_void_p, c_void_p]),
     'simq_comm_destroy': (c_int, [c_void_p]),
 }
 

@@ -197,6 +197,14 @@ class Comm:
     def wait(self):
         self._lib.call('simq_comm_wait', self.handle, self._stream())
 
+    def progress(self):
+        """{'enqueued', 'completed', 'last'}: collectives this rank has enqueued on the communicator, those the device has finished, and
+        what the last one was (simq_comm_progress) -- for a watchdog thread to say WHICH collective a hung rank sits in."""
+        out = (ctypes.c_int64 * 4)()
+        self._lib.call('simq_comm_progress', self.handle, out)
+        kind = {0: 'all-reduce fp32', 1: 'all-reduce fp64', 2: 'broadcast'}.get(int(out[2]), 'none')
+        return {'enqueued': int(out[0]), 'completed': int(out[1]), 'last': '%s x %d' % (kind, int(out[3]))}
+
     def close(self):
         if getattr(self, 'handle', None):
             self._lib.call('simq_comm_destroy', self.handle)
