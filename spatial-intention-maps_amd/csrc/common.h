@@ -74,11 +74,36 @@ struct ConvEpilogue {
     const float* bnr_y2 = nullptr; const float* bnr_mean2 = nullptr; const float* bnr_invstd2 = nullptr; double* bnr_red2 = nullptr;
 };
 
+// One BatchNorm layer as its consumers see it: train mode = fp64 sum / sum-of-squares over `rows` written by the producing
+// convolution's epilogue (stats != nullptr; the consumer also saves mean / invstd for backward and updates the running
+// statistics), eval mode = running statistics (stats == nullptr).
+struct BnRef {
+    const double* stats = nullptr;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* rmean = nullptr;
+    float* rvar = nullptr;
+    float* save_mean = nullptr;
+    float* save_invstd = nullptr;
+    float* save_scale = nullptr;     // optional: the consumer's scale / shift kept for a backward pass that recomputes the ReLU mask
+    float* save_shift = nullptr;     // from the pre-BN output (bn_bwd_apply's mscale / mshift)
+    double rows = 0.0, inv_rows = 0.0;
+    int C = 0;
+};
 // A convolution input that is still the PRE-BatchNorm output y of the producing convolution: the consumer applies
 // relu(y * scale[c] + shift[c]) -- the fma / max sequence of bn_apply -- while it stages its operand, so the train-mode
 // "conv -> bn -> relu -> conv" chain of resnet.py:34-40 (and networks.py:18-20) never writes the activation in between.
-// scale / shift: per input channel, from launch_bn_finalize.  Zero padding applies to the ACTIVATION (out-of-image taps stay 0).
-struct InBn { const float* scale = nullptr; const float* shift = nullptr; };
+// Zero padding applies to the ACTIVATION (out-of-image taps stay 0).  Two forms:
+//   live != 0   forward pass: `bn` is the train-mode BatchNorm whose [sum | sum of squares] the producing convolution just accumulated; the
+//               consumer forms scale / shift itself (bn_coeff.h, like bn_apply) and its block 0 commits the layer -- saves mean / invstd /
+//               scale / shift for backward, updates the running statistics.  No finalize launch.
+//   scale/shift backward pass (weight gradient of the consumer): the two vectors the forward pass saved.
+struct InBn {
+    const float* scale = nullptr; const float* shift = nullptr;
+    BnRef bn;
+    int live = 0;
+    bool on() const { return live != 0 || scale != nullptr; }
+};
 
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
 void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
@@ -144,31 +169,12 @@ int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int c
 struct Planes { uint16_t* hi = nullptr; uint16_t* lo = nullptr; };
 
 // ---- channel-last elementwise / reduction kernels (elementwise.hip) -------------------------------
-// One BatchNorm layer as its consumers see it: train mode = fp64 sum / sum-of-squares over `rows` written by the producing
-// convolution's epilogue (stats != nullptr; the consumer also saves mean / invstd for backward and updates the running
-// statistics), eval mode = running statistics (stats == nullptr).
-struct BnRef {
-    const double* stats = nullptr;
-    const float* gamma = nullptr;
-    const float* beta = nullptr;
-    float* rmean = nullptr;
-    float* rvar = nullptr;
-    float* save_mean = nullptr;
-    float* save_invstd = nullptr;
-    float* save_scale = nullptr;     // optional: the consumer's scale / shift kept for a backward pass that recomputes the ReLU mask
-    float* save_shift = nullptr;     // from the pre-BN output (bn_bwd_apply's mscale / mshift)
-    double rows = 0.0, inv_rows = 0.0;
-    int C = 0;
-};
 // eval-mode coefficient table: one entry per BatchNorm layer (offsets in floats)
 struct BnEvalDesc { int64_t g_off, b_off, buf_off, aux_off; int C, pad_; };
 struct BnEvalTable { BnEvalDesc d[24]; int n; };
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream);
 // running mean / var <- momentum update from [sum | sum of squares] over `rows` rows (no normalisation: simq_forward_sync_null)
 int launch_bn_running_update(const double* stats, float* rmean, float* rvar, double rows, int C, hipStream_t stream);
-// scale / shift of a train-mode BatchNorm whose application is fused into its consumer (InBn): one small block forms them from the
-// producing convolution's [sum | sum of squares], saves mean / invstd for backward and commits the running statistics
-int launch_bn_finalize(const BnRef& bn, float* scale, float* shift, hipStream_t stream);
 // out = [relu]( y*scale+shift  [+ res | + res*rscale+rshift] )
 // out = [relu]( bn(y) [+ res | + rbn(res)] )
 // y_bf16: `y` points at bf16 values (uint16_t), see ConvEpilogue::y_bf16

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "common.h"
+#include "bn_coeff.h"
 #include "igemm_epilogue.h"
 
 namespace simq {
@@ -64,15 +65,15 @@ struct IgemmArgs {
     // the next N-tile's first K-steps are in flight while the last MFMAs of the current one run), so a short K = Cin (16-32
     // K-steps) does not pay the pipeline prologue per tile (tools/probes/shortk_probe.py); measured neutral, default 1 (see run())
     int nt_run;
-    // XBN: x is the pre-BatchNorm output of the producing convolution; the A operand is relu(x * xscale[ci] + xshift[ci]) (common.h InBn)
-    const float* xscale; const float* xshift;
+    // XBN: x is the pre-BatchNorm output of the producing convolution; the A operand is relu(x * scale[ci] + shift[ci]) (common.h InBn)
+    InBn in;
 };
 
 // occupancy target: tiles up to 96x128 run 3 blocks per CU, up to 96x64 five; the register budget is held to what that allows
-// (168 / 96; the BatchNorm-on-load variants carry 17 more registers and take four blocks per CU instead of spilling).  (Six waves for 96x64 compile to 78 registers without spilling but lose the software pipeline: 1445 vs 1737 tr/s;
+// (168 / 96).  (Six waves for 96x64 compile to 78 registers without spilling but lose the software pipeline: 1445 vs 1737 tr/s;
 // four for 96x128 spill.)  LDS is not the limit: 20.5 KB (96x64) / 28.7 KB (96x128) per block with unpadded swizzled rows.
 template <int BM, int BN, bool VEC, bool BATCHED = false, bool XBN = false>
-__global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? (XBN ? 4 : 5) : (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
+__global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96 * 128) ? 3 : 2) igemm_conv_kernel(const IgemmArgs p) {
     static_assert(BM % 32 == 0 && BN % 32 == 0, "block tile must be a multiple of 32x32");
     static_assert(!XBN || (VEC && !BATCHED), "the BatchNorm-on-load form exists for the vector loader of a single convolution");
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave (2x2 waves)
@@ -135,10 +136,20 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? (XBN ? 4 : 5) : (B
     constexpr int A_PASSES_S = BM / 16, B_PASSES_S = BN / 16;
     float4 va[2][VEC ? A_PASSES_V : 1], vb[2][VEC ? B_PASSES_V : 1];
     float sa[2][VEC ? 1 : A_PASSES_S], sb[2][VEC ? 1 : B_PASSES_S];
-    // XBN: per register set, the coefficients of the 4 channels this lane holds (the set's channel chunk) and which passes loaded a
-    // real pixel -- out-of-image taps / rows past M must stay 0 behind the BatchNorm + ReLU
-    float4 xsc[2], xsh[2];
+    // XBN: scale | shift of every input channel in LDS (formed from the producing convolution's statistics, or the saved pair); per
+    // register set the channel of the lane's first value and which passes loaded a real pixel -- out-of-image taps / rows past M must
+    // stay 0 behind the BatchNorm + ReLU
+    __shared__ __attribute__((aligned(16))) float xtab[XBN ? 2 * kCoeffMaxC : 4];
+    int xch[2] = {0, 0};
     unsigned xok[2] = {0u, 0u};
+    if constexpr (XBN) {
+        if (p.in.live) {
+            bn_coeff_block(p.in.bn, xtab);
+        } else {
+            for (int c = tid; c < p.Cin; c += 256) { xtab[c] = p.in.scale[c]; xtab[kCoeffMaxC + c] = p.in.shift[c]; }
+        }
+        __syncthreads();
+    }
 
     const int lrow = tid >> 2, kq = tid & 3;    // VEC: 4 threads x float4 per row, 64 rows per pass
     const int srow = tid >> 4, kl = tid & 15;   // SCALAR: 16 threads per row, 16 rows per pass
@@ -187,9 +198,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? (XBN ? 4 : 5) : (B
             const unsigned soff_a = (unsigned)(((ky * p.Win + kx) * p.Cin + c0) * 4), soff_b = (unsigned)((tap * p.Cin + c0) * 4);
             const unsigned bit = live ? (1u << tap) : 0u;
             if constexpr (XBN) {
-                const int ch = (c0 < p.Cin ? c0 : 0) + kq * 4;          // (past the last K-tile every pass is masked anyway)
-                xsc[SET] = make_float4(p.xscale[ch], p.xscale[ch + 1], p.xscale[ch + 2], p.xscale[ch + 3]);
-                xsh[SET] = make_float4(p.xshift[ch], p.xshift[ch + 1], p.xshift[ch + 2], p.xshift[ch + 3]);
+                xch[SET] = (c0 < p.Cin ? c0 : 0) + kq * 4;              // (past the last K-tile every pass is masked anyway)
                 xok[SET] = 0u;
             }
 #pragma unroll
@@ -233,7 +242,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? (XBN ? 4 : 5) : (B
                 float4 v = va[SET][ps];
                 if constexpr (XBN) {
                     const bool ok = (xok[SET] >> ps) & 1u;
-                    const float4 sc = xsc[SET], sh = xsh[SET];
+                    const float4 sc = *reinterpret_cast<const float4*>(xtab + xch[SET]), sh = *reinterpret_cast<const float4*>(xtab + kCoeffMaxC + xch[SET]);
                     v.x = ok ? fmaxf(__builtin_fmaf(v.x, sc.x, sh.x), 0.f) : 0.f; v.y = ok ? fmaxf(__builtin_fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
                     v.z = ok ? fmaxf(__builtin_fmaf(v.z, sc.z, sh.z), 0.f) : 0.f; v.w = ok ? fmaxf(__builtin_fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
                 }
@@ -380,6 +389,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? (XBN ? 4 : 5) : (B
         return;
     }
     igemm_epilogue<BM, BN, TM, TN>(p.epi, acc, m0, n0, p.M, p.Cout, smem);
+    if constexpr (XBN) inbn_commit(p.in);             // (block 0: mean / invstd / scale / shift for backward, running statistics)
 }
 
 // Sums the K-slices of the last round's tiles (fixed order: deterministic) and applies the epilogue the main kernel skipped.
@@ -473,7 +483,7 @@ int resident_blocks() {
 template <int BM, int BN, bool VEC, bool BATCHED = false>
 int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     if constexpr (!VEC || BATCHED) {
-        SIMQ_REQUIRE(!a.xscale, "conv_igemm: BatchNorm-on-load needs the vector loader (Cin %% 16 == 0) of a single convolution");
+        SIMQ_REQUIRE(!a.in.on(), "conv_igemm: BatchNorm-on-load needs the vector loader (Cin %% 16 == 0) of a single convolution");
     }
     IgemmArgs p = a;
     p.tilesN = p.Cout / BN;
@@ -522,7 +532,8 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
     if constexpr (VEC && !BATCHED) {
-        if (p.xscale) hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC, BATCHED, true>), grid, dim3(256), 0, stream, p);
+        SIMQ_REQUIRE(!p.in.on() || p.Cin <= kCoeffMaxC, "conv_igemm: BatchNorm-on-load holds at most %d input channels (Cin=%d)", kCoeffMaxC, p.Cin);
+        if (p.in.on()) hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC, BATCHED, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC, BATCHED>), grid, dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, VEC, BATCHED>), grid, dim3(256), 0, stream, p);
@@ -581,7 +592,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
                       hipStream_t stream, const InBn& in) {
     IgemmArgs a;
     a.x = x; a.w = w;
-    a.xscale = in.scale; a.xshift = in.shift;
+    a.in = in;
     a.epi = make_epi(y, e);
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
@@ -622,7 +633,6 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
 #endif
     IgemmArgs a;
     a.x = x; a.w = w;
-    a.xscale = a.xshift = nullptr;
     ConvEpilogue e;
     a.epi = make_epi(y, e);
     a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;

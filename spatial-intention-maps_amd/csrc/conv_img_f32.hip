@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "bn_coeff.h"
 #include "igemm_epilogue.h"
 
 namespace simq {
@@ -58,7 +59,7 @@ struct ImgF32Args {
     EpiArgs epi;
     int M, Cout, tilesN;
     unsigned x_bytes, w_bytes;
-    const float* xscale; const float* xshift;   // XBN: x is a pre-BatchNorm output; the patch becomes relu(x * xscale[ci] + xshift[ci]) in LDS (common.h InBn)
+    InBn in;   // XBN: x is a pre-BatchNorm output; the patch becomes relu(x * scale[ci] + shift[ci]) in LDS (common.h InBn)
 };
 
 template <int N>
@@ -158,20 +159,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_img_f32_kernel(const ImgF32Ar
         // keeps its quad (512 % 16 == 0), so its eight coefficients are loaded once.
         const int slot = tid & 15;
         floatx4 sc, sh;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { sc[c] = p.xscale[slot * 4 + c]; sh[c] = p.xshift[slot * 4 + c]; }
+        inbn_coeff4(p.in, slot * 4, sc, sh);
         for (int pix = tid >> 4; pix < PR * PW; pix += NW * 4) {
             const int prow = pix / PW, pcol = pix - prow * PW;
             const int iy = y0 - 1 + prow, ix = pcol - 1;
             if ((unsigned)iy < (unsigned)HW && (unsigned)ix < (unsigned)HW) {
                 floatx4* q = reinterpret_cast<floatx4*>(smem + pix * PPITCH + slot * 16);
-                floatx4 v = *q;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fmaxf(__builtin_fmaf(v[c], sc[c], sh[c]), 0.f);
-                *q = v;
+                *q = inbn_apply(*q, sc, sh);
             }
         }
         __syncthreads();
+        inbn_commit(p.in);                                   // (block 0: mean / invstd / scale / shift for backward, running statistics)
     }
 
     // K-step s = (tap, 16-channel chunk), 36 of them, unrolled.  TMW = this wave's real tiles (3 / 2).
@@ -232,11 +230,11 @@ int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g
     p.x = x; p.w = w; p.epi = make_epi(y, e);
     p.M = g.M(); p.Cout = g.Cout; p.tilesN = g.Cout / BN;
     p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-    p.xscale = in.scale; p.xshift = in.shift;
+    p.in = in;
     const unsigned blocks = (unsigned)(g.B * (HW / ROWS) * p.tilesN);
     if (blocks > 512) return 0;                                  // more rounds: the implicit-GEMM tiles win (see the header)
     prof_launch_begin(2, 2.0 * p.M * p.Cout * TAPS * CIN, 4.0 * ((double)p.M * CIN + (double)p.Cout * TAPS * CIN + (double)p.M * p.Cout), stream);
-    if (in.scale) hipLaunchKernelGGL(conv_img_f32_kernel<true>, dim3(blocks), dim3(NW * 64), 0, stream, p);
+    if (in.on()) hipLaunchKernelGGL(conv_img_f32_kernel<true>, dim3(blocks), dim3(NW * 64), 0, stream, p);
     else hipLaunchKernelGGL(conv_img_f32_kernel<false>, dim3(blocks), dim3(NW * 64), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();

@@ -294,6 +294,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
     a.xscale = in.scale; a.xshift = in.shift;
+    SIMQ_REQUIRE(!in.live, "conv_wgrad: BatchNorm-on-load takes the scale / shift the forward pass saved (not a live layer)");
     SIMQ_REQUIRE(!in.scale || g.Cin % 64 == 0, "conv_wgrad: BatchNorm-on-load needs Cin %% 64 == 0 (Cin=%d)", g.Cin);
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;

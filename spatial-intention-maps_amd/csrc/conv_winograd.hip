@@ -18,6 +18,7 @@
 // U = G g G^T is part of the weight cache (wino_weight_kernel, refreshed by simq_weights_prepare with the other derived
 // weights); a dgrad is the same convolution over the flipped / transposed weight.
 #include "common.h"
+#include "bn_coeff.h"
 #include "igemm_epilogue.h"
 
 namespace simq {
@@ -86,24 +87,20 @@ __device__ __forceinline__ void w4f_at(const floatx4 (&m)[6], floatx4 (&y)[4]) {
     y[3] = d + 0.125f * m[3] - 8.f * m[4] + m[5];
 }
 
-// operand load of the input transforms: the activation itself, or (XBN) the saved pre-BatchNorm output with the BatchNorm + ReLU
-// of the layer in between applied on the way in (common.h InBn: the fma / max sequence of bn_apply, so the transform sees the
-// values bn_apply would have stored).  Out-of-image positions stay 0 either way.
+// operand load of the input transforms (XBN): the saved pre-BatchNorm output with the BatchNorm + ReLU of the layer in between applied on
+// the way in (common.h InBn: the fma / max sequence of bn_apply, so the transform sees the values bn_apply would have stored).  The load
+// itself is UNCONDITIONAL from a clamped in-image address and the zero padding a select behind it: every load of a tile can be in flight
+// before the first one is consumed (a load under a branch is waited for inside its branch).
 template <bool XBN>
-__device__ __forceinline__ floatx4 ld_in(const float* __restrict__ q, const floatx4& sc, const floatx4& sh) {
-    floatx4 v = *reinterpret_cast<const floatx4*>(q);
+__device__ __forceinline__ floatx4 ld_tap(const float* __restrict__ img, int yy, int xx, int H, int W, int C, const floatx4& sc, const floatx4& sh) {
+    const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
     if constexpr (XBN) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaxf(__builtin_fmaf(v[c], sc[c], sh[c]), 0.f);
-    }
-    return v;
-}
-template <bool XBN>
-__device__ __forceinline__ void ld_inbn(const float* __restrict__ isc, const float* __restrict__ ish, int c, floatx4& sc, floatx4& sh) {
-    sc = floatx4{1.f, 1.f, 1.f, 1.f}; sh = floatx4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (XBN) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sc[k] = isc[c + k]; sh[k] = ish[c + k]; }
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        const floatx4 v = inbn_apply(*reinterpret_cast<const floatx4*>(img + ((size_t)yc * W + xc) * C), sc, sh);
+        return ok ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        if (ok) return *reinterpret_cast<const floatx4*>(img + ((size_t)yy * W + xx) * C);
+        return floatx4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -164,29 +161,24 @@ __global__ void __launch_bounds__(256) wino_weight_all_kernel(const float* __res
 // One thread: one tile x 4 channels (float4); the C/4 lanes of a tile read / write full contiguous rows of C floats.
 template <bool XBN>
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C,
-                                                         int T, const float* __restrict__ isc, const float* __restrict__ ish) {
+                                                         int T, const InBn in) {
     const int lanes = C >> 2;                       // float4 lanes per tile
     const int tpb = 256 / lanes;                    // tiles per block iteration
     const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
     const int th = H >> 1, tw = W >> 1;
     const size_t gstride = (size_t)T * C;
-    floatx4 bsc, bsh;
-    ld_inbn<XBN>(isc, ish, cl * 4, bsc, bsh);
+    floatx4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XBN) inbn_coeff4(in, cl * 4, bsc, bsh);
     for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
         const int b = t / (th * tw), r = t - b * (th * tw);
         const int ty = r / tw, tx = r - ty * tw;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        const float* img = x + (size_t)b * H * W * C + cl * 4;
         floatx4 d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int yy = y0 + i, xx = x0 + j;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    d[i][j] = ld_in<XBN>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4, bsc, bsh);
-                else
-                    d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int j = 0; j < 4; ++j) d[i][j] = ld_tap<XBN>(img, y0 + i, x0 + j, H, W, C, bsc, bsh);
         floatx4 e[4][4];                            // B^T d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -204,6 +196,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
             *reinterpret_cast<floatx4*>(dst + (i * 4 + 3) * gstride) = e[i][1] - e[i][3];
         }
     }
+    if constexpr (XBN) inbn_commit(in);
 }
 
 // ---- y = A^T m A (+ epilogue),  A^T = [[1,1,1,0],[0,1,-1,-1]] ----
@@ -306,29 +299,24 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 // V4[g][t][c] = (B^T d B)[g / 6][g % 6] over 6x6 patches at stride 4; one thread = one tile x 4 channels
 template <bool XBN>
 __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int T,
-                                                           const float* __restrict__ isc, const float* __restrict__ ish) {
+                                                           const InBn in) {
     const int lanes = C >> 2, tpb = 256 / lanes;
     const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
     const int th = H >> 2, tw = W >> 2;
     const size_t gstride = (size_t)T * C;
-    floatx4 bsc, bsh;
-    ld_inbn<XBN>(isc, ish, cl * 4, bsc, bsh);
+    floatx4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XBN) inbn_coeff4(in, cl * 4, bsc, bsh);
     for (int t = blockIdx.x * tpb + tl; t < T; t += gridDim.x * tpb) {
         const int b = t / (th * tw), r = t - b * (th * tw);
         const int ty = r / tw, tx = r - ty * tw;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        const float* img = x + (size_t)b * H * W * C + cl * 4;
         floatx4 v[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                // B^T d, column by column
             floatx4 a[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int yy = y0 + i, xx = x0 + j;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    a[i] = ld_in<XBN>(x + ((size_t)(b * H + yy) * W + xx) * C + cl * 4, bsc, bsh);
-                else
-                    a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < 6; ++i) a[i] = ld_tap<XBN>(img, y0 + i, x0 + j, H, W, C, bsc, bsh);
             w4f_bt(a);
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[i][j] = a[i];
@@ -341,6 +329,7 @@ __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restri
             for (int j = 0; j < 6; ++j) *reinterpret_cast<floatx4*>(dst + (i * 6 + j) * gstride) = v[i][j];
         }
     }
+    if constexpr (XBN) inbn_commit(in);
 }
 
 // y = A^T m A (4x4 outputs per tile) + the forward epilogue of igemm_epilogue.h (bias, BatchNorm batch statistics, folded-BN affine,
@@ -476,7 +465,7 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 // and leave as 128-B rows of 32 consecutive tiles.  DY = false: x -> (B^T d B)^T layout; DY = true: dy -> (A dY A^T).
 template <bool DY, bool XBN = false>
 __global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T,
-                                                      const float* __restrict__ isc = nullptr, const float* __restrict__ ish = nullptr) {
+                                                      const InBn in) {
     static_assert(!(DY && XBN), "the BatchNorm-on-load form is for the activation operand");
     __shared__ float tbuf[4][32][33];
     const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
@@ -484,8 +473,8 @@ __global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ 
     const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
     const int t = t0 + tl, c = c0 + cq * 4;
     const int th = H >> 1, tw = W >> 1;
-    floatx4 bsc, bsh;
-    ld_inbn<XBN>(isc, ish, c, bsc, bsh);
+    floatx4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XBN) inbn_coeff4(in, c, bsc, bsh);
     floatx4 v[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) v[g] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -507,17 +496,12 @@ __global__ void __launch_bounds__(256) wino_tr_kernel(const float* __restrict__ 
             }
         } else {
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            const float* img = src + (size_t)b * H * W * C + c;
             floatx4 d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int yy = y0 + i, xx = x0 + j;
-                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                        d[i][j] = ld_in<XBN>(src + ((size_t)(b * H + yy) * W + xx) * C + c, bsc, bsh);
-                    else
-                        d[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int j = 0; j < 4; ++j) d[i][j] = ld_tap<XBN>(img, y0 + i, x0 + j, H, W, C, bsc, bsh);
             floatx4 e[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -575,7 +559,7 @@ __device__ __forceinline__ void w4_a(const floatx4 (&y)[4], floatx4 (&r)[6]) {  
 
 template <bool DY, bool XBN = false>
 __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T,
-                                                       const float* __restrict__ isc = nullptr, const float* __restrict__ ish = nullptr) {
+                                                       const InBn in) {
     static_assert(!(DY && XBN), "the BatchNorm-on-load form is for the activation operand");
     __shared__ float tbuf[4][32][33];
     const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
@@ -583,8 +567,8 @@ __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__
     const int t0 = (blockIdx.x / cblocks) * 32, c0 = (blockIdx.x % cblocks) * 32;
     const int t = t0 + tl, c = c0 + cq * 4;
     const int th = H >> 2, tw = W >> 2;
-    floatx4 bsc, bsh;
-    ld_inbn<XBN>(isc, ish, c, bsc, bsh);
+    floatx4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XBN) inbn_coeff4(in, c, bsc, bsh);
     floatx4 v[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -609,17 +593,12 @@ __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__
             }
         } else {
             const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+            const float* img = src + (size_t)b * H * W * C + c;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {            // B^T d, column by column
                 floatx4 a[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int yy = y0 + i, xx = x0 + j;
-                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                        a[i] = ld_in<XBN>(src + ((size_t)(b * H + yy) * W + xx) * C + c, bsc, bsh);
-                    else
-                        a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int i = 0; i < 6; ++i) a[i] = ld_tap<XBN>(img, y0 + i, x0 + j, H, W, C, bsc, bsh);
                 w4_bt(a);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) v[i][j] = a[i];
@@ -760,8 +739,8 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
     int bin = (T + tpb_in - 1) / tpb_in;
     if (bin > 4096) bin = 4096;
-    if (in.scale) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
-    else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
+    if (in.on()) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in);
+    else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in);
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
     int bout = (T + tpb_out - 1) / tpb_out;
@@ -801,8 +780,8 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
     int bin = (T4 + tpb_in - 1) / tpb_in;
     if (bin > 4096) bin = 4096;
-    if (in.scale) hipLaunchKernelGGL(wino4f_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in.scale, in.shift);
-    else hipLaunchKernelGGL(wino4f_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, nullptr, nullptr);
+    if (in.on()) hipLaunchKernelGGL(wino4f_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
+    else hipLaunchKernelGGL(wino4f_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream)) return rc;
     int bout = (T4 + tpb_out - 1) / tpb_out;
@@ -844,9 +823,9 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][Cout][T4]
         float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][Cout][Cin]
         const int tb = (T4 + 31) / 32;
-        if (in.scale) hipLaunchKernelGGL((wino4_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in.scale, in.shift);
-        else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, nullptr, nullptr);
-        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, nullptr, nullptr);
+        if (in.on()) hipLaunchKernelGGL((wino4_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in);
+        else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in);
+        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, InBn());
         SIMQ_CHECK_LAUNCH();
         if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, T4, 36, stream)) return rc;
         int blocks4 = (g.Cout * g.Cin + 255) / 256;
@@ -861,8 +840,8 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         int bin = (T + tpb_in - 1) / tpb_in, bout = (T + tpb_out - 1) / tpb_out;
         if (bin > 4096) bin = 4096;
         if (bout > 4096) bout = 4096;
-        if (in.scale) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
-        else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
+        if (in.on()) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in);
+        else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in);
         hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
         SIMQ_CHECK_LAUNCH();
         SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
@@ -870,9 +849,9 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
     } else {
         // tile index contiguous: dU[g] = dMt[g] (Cout x T) * Vt[g]^T (T x Cin) is a K-contiguous GEMM with K = T
         const int tb = (T + 31) / 32;
-        if (in.scale) hipLaunchKernelGGL((wino_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in.scale, in.shift);
-        else hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, nullptr, nullptr);
-        hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T, nullptr, nullptr);
+        if (in.on()) hipLaunchKernelGGL((wino_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in);
+        else hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in);
+        hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T, InBn());
         SIMQ_CHECK_LAUNCH();
         if (int rc = launch_gemm_batched(dMt, Vt, dU, g.Cout, g.Cin, T, 16, stream)) return rc;
     }

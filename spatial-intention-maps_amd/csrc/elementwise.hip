@@ -9,66 +9,11 @@
 //   F.interpolate(x2, bilinear, align_corners=True) networks.py:21,25 (+ backward)
 //   ToTensor HWC->CHW of policies.py:44-45 (layout helpers)
 #include "common.h"
+#include "bn_coeff.h"
 
 namespace simq {
 
 namespace {
-
-constexpr float BN_EPS = 1e-5f;
-constexpr double BN_MOMENTUM = 0.1;
-
-// ---- BatchNorm coefficients computed where they are consumed (no separate finalize launch) -------------------------
-// train: mean / biased var from the conv epilogue's fp64 sum / sum-of-squares; eval: running statistics.
-__device__ __forceinline__ void bn_coeff(const BnRef& b, int c, float& scale, float& shift, float& mean_f, float& invstd_f,
-                                         double& mean_d, double& var_d) {
-    double mean, var;
-    if (b.stats) {
-        mean = b.stats[c] * b.inv_rows;
-        var = b.stats[b.C + c] * b.inv_rows - mean * mean;
-        if (var < 0.0) var = 0.0;
-    } else {
-        mean = (double)b.rmean[c];
-        var = (double)b.rvar[c];
-    }
-    // 1/sqrt in fp64 without the (slow) fp64 sqrt / divide: fp32 rsqrt seed + two Newton steps (error < 1e-15)
-    const double v = var + (double)BN_EPS;
-    double invstd = (double)rsqrtf((float)v);
-    invstd = invstd * (1.5 - 0.5 * v * invstd * invstd);
-    invstd = invstd * (1.5 - 0.5 * v * invstd * invstd);
-    scale = (float)((double)b.gamma[c] * invstd);
-    shift = (float)((double)b.beta[c] - mean * (double)b.gamma[c] * invstd);
-    mean_f = (float)mean; invstd_f = (float)invstd; mean_d = mean; var_d = var;
-}
-__device__ __forceinline__ void bn_coeff4(const BnRef& b, int c, float4& sc, float4& sh) {
-    float m, i; double md, vd;
-    bn_coeff(b, c, sc.x, sh.x, m, i, md, vd); bn_coeff(b, c + 1, sc.y, sh.y, m, i, md, vd);
-    bn_coeff(b, c + 2, sc.z, sh.z, m, i, md, vd); bn_coeff(b, c + 3, sc.w, sh.w, m, i, md, vd);
-}
-// scale / shift of a train- or eval-mode BatchNorm for every channel, once per block (fp64 mean / variance / rsqrt per channel:
-// per thread it cost more than the short grid-stride loops that follow).  cs: [2][kCoeffMaxC] floats of LDS
-constexpr int kCoeffMaxC = 512;
-__device__ __forceinline__ void bn_coeff_block(const BnRef& b, float* cs) {
-    for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
-        float sc, sh, m, i; double md, vd;
-        bn_coeff(b, c, sc, sh, m, i, md, vd);
-        cs[c] = sc; cs[kCoeffMaxC + c] = sh;
-    }
-}
-// once per launch (block 0): save mean / invstd for backward and update the running statistics (momentum 0.1,
-// unbiased variance, in fp64 like ATen's CPU kernel)
-__device__ __forceinline__ void bn_commit(const BnRef& b) {
-    if (!b.stats || blockIdx.x != 0) return;
-    for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
-        float sc, sh, m, i; double md, vd;
-        bn_coeff(b, c, sc, sh, m, i, md, vd);
-        b.save_mean[c] = m;
-        b.save_invstd[c] = i;
-        if (b.save_scale) { b.save_scale[c] = sc; b.save_shift[c] = sh; }
-        const double unbiased = b.rows > 1.0 ? vd * b.rows / (b.rows - 1.0) : vd;
-        b.rmean[c] = (float)(BN_MOMENTUM * md + (1.0 - BN_MOMENTUM) * (double)b.rmean[c]);
-        b.rvar[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)b.rvar[c]);
-    }
-}
 
 // eval mode: scale / shift of every BatchNorm layer from the running statistics in ONE launch (one block per layer); the
 // convolution epilogues then apply them (+ residual + ReLU) and no bn_apply launch is needed.
@@ -85,18 +30,6 @@ __global__ void bn_eval_coeff_kernel(BnEvalTable t, const float* __restrict__ pa
         aux[d.aux_off + c] = sc;
         aux[d.aux_off + d.C + c] = sh;
     }
-}
-
-// train mode, BatchNorm applied inside its consumer (common.h InBn): scale / shift for that consumer (and for the backward pass, which
-// recomputes the activation and its ReLU mask from the saved pre-BN output with the SAME two numbers), mean / invstd for backward, the
-// running-statistics update -- what bn_apply's prologue + bn_commit do, as one small block
-__global__ void __launch_bounds__(256) bn_finalize_kernel(BnRef bn, float* __restrict__ scale, float* __restrict__ shift) {
-    for (int c = threadIdx.x; c < bn.C; c += blockDim.x) {
-        float sc, sh, m, i; double md, vd;
-        bn_coeff(bn, c, sc, sh, m, i, md, vd);
-        scale[c] = sc; shift[c] = sh;
-    }
-    bn_commit(bn);
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -230,6 +163,10 @@ __global__ void __launch_bounds__(256) bn_apply16_kernel(const uint16_t* __restr
     if (has_rbn) bn_commit(rbn);
 }
 
+// MFY: no mask plane -- the ReLU mask is recomputed from the pre-BN output, (y * mscale + mshift > 0) (Ctx::mask1_from_y: one plane less to
+// read).  A template parameter, not a run-time test: a load under a branch is waited for inside its branch, which serialised the three
+// streams of this HBM-bound kernel (46 us instead of 27 per launch when it was a run-time test).
+template <bool MFY>
 __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ mask16,
                                                              const uint16_t* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -247,14 +184,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     const int c = (int)(i0 % C8) * 8;
     // the expression of bn_bwd_apply_kernel with the per-channel factors (gamma*invstd, dbeta/rows, dgamma/rows) formed once
-    // mask16 == NULL: the ReLU mask is recomputed from the pre-BN output, (y * mscale + mshift > 0) (the activation was not stored, or
-    // need not be read: one plane less)
-    float ka[8], mu[8], is[8], db[8], dg[8], ms[8], mh[8];
+    float ka[8], mu[8], is[8], db[8], dg[8], ms[MFY ? 8 : 1], mh[MFY ? 8 : 1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c + k]; is[k] = invstd[c + k]; ka[k] = gamma[c + k] * is[k];
         db[k] = (float)red[c + k] * inv_rows; dg[k] = (float)red[C + c + k] * inv_rows;
-        ms[k] = mask16 ? 0.f : mscale[c + k]; mh[k] = mask16 ? 0.f : mshift[c + k];
+        if constexpr (MFY) { ms[k] = mscale[c + k]; mh[k] = mshift[c + k]; }
     }
     auto one = [&](uint4 gr, uint4 mr, uint4 yr, uint4& dzr) {
         F8 gv = unpack8(gr), yv = unpack8(yr), o;
@@ -263,7 +198,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const short m = (short)(k & 1 ? mw[k >> 1] >> 16 : mw[k >> 1] & 0xffffu);
-            const bool pos = mask16 ? m > 0 : fmaf(yv.v[k], ms[k], mh[k]) > 0.f;
+            bool pos;
+            if constexpr (MFY) pos = fmaf(yv.v[k], ms[k], mh[k]) > 0.f;
+            else pos = m > 0;
             if (!pos) zw[k >> 1] &= (k & 1) ? 0x0000ffffu : 0xffff0000u;
             const float dz = pos ? gv.v[k] : 0.f;
             o.v[k] = ka[k] * (dz - db[k] - (yv.v[k] - mu[k]) * is[k] * dg[k]);
@@ -274,8 +211,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     size_t i = i0;
     for (; i + stride < total8; i += 2 * stride) {
         const uint4 g0 = ld16(g, i), g1 = ld16(g, i + stride);
-        const uint4 zz = make_uint4(0, 0, 0, 0);
-        const uint4 m0 = mask16 ? ld16(mask16, i) : zz, m1 = mask16 ? ld16(mask16, i + stride) : zz;
+        uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
+        if constexpr (!MFY) { m0 = ld16(mask16, i); m1 = ld16(mask16, i + stride); }
         const uint4 y0 = ld16(y, i), y1 = ld16(y, i + stride);
         uint4 z0, z1;
         st16(dy, i, one(g0, m0, y0, z0));
@@ -284,7 +221,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const uint16_t* __r
     }
     if (i < total8) {
         uint4 z0;
-        st16(dy, i, one(ld16(g, i), mask16 ? ld16(mask16, i) : make_uint4(0, 0, 0, 0), ld16(y, i), z0));
+        uint4 mt = make_uint4(0, 0, 0, 0);
+        if constexpr (!MFY) mt = ld16(mask16, i);
+        st16(dy, i, one(ld16(g, i), mt, ld16(y, i), z0));
         if (dz_out) st16(dz_out, i, z0);
     }
 }
@@ -713,13 +652,6 @@ int launch_bn_running_update(const double* stats, float* rmean, float* rvar, dou
     return 0;
 }
 
-int launch_bn_finalize(const BnRef& bn, float* scale, float* shift, hipStream_t stream) {
-    SIMQ_REQUIRE(bn.stats && scale && shift && bn.C >= 1, "bn_finalize: train-mode BatchNorm with scale / shift outputs expected");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, stream, bn, scale, shift);
-    SIMQ_CHECK_LAUNCH();
-    return 0;
-}
-
 int launch_bn_eval_coeff(const BnEvalTable& t, const float* params, const float* bnbuf, float* aux, hipStream_t stream) {
     hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(t.n), dim3(256), 0, stream, t, params, bnbuf, aux);
     SIMQ_CHECK_LAUNCH();
@@ -805,9 +737,13 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
     SIMQ_REQUIRE(!mscale || (mshift && !mask && !mask16), "bn_bwd_apply: the recomputed mask (mscale / mshift) excludes a mask tensor");
     if (g_bf16 && y_bf16 && (mask16 || mscale) && !mask && !dy && pl.hi && !pl.lo && C % 8 == 0 && 256 % (C / 8) == 0) {   // all-bf16 form
         size_t total8 = (size_t)rows * (C / 8);
-        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
-                           reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
-                           total8, C / 8, (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows)), dparam_scale, mscale, mshift);
+        const float inv_rows = (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows));
+        if (mscale) hipLaunchKernelGGL(bn_bwd_apply16_kernel<true>, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
+                                       reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
+                                       total8, C / 8, inv_rows, dparam_scale, mscale, mshift);
+        else hipLaunchKernelGGL(bn_bwd_apply16_kernel<false>, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
+                                reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
+                                total8, C / 8, inv_rows, dparam_scale, mscale, mshift);
         SIMQ_CHECK_LAUNCH();
         return 0;
     }

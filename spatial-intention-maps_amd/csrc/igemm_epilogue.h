@@ -207,6 +207,9 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
             const uint16_t* y116 = reinterpret_cast<const uint16_t*>(p.bnr_y1);
             const uint16_t* y216 = reinterpret_cast<const uint16_t*>(p.bnr_y2);
             uint16_t* out16 = reinterpret_cast<uint16_t*>(p.y);
+            // recomputed mask: the mask load stays UNCONDITIONAL (it re-reads y1's address: the same cache lines) -- a load under a branch
+            // would be waited for inside its branch and break the batch of loads in flight
+            const uint16_t* mk16 = mfy ? y116 : p.bnr_mask16;
 #pragma unroll
             for (int kg = 0; kg < NK / KB; ++kg) {
                 ushort4 ha[KB], hm[KB], h1[KB], h2[KB];
@@ -216,7 +219,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const EpiArgs& p, floatx4 
                     const int m = m0 + wm * (TM * 16) + ig * ROWS + (kg * KB + u) * RPI + rl;
                     off[u] = (size_t)(m < M ? m : M - 1) * Cout + n;
                     if (ad16) ha[u] = *reinterpret_cast<const ushort4*>(ad16 + off[u]);
-                    if (!mfy) hm[u] = *reinterpret_cast<const ushort4*>(p.bnr_mask16 + off[u]);
+                    hm[u] = *reinterpret_cast<const ushort4*>(mk16 + off[u]);
                     h1[u] = *reinterpret_cast<const ushort4*>(y116 + off[u]);
                     if (bnr2) h2[u] = *reinterpret_cast<const ushort4*>(y216 + off[u]);
                 }

@@ -280,7 +280,7 @@ struct Ctx {
     bool mask1_from_y() const {
         return lazy1() || (p->precision == SIMQ_PREC_BF16 && p->opt.bn1_mask_from_preact && planes_only());
     }
-    InBn inbn(const BnL& b) const { InBn in; in.scale = aux(b, 0); in.shift = aux(b, 1); return in; }
+    InBn inbn_saved(const BnL& b) const { InBn in; in.scale = aux(b, 0); in.shift = aux(b, 1); return in; }     // backward pass
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
         uint16_t* base = reinterpret_cast<uint16_t*>(wc + (transposed ? W.wtpl : W.wpl));
@@ -303,7 +303,7 @@ ConvGeom geom(const ConvL& c, int B, int hin) {
 int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGeom& g, const ConvEpilogue& e, bool nograd = false,
              const InBn& in = InBn()) {
     if (c.mc() && cv.wp_off >= 0) {
-        SIMQ_REQUIRE(!in.scale, "conv_fwd: BatchNorm-on-load exists for fp32 plans only");
+        SIMQ_REQUIRE(!in.on(), "conv_fwd: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* wsp[2];
         c.wplanes(cv, false, wsp);
@@ -466,10 +466,10 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
             continue;
         }
         RC(conv_bn(c, b.c1, b.b1, mode, cur, c.f(o.y1), 24));
-        if (c.lazy1()) {                                      // bn1 + ReLU inside conv2's operand staging: a1 is never written
-            RC(launch_bn_finalize(bnref(c, b.b1, mode, rows), c.aux(b.b1, 0), c.aux(b.b1, 1), c.stream));
-            Act y1; y1.f = c.f(o.y1);
-            RC(conv_bn(c, b.c2, b.b2, mode, y1, c.f(o.y2), 24, c.inbn(b.b1)));
+        if (c.lazy1()) {                                      // bn1 + ReLU inside conv2's operand staging: a1 is never written, and
+            Act y1; y1.f = c.f(o.y1);                         // conv2's first block commits bn1 (statistics for backward, running update)
+            InBn in; in.bn = bnref(c, b.b1, mode, rows); in.live = 1;
+            RC(conv_bn(c, b.c2, b.b2, mode, y1, c.f(o.y2), 24, in));
         } else {
         RC(launch_bn_apply(c.f(o.y1), bnref(c, b.b1, mode, rows), nullptr, nullptr, 1, a1.fv ? a1.f : nullptr, rows, b.planes, c.stream, a1.pl,
                            Planes(), c.ybf()));
@@ -502,8 +502,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(conv_bn_folded(c, p->h1, p->hb1, cur, a1.f, 24, nullptr, 1));
     } else {
         RC(conv_bn(c, p->h1, p->hb1, mode, cur, c.f(L.yh1), 24));
-        if (c.lazy1()) RC(launch_bn_finalize(bnref(c, p->hb1, mode, rows), c.aux(p->hb1, 0), c.aux(p->hb1, 1), c.stream));
-        else RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
+        if (!c.lazy1()) RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
     }
     {
         ConvGeom g2 = geom(p->h2, c.B, 24);
@@ -512,7 +511,8 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         if (folded) { e2.scale = c.aux(p->hb2, 0); e2.shift = c.aux(p->hb2, 1); }     // eval: the affine map commutes with the upsample too
         if (!folded && c.lazy1()) {                            // (head bn1 + ReLU inside conv2's operand staging, as in the blocks)
             Act yh1; yh1.f = c.f(L.yh1);
-            RC(conv_fwd(c, p->h2, yh1, z2, g2, e2, mode != SIMQ_MODE_TRAIN, c.inbn(p->hb1)));
+            InBn in; in.bn = bnref(c, p->hb1, mode, rows); in.live = 1;
+            RC(conv_fwd(c, p->h2, yh1, z2, g2, e2, mode != SIMQ_MODE_TRAIN, in));
         } else {
             RC(conv_fwd(c, p->h2, a1, z2, g2, e2, mode != SIMQ_MODE_TRAIN));
         }
@@ -568,7 +568,7 @@ int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin, const InBn& in = InBn()) {
     ConvGeom g = geom(cv, c.B, hin);
     if (c.mc() && cv.wp_off >= 0) {
-        SIMQ_REQUIRE(!in.scale, "conv_wgrad: BatchNorm-on-load exists for fp32 plans only");
+        SIMQ_REQUIRE(!in.on(), "conv_wgrad: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
         return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream, c.L.wslab >= 0 ? c.f(c.L.wslab) : nullptr);
@@ -647,7 +647,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         if (c.lazy1()) {                                             // (a1 was never stored: conv2's weight gradient re-applies bn1 + ReLU to yh1)
             Act yh1; yh1.f = c.f(L.yh1);
-            RC(conv_wgrad(c, p->h2, yh1, t2, 24, c.inbn(p->hb1)));
+            RC(conv_wgrad(c, p->h2, yh1, t2, 24, c.inbn_saved(p->hb1)));
         } else {
             RC(conv_wgrad(c, p->h2, a1, t2, 24));
         }
@@ -712,7 +712,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out, -1, gb));
         if (c.lazy1()) {                                     // (a1 was never stored: the weight gradient re-applies bn1 + ReLU to y1)
             Act y1; y1.f = c.f(o.y1);
-            RC(conv_wgrad(c, b.c2, y1, T0, 24, c.inbn(b.b1)));
+            RC(conv_wgrad(c, b.c2, y1, T0, 24, c.inbn_saved(b.b1)));
         } else {
             RC(conv_wgrad(c, b.c2, a1, T0, 24));
         }

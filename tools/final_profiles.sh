@@ -14,7 +14,7 @@ cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 prof() {   # name, extra bench args...
   local name=$1; shift
-  local B="python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --steps 5 --warmup 2 $*"
+  local B="python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --sustained-seconds 0 --steps 5 --warmup 2 $*"
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace -d $O -o kt_$name -- $B > $O/kt_$name.out 2> $O/kt_$name.err
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $O -o ps_$name -- $B > $O/ps_$name.out 2> $O/ps_$name.err
