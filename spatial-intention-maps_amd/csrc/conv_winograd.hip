@@ -318,6 +318,8 @@ __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 6; ++i) a[i] = ld_tap<XBN>(img, y0 + i, x0 + j, H, W, C, bsc, bsh);
             w4f_bt(a);
+            // (one column at a time: with all 36 unconditional loads hoisted the kernel needed 256 + 34 registers = one wave per SIMD)
+            if constexpr (XBN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[i][j] = a[i];
         }
