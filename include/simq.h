@@ -101,6 +101,11 @@ typedef struct simq_plan_options {
     int fuse_bn1_apply;           /* 1 (fp32 plans): the consuming convolution applies scale*y+shift -> ReLU while it stages its operand (Winograd input
                                    * transforms, image-tile / implicit-GEMM loaders), its weight gradient and the BatchNorm backward recompute the
                                    * activation / its mask from the saved pre-BN output.  Needs fuse_bn_backward_sums. */
+    int deterministic;            /* 0.  1: run-to-run bit-identical results (debugging aid, e.g. rank divergence in data-parallel runs): the weight
+                                   * gradients whose pixel reduction is split over blocks leave per-split partial tiles in a slab (64 MB more
+                                   * workspace) that a second launch adds in split order, instead of fp32 atomics; the one-hot head backward walks the
+                                   * transitions in order.  Forward, TD targets, loss and BatchNorm statistics are bit-reproducible in either setting
+                                   * (tools/determinism_probe.py): their fp64 accumulators round to the same fp32 value whatever the order. */
     int bn1_mask_from_preact;     /* 1 (plain-bf16 plans): the backward pass takes that ReLU mask from the saved pre-BN output (scale*y+shift > 0)
                                    * instead of reading the activation's plane -- one bf16 plane less in bn_bwd_apply and in the dgrad epilogue */
 } simq_plan_options;
@@ -141,6 +146,14 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
  * environment has SIMQ_KEEP_FP32_ACT=1 (diagnostics).                                                              */
 int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems,
                           int* channels);
+
+/* The block-internal tensors a forward pass leaves in its workspace (teacher-forced parity tests: every stored tensor against an fp64
+ * recomputation from the STORED tensors it was computed from).  name: "layer<1-4>.<0-1>.<y1|a1|y2|yd|out>" (pre-BatchNorm outputs of
+ * conv1 / conv2 / the downsample convolution, the activation between the two convolutions, the block output; NHWC [batch][24][24][C]),
+ * "layer<l>.<b>.<bn1|bn2|bnd>" (4*C floats: scale | shift | mean | invstd as the consuming kernel formed them), "stem.pool.plane"
+ * (matrix-core precisions).  storage: 0 fp32, 1 bf16.  Fails for tensors the plan does not store (e.g. a1 under fuse_bn1_apply). */
+int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels,
+                             int* storage);
 
 /* ---- FCN.forward (networks.py:16-26) ---------------------------------------------------------
  * d_x      [batch][96][96][Cin] fp32 NHWC  (== the reference's HWC replay states, stacked)
@@ -315,6 +328,21 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const floa
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                               int batch, int hin, int win, int cin, int cout,
                               double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+/* The plan's elementwise BatchNorm pass, on its own (per-kernel parity tests): train-mode nn.BatchNorm2d + residual + ReLU
+ * (resnet.py:35-36,42-45) with the batch statistics GIVEN as [sum | sum of squares] over `rows` (what the producing convolution's
+ * epilogue leaves):  out = [relu]( (y - mean) * invstd * gamma + beta  [+ res] ).
+ * storage 0: y / res / out fp32 [rows][channels];  1: all three bf16 (the all-bf16 form of plain-bf16 plans: 16-byte accesses).
+ * d_saved [4*channels]: scale | shift | mean | invstd (written);  d_running [2*channels]: running mean | var (momentum 0.1, updated). */
+int simq_bn_relu_apply(const void* d_y, const double* d_stats, const float* d_gamma, const float* d_beta, const void* d_res, int relu,
+                       void* d_out, int64_t rows, int channels, int storage, float* d_saved, float* d_running, void* stream);
+/* ... and its backward:  dz = g * mask,  dy = gamma * invstd * (dz - sum(dz)/rows - xhat * sum(dz*xhat)/rows),  dgamma = sum(dz*xhat),
+ * dbeta = sum(dz), with the two sums GIVEN in d_red [2*channels] (in the plan they come from the dgrad epilogue that produced g).
+ * mask_kind 0: no mask; 1: d_mask = the activation that followed (fp32 or bf16 per `storage`), mask = activation > 0;
+ * 2: recomputed from the pre-BN output, mask = (y * scale + shift > 0) with d_saved's scale | shift (simq_plan_options.fuse_bn1_apply /
+ * bn1_mask_from_preact).  d_saved as written by simq_bn_relu_apply.  d_dz_out: NULL or the masked gradient (same storage as g). */
+int simq_bn_relu_backward(const void* d_g, const void* d_mask, int mask_kind, const void* d_y, const float* d_saved, const float* d_gamma,
+                          const double* d_red, void* d_dy, void* d_dz_out, float* d_dgamma, float* d_dbeta, int64_t rows, int channels,
+                          int storage, void* stream);
 /* conv( relu( y_pre * in_scale[ci] + in_shift[ci] ) ): the second convolution of a train-mode "conv -> BatchNorm -> ReLU -> conv" chain
  * (reference resnet.py:34-40, networks.py:18-20) consuming the FIRST convolution's pre-BatchNorm output -- the BatchNorm + ReLU in
  * between is applied while the operand is staged and the activation is never stored (simq_plan_options.fuse_bn1_apply; fp32).

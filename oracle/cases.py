@@ -54,6 +54,9 @@ GRAD_STUDY_B64_CASES = [('gs_b64_%02d' % i, 5, (2, 1)[i % 2], 64, 270 + i, 370 +
 # ... and at configs[1]'s own batch (32, Cin 4, Cout 2: the headline workload): twelve more batches, for the decision which layers' grad-mode
 # forward may run in F(4x4,3x3)
 GRAD_STUDY_B32_CASES = [('gs_b32x_%02d' % i, 4, 2, 32, 400 + i, 500 + i) for i in range(12)]
+# ... and at configs[2] / configs[4]'s per-GPU batch (128, Cin 5, Cout 2): twelve batches -- the single fixture train_c5o2_b128 sat at 2.6 x the
+# reference's own error (one unlucky batch or a regression?); the distribution answers it (round 4)
+GRAD_STUDY_B128_CASES = [('gs_b128_%02d' % i, 5, 2, 128, 600 + i, 700 + i) for i in range(12)]
 INTENTION_CASES = [('intent_c5_b4', 5, 4, 34, 44), ('intent_c4_b3', 4, 3, 35, 45)]   # (name, cfg.num_input_channels, B, wseed, dseed)
 SAMPLER_CASES = [(64, 4, 5), (10000, 32, 6), (10000, 1024, 7), (21, 21, 8)]
 

@@ -381,6 +381,70 @@ def gen_dense_grad():
                  out['bf16cal_grad'], out['bf16cal_grad_sampled'], out['bf16cal_worst_tensor'], time.time() - t0), flush=True)
 
 
+def gen_bf16_points():
+    """Fixtures of the bf16 plan's MODEL (oracle/bf16_points.py: fp64 arithmetic, operands rounded to bf16 where libsimq's plain-bf16 plan
+    rounds them) at the sizes the bf16 configs run: the TD step of cases.TRAIN_CASES_SIZED[:2] and the dense-upstream gradient of
+    cases.DENSE_GRAD_CASES[0].  Validated here before anything is written: with the rounding points OFF the model is the fp64 oracle
+    (1e-12; the oracle itself is pinned bit-exact to the imported reference by the generators above), with them ON it lands inside the
+    reference's own bf16-autocast calibration of the same batch (train_sized / dense_grad fixtures).  Summaries only."""
+    import time
+    from . import bf16_points as bp
+    rl2 = lambda a, b: float(np.sqrt(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).sum() / (np.asarray(b, np.float64) ** 2).sum()))
+
+    def sampled(d, keys):
+        return np.stack([d[k].double().reshape(-1)[torch.tensor(cases.sample_indices(d[k].numel()))].numpy() for k in keys])
+    for name, cin, cout, B, wseed, dseed in cases.TRAIN_CASES_SIZED[:2]:
+        t0 = time.time()
+        cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
+        gkeys = learner.grad_keys(spec)
+
+        def run(fn, **kw):
+            st, tg = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
+            ex = {}
+            info = fn(cfg, st, tg, spec, [None] * len(gkeys), batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, extras=ex, **kw)
+            return info, ex, st
+        i64, e64, s64 = run(learner.train_step, dtype=torch.float64)
+        ioff, eoff, soff = run(bp.train_step, points=False)
+        assert abs(ioff['loss'] - i64['loss']) <= 1e-12 * abs(i64['loss']), (name, ioff, i64)
+        assert rl2(sampled(eoff['grads'], gkeys), sampled(e64['grads'], gkeys)) < 1e-10, name
+        ion, eon, son = run(bp.train_step, points=True)
+        cal = np.load(os.path.join(cases.GOLDEN_DIR, name + '.npz'))
+        g_on, g_64 = sampled(eon['grads'], gkeys), sampled(e64['grads'], gkeys)
+        dist = dict(q_sa=float((eon['q'] - e64['q']).abs().max() / e64['q'].abs().max()), loss=abs(ion['loss'] - i64['loss']) / abs(i64['loss']),
+                    grad_sampled=rl2(g_on, g_64), y_maxabs=float((eon['y'] - e64['y']).abs().max()))
+        print('  %s: model vs fp64 -- q_sa %.3g, loss %.3g, sampled gradient %.3g, max |dy| %.3g;  reference under autocast on this batch: q_sa %.3g, '
+              'loss %.3g, gradient %.3g' % (name, dist['q_sa'], dist['loss'], dist['grad_sampled'], dist['y_maxabs'], float(cal['bf16cal_q_sa']),
+                                            float(cal['bf16cal_loss']), float(cal['bf16cal_grad'])), flush=True)
+        assert dist['q_sa'] <= 2.0 * float(cal['bf16cal_q_sa']) and dist['grad_sampled'] <= 2.0 * float(cal['bf16cal_grad']), (name, dist)
+        out = dict(loss=np.array(ion['loss']), td_error=np.array(ion['td_error']), q_sa=eon['q'].numpy(), y=eon['y'].numpy(),
+                   total_norm=np.array(eon['total_norm']), grad_keys=np.array(gkeys),
+                   grad_norm=np.array([float(eon['grads'][k].norm()) for k in gkeys]), grad=g_on,
+                   q_checksum=np.array([float(eon['output'].sum()), float(eon['output'].abs().sum())]),
+                   bn_buffers=cases.bn_buffer_vector(son), vs_fp64=np.array([dist['q_sa'], dist['loss'], dist['grad_sampled'], dist['y_maxabs']]))
+        np.savez_compressed(os.path.join(cases.GOLDEN_DIR, 'bf16pts_' + name + '.npz'), **out)
+        print('bf16-points case %s saved [%.0f s]' % (name, time.time() - t0), flush=True)
+    for name, cin, cout, B, wseed, dseed in cases.DENSE_GRAD_CASES[:1]:
+        t0 = time.time()
+        spec = fcn.state_spec(cin, cout)
+        gkeys = learner.grad_keys(spec)
+        x = torch.cat([learner.apply_transform(s_) for s_ in synth.make_states(B, cin, dseed)]).double()
+        R = torch.from_numpy(cases.dense_upstream(cout, B, dseed)).double()
+        q_off, g_off = bp.dense_gradient(cases.oracle_state(cin, cout, wseed, torch.float64), spec, x, R, points=False)
+        cal = np.load(os.path.join(cases.GOLDEN_DIR, name + '.npz'))
+        assert rl2(sampled(dict(zip(gkeys, g_off)), gkeys), cal['grad64']) < 1e-10, name
+        q_on, g_on = bp.dense_gradient(cases.oracle_state(cin, cout, wseed, torch.float64), spec, x, R, points=True)
+        gs = sampled(dict(zip(gkeys, g_on)), gkeys)
+        d_grad, d_q = rl2(gs, cal['grad64']), float((q_on - q_off).abs().max() / q_off.abs().max())
+        print('  %s: model vs fp64 -- Q %.3g, sampled gradient %.3g;  reference under autocast: Q %.3g, gradient (sampled) %.3g'
+              % (name, d_q, d_grad, float(cal['bf16cal_q']), float(cal['bf16cal_grad_sampled'])), flush=True)
+        assert d_q <= 2.0 * float(cal['bf16cal_q']) and d_grad <= 2.0 * float(cal['bf16cal_grad_sampled']), (name, d_q, d_grad)
+        out = dict(grad_keys=np.array(gkeys), grad_norm=np.array([float(g.norm()) for g in g_on]), grad=gs,
+                   q_checksum=np.array([float(q_on.sum()), float(q_on.abs().sum()), float((q_on * R).sum())]),
+                   q_sample=q_on.reshape(-1)[torch.tensor(cases.sample_indices(q_on.numel(), 4096))].numpy(), vs_fp64=np.array([d_q, d_grad]))
+        np.savez_compressed(os.path.join(cases.GOLDEN_DIR, 'bf16pts_' + name + '.npz'), **out)
+        print('bf16-points case %s saved [%.0f s]' % (name, time.time() - t0), flush=True)
+
+
 def gen_dp():
     """Fixture G7: the reference's multi-GPU form is nn.DataParallel (policies.py:39) -- the minibatch is cut
     into contiguous chunks, every replica runs the reference's own FCN on its chunk with ITS OWN train-mode BatchNorm statistics,
@@ -806,9 +870,10 @@ if __name__ == '__main__':
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
             'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
-            'dp': gen_dp, 'dp_literal': gen_dp_literal, 'bf16_calibration': gen_bf16_calibration,
+            'dp': gen_dp, 'dp_literal': gen_dp_literal, 'bf16_calibration': gen_bf16_calibration, 'bf16_points': gen_bf16_points,
             'grad_study': gen_grad_study,
             'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz'),
-            'grad_study_b32': lambda: gen_grad_study(cases.GRAD_STUDY_B32_CASES, 'grad_study_b32.npz')}
+            'grad_study_b32': lambda: gen_grad_study(cases.GRAD_STUDY_B32_CASES, 'grad_study_b32.npz'),
+            'grad_study_b128': lambda: gen_grad_study(cases.GRAD_STUDY_B128_CASES, 'grad_study_b128.npz')}
     for which in (sys.argv[1:] or list(gens)):     # e.g. `python -m oracle.gen_golden intention` regenerates one family
         gens[which]()

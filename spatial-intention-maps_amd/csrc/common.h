@@ -132,7 +132,11 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
 bool winograd_f4_forward(const ConvGeom& g, int min_tiles);
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                           hipStream_t stream, const InBn& in = InBn());
-int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in = InBn());
+// det_slab: NULL, or kWgradDetSlabFloats floats of scratch -- the pixel-split blocks then leave their partial tiles there and a second launch
+// adds them in split order (deterministic plans) instead of fp32 atomics into the zeroed dw
+constexpr int64_t kWgradDetSlabFloats = 16 << 20;
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in = InBn(), float* det_slab = nullptr);
+int launch_wgrad_slab_sum(const float* slab, float* dw, int64_t n, int splits, hipStream_t stream);   // dw[e] = sum_s slab[s][e], s ascending
 // conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
 int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
 bool winograd_wgrad_eligible(const ConvGeom& g);
@@ -146,7 +150,7 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
 // slab: conv_wgrad_bf16_slab_bytes() of scratch for the image-tile kernel's partial tiles, or NULL (every kernel then adds into the
 // zeroed dw with fp32 atomics)
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
-                           hipStream_t stream, float* slab = nullptr);
+                           hipStream_t stream, float* slab = nullptr, float* det_slab = nullptr);   // det_slab: as launch_conv_wgrad
 // conv_wgrad_bf16_pp.hip: 256 x 256 tiles, LDS-DMA staging, ping-pong wave groups; 1 = took the launch, 0 = shape not covered
 int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, const ConvGeom& g, unsigned x_bytes, unsigned dy_bytes,
                            hipStream_t stream);
@@ -232,9 +236,10 @@ int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, i
 int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
                            float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream,
                            const float* ypre = nullptr, int ypre_bf16 = 0, const float* mean = nullptr, const float* invstd = nullptr,
-                           double* red = nullptr);   // red: fused BN-backward sums of the BatchNorm in front (hb2)
+                           double* red = nullptr,    // red: fused BN-backward sums of the BatchNorm in front (hb2)
+                           int serial = 0);          // 1: one block walks the transitions in order (deterministic plans)
 int launch_head_conv3_bwd(const float* x, const float* w, const float* dq, float* dx, float* dw, float* dbias,
-                          int B, int HW, int Cin, int Cout, hipStream_t stream);
+                          int B, int HW, int Cin, int Cout, hipStream_t stream, float* det_slab = nullptr);   // det_slab: as launch_conv_wgrad
 
 // ---- learner kernels (learner.hip) -------------------------------------------------------------------
 int launch_q_argmax(const float* q, int rows, int n, int64_t* index, float* maxv, hipStream_t stream);

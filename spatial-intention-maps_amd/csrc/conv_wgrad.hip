@@ -31,6 +31,7 @@ struct WgradArgs {
     int tilesI, tilesJ, rows_per_split;
     unsigned x_bytes, dy_bytes;
     long gx, gdy, gdw;   // batched launch (blockIdx.y = g): element offsets of the g-th x / dy / dw (conv_winograd.hip)
+    float* slab;         // NULL, or [splits][Cout][K] partial tiles (deterministic plans: plain stores, summed in split order afterwards)
     const float* xscale; const float* xshift;   // XBN: x is a pre-BatchNorm output, the operand is relu(x * xscale[ci] + xshift[ci]) (common.h InBn)
 };
 
@@ -239,7 +240,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wi * (TI / WI) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                unsafeAtomicAdd(p.dw + blockIdx.y * p.gdw + (size_t)i * p.K + col, acc[a][b][r]);
+                if (p.slab) p.slab[((size_t)split * p.Cout + i) * p.K + col] = acc[a][b][r];
+                else unsafeAtomicAdd(p.dw + blockIdx.y * p.gdw + (size_t)i * p.K + col, acc[a][b][r]);
             }
         }
     }
@@ -269,6 +271,11 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
         const double cost = (double)rounds * ((rsteps + s - 1) / s + 6) / util;
         if (cost < best * 0.999) { best = cost; splits = s; }
     }
+    if (p.slab) {                                    // deterministic: every split owns a slab of Cout x K floats
+        const int64_t fit = kWgradDetSlabFloats / ((int64_t)p.Cout * p.K);
+        SIMQ_REQUIRE(batch == 1 && fit >= 1, "wgrad: the deterministic slab holds %ld floats, one tile set needs %ld", (long)kWgradDetSlabFloats, (long)p.Cout * p.K);
+        if (splits > fit) splits = (int)fit;
+    }
     if (const int forced_s = batch > 1 ? SIMQ_TUNE_INT("SIMQ_WGRAD_BATCHED_SPLITS", 0) : SIMQ_TUNE_INT("SIMQ_WGRAD_SPLITS", 0)) splits = forced_s;   // tuning aid (tools/wgrad_splits.py, ablation build)
     int rps = (p.M + splits - 1) / splits;
     rps = ((rps + BR - 1) / BR) * BR;
@@ -285,14 +292,31 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     }
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
+    if (p.slab) return launch_wgrad_slab_sum(p.slab, p.dw, (int64_t)p.Cout * p.K, splits, stream);
     return 0;
+}
+
+__global__ void __launch_bounds__(256) wgrad_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ dw, size_t n, int splits) {
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float a = slab[e];
+        for (int s2 = 1; s2 < splits; ++s2) a += slab[(size_t)s2 * n + e];
+        dw[e] = a;
+    }
 }
 
 }  // namespace
 
-int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in) {
+int launch_wgrad_slab_sum(const float* slab, float* dw, int64_t n, int splits, hipStream_t stream) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_slab_sum_kernel, dim3(blocks), dim3(256), 0, stream, slab, dw, (size_t)n, splits);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in, float* det_slab) {
     WgradArgs a;
-    a.x = x; a.dy = dy; a.dw = dw;
+    a.x = x; a.dy = dy; a.dw = dw; a.slab = det_slab;
     a.xscale = in.scale; a.xshift = in.shift;
     SIMQ_REQUIRE(!in.live, "conv_wgrad: BatchNorm-on-load takes the scale / shift the forward pass saved (not a live layer)");
     SIMQ_REQUIRE(!in.scale || g.Cin % 64 == 0, "conv_wgrad: BatchNorm-on-load needs Cin %% 64 == 0 (Cin=%d)", g.Cin);
@@ -332,7 +356,7 @@ int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int 
     a.M = M; a.K = K;
     a.tilesI = a.tilesJ = a.rows_per_split = 0;
     a.gx = (long)M * K; a.gdy = (long)M * N; a.gdw = (long)N * K;
-    a.xscale = a.xshift = nullptr;
+    a.xscale = a.xshift = nullptr; a.slab = nullptr;
     const double xb = 4.0 * M * K, yb = 4.0 * M * N;
     SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "wgrad_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;

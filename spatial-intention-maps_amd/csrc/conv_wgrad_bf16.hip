@@ -30,6 +30,7 @@ struct WgradBfArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesI, tilesJ, rows_per_split;
+    float* slab;         // NULL, or [splits][Cout][K] partial tiles (deterministic plans, see conv_wgrad.hip)
     unsigned x_bytes, dy_bytes;
 };
 
@@ -226,7 +227,8 @@ __global__ void __launch_bounds__(256, NP == 1 ? 3 : 2) wgrad_bf16_kernel(const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * (TI / 2) + a * 16 + 4 * fg + r;
-                unsafeAtomicAdd(p.dw + (size_t)i * p.K + col, acc[a][b][r]);
+                if (p.slab) p.slab[((size_t)split * p.Cout + i) * p.K + col] = acc[a][b][r];
+                else unsafeAtomicAdd(p.dw + (size_t)i * p.K + col, acc[a][b][r]);
             }
         }
     }
@@ -254,6 +256,11 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
         const double cost = (double)rounds * ((rsteps + s - 1) / s + 4);
         if (cost < best * 0.999) { best = cost; splits = s; }
     }
+    if (p.slab) {                                    // deterministic: every split owns a slab of Cout x K floats
+        const int64_t fit = kWgradDetSlabFloats / ((int64_t)p.Cout * p.K);
+        SIMQ_REQUIRE(fit >= 1, "wgrad_bf16: the deterministic slab holds %ld floats, one tile set needs %ld", (long)kWgradDetSlabFloats, (long)p.Cout * p.K);
+        if (splits > fit) splits = (int)fit;
+    }
     int rps = (p.M + splits - 1) / splits;
     rps = ((rps + BRB - 1) / BRB) * BRB;
     splits = (p.M + rps - 1) / rps;
@@ -264,6 +271,7 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((wgrad_bf16_kernel<TI, TJ, NP>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
+    if (p.slab) return launch_wgrad_slab_sum(p.slab, p.dw, (int64_t)p.Cout * p.K, splits, stream);
     return 0;
 }
 
@@ -282,8 +290,9 @@ int dispatch(const WgradBfArgs& a, hipStream_t stream) {
 }  // namespace
 
 int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[2], int nplanes, float* dw, const ConvGeom& g,
-                           hipStream_t stream, float* slab) {
+                           hipStream_t stream, float* slab, float* det_slab) {
     WgradBfArgs a;
+    a.slab = det_slab;
     a.x[0] = x[0]; a.x[1] = nplanes == 2 ? x[1] : x[0];
     a.dy[0] = dy[0]; a.dy[1] = nplanes == 2 ? dy[1] : dy[0];
     a.dw = dw;
@@ -299,8 +308,10 @@ int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[
     if (nplanes == 1) {                                  // wide 3x3 layers: 256 x 256 ping-pong tiles (conv_wgrad_bf16_pp.hip)
         int took = try_conv_wgrad_bf16_img(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream, slab);      // image tile: all nine taps per block
         if (took != 0) return took < 0 ? took : 0;
-        took = try_conv_wgrad_bf16_pp(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream);
-        if (took != 0) return took < 0 ? took : 0;
+        if (!det_slab) {                                 // (its pixel split adds with fp32 atomics: not for deterministic plans)
+            took = try_conv_wgrad_bf16_pp(x[0], dy[0], dw, g, a.x_bytes, a.dy_bytes, stream);
+            if (took != 0) return took < 0 ? took : 0;
+        }
     }
     return nplanes == 2 ? dispatch<2>(a, stream) : dispatch<1>(a, stream);
 }

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) head_conv3_fwd_kernel(const float* __rest
 template <int CIN>
 __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ dq, float* __restrict__ dx,
-                                                             float* dw, float* dbias, int B, int HW, int Cout) {
+                                                             float* dw, float* dbias, int B, int HW, int Cout, float* slab_w, float* slab_b) {
     constexpr int L = CIN / 4;
     __shared__ float red[256 * 4];
     const int sub = threadIdx.x % L;
@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __rest
             int s = threadIdx.x / 4, e = threadIdx.x % 4;
             float a = 0.f;
             for (int t = s; t < 256; t += L) a += red[t * 4 + e];
-            unsafeAtomicAdd(dw + co * CIN + threadIdx.x, a);
+            if (slab_w) slab_w[(size_t)blockIdx.x * Cout * CIN + co * CIN + threadIdx.x] = a;     // deterministic plans: summed in block order afterwards
+            else unsafeAtomicAdd(dw + co * CIN + threadIdx.x, a);
         }
         __syncthreads();
         red[threadIdx.x] = (sub == 0) ? gb[co] : 0.f;
@@ -88,7 +89,8 @@ __global__ void __launch_bounds__(256) head_conv3_bwd_kernel(const float* __rest
         if (threadIdx.x == 0) {
             float a = 0.f;
             for (int t = 0; t < 256; ++t) a += red[t];
-            unsafeAtomicAdd(dbias + co, a);
+            if (slab_b) slab_b[(size_t)blockIdx.x * Cout + co] = a;
+            else unsafeAtomicAdd(dbias + co, a);
         }
     }
 }
@@ -110,12 +112,15 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
                                                              const int64_t* __restrict__ action, const float* __restrict__ q_sa,
                                                              const float* __restrict__ y, float grad_scale, float* ds1, float* dw3,
                                                              float* db3, int Cout, const float* __restrict__ ypre, int ypre_bf16,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd, double* red) {
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, double* red, int B) {
     constexpr int W2 = 96, W1 = 48, CIN = 32;
-    const int b = blockIdx.x, ci = threadIdx.x;
+    // one block per transition (the default), or ONE block that walks the transitions in order (deterministic plans: the B atomic adds
+    // into dw3 / db3 / red then happen in a fixed order)
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int ci = threadIdx.x;
     const int64_t a = action[b];
     const int co = (int)(a / (W2 * W2)), p = (int)(a - (int64_t)co * W2 * W2);
-    if (co >= Cout) return;
+    if (co >= Cout) continue;
     const int oy = p / W2, ox = p - oy * W2;
     const float d = q_sa[b] - y[b];
     const float g = fminf(fmaxf(d, -1.f), 1.f) * grad_scale;
@@ -138,7 +143,7 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
     base[(y1 * W1 + x1) * CIN] += ly1 * lx1 * dx;
     // The gradient of this sample is zero outside these <= 4 pixels, so the BatchNorm-backward sums of the layer in front (sum dz,
     // sum dz * xhat with dz = ds1 * [a > 0]) are complete after a look at them -- no pass over the 48x48x32 map (red == NULL: not fused)
-    if (!red) return;
+    if (!red) continue;
     const float mu = mean[ci], is = invstd[ci];
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -156,6 +161,7 @@ __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __rest
     }
     unsafeAtomicAdd(red + ci, (double)s0);
     unsafeAtomicAdd(red + CIN + ci, (double)s1);
+    }
 }
 
 // q[b][co] (96x96, NCHW) = bilinear x2 (align_corners=True) of z[b][co] (48x48) + bias[co]: 4 outputs along x per thread
@@ -201,11 +207,11 @@ int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, i
 
 int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,
                            float grad_scale, float* ds1, float* dw3, float* db3, int B, int Cout, hipStream_t stream,
-                           const float* ypre, int ypre_bf16, const float* mean, const float* invstd, double* red) {
+                           const float* ypre, int ypre_bf16, const float* mean, const float* invstd, double* red, int serial) {
     SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_onehot_bwd: Cout=%d unsupported", Cout);
     SIMQ_CHECK_HIP(hipMemsetAsync(ds1, 0, sizeof(float) * (size_t)B * 48 * 48 * 32, stream));
-    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout,
-                       ypre, ypre_bf16, mean, invstd, red);
+    hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(serial ? 1 : B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout,
+                       ypre, ypre_bf16, mean, invstd, red, B);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
@@ -222,14 +228,20 @@ int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, flo
 }
 
 int launch_head_conv3_bwd(const float* x, const float* w, const float* dq, float* dx, float* dw, float* dbias, int B,
-                          int HW, int Cin, int Cout, hipStream_t stream) {
+                          int HW, int Cin, int Cout, hipStream_t stream, float* det_slab) {
     SIMQ_REQUIRE(Cin == 32 && Cout >= 1 && Cout <= MAX_COUT, "head_conv3: Cin=%d Cout=%d unsupported", Cin, Cout);
     SIMQ_REQUIRE((size_t)B * HW < 2147483648ull, "head_conv3: too many pixels for 32-bit indexing");
     size_t blocks = ((size_t)B * HW + 31) / 32;
     if (blocks > 1024) blocks = 1024;
+    float* slab_w = det_slab;
+    float* slab_b = det_slab ? det_slab + 1024 * MAX_COUT * 32 : nullptr;
     hipLaunchKernelGGL(head_conv3_bwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, stream, x, w, dq, dx, dw, dbias, B,
-                       HW, Cout);
+                       HW, Cout, slab_w, slab_b);
     SIMQ_CHECK_LAUNCH();
+    if (det_slab) {                                   // (dw / dbias are overwritten: they were zero, nothing else adds into them)
+        if (int rc = launch_wgrad_slab_sum(slab_w, dw, (int64_t)Cout * 32, (int)blocks, stream)) return rc;
+        return launch_wgrad_slab_sum(slab_b, dbias, Cout, (int)blocks, stream);
+    }
     return 0;
 }
 

@@ -153,6 +153,7 @@ struct Layout {
     int64_t p_pooled, p_up1, DP[2];
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
     int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
+    int64_t dslab;   // deterministic plans: per-split partial tiles of the pixel-split weight-gradient kernels (64 MB), -1 otherwise
     int64_t total;
 };
 
@@ -196,6 +197,7 @@ Layout make_layout(const simq_plan* p, int B) {
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
     L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
+    L.dslab = p->opt.deterministic ? take(kWgradDetSlabFloats * f) : -1;
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.total = off;
     return L;
@@ -280,6 +282,7 @@ struct Ctx {
     bool mask1_from_y() const {
         return lazy1() || (p->precision == SIMQ_PREC_BF16 && p->opt.bn1_mask_from_preact && planes_only());
     }
+    float* dslab() const { return L.dslab >= 0 ? f(L.dslab) : nullptr; }      // deterministic plans: slab of the pixel-split weight gradients
     InBn inbn_saved(const BnL& b) const { InBn in; in.scale = aux(b, 0); in.shift = aux(b, 1); return in; }     // backward pass
     // weight planes of conv cv: plain (OHWI) or flipped/transposed (dgrad)
     void wplanes(const ConvL& cv, bool transposed, const uint16_t* out[2]) const {
@@ -571,12 +574,12 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
         SIMQ_REQUIRE(!in.on(), "conv_wgrad: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
         const uint16_t* ds[2] = {dy.pl.hi, dy.pl.lo ? dy.pl.lo : dy.pl.hi};
-        return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream, c.L.wslab >= 0 ? c.f(c.L.wslab) : nullptr);
+        return launch_conv_wgrad_bf16(xs, ds, c.p->np(), c.grads + cv.w_off, g, c.stream, c.L.wslab >= 0 ? c.f(c.L.wslab) : nullptr, c.dslab());
     }
     if (cv.wu_off >= 0 && c.L.wino >= 0 && winograd_wgrad_eligible(g) && c.p->opt.winograd_wgrad &&
         winograd_wgrad_pays(g, c.p->opt.winograd_wgrad_f4 != 0))
         return launch_conv_wgrad_winograd(x.f, dy.f, c.grads + cv.w_off, g, c.f(c.L.wino), c.stream, c.p->opt.winograd_wgrad_f4 != 0, in);
-    return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream, in);
+    return launch_conv_wgrad(x.f, dy.f, c.grads + cv.w_off, g, c.stream, in, c.dslab());
 }
 
 // dx = dgrad(dy) (+ addend): a stride-1 convolution of dy with the flipped / transposed weight
@@ -630,10 +633,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
         RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
                                   c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, p->cout, c.stream,
-                                  c.f(L.yh2), 0, c.aux(p->hb2, 2), c.aux(p->hb2, 3), no_fuse_head ? nullptr : c.red(p->hb2)));
+                                  c.f(L.yh2), 0, c.aux(p->hb2, 2), c.aux(p->hb2, 3), no_fuse_head ? nullptr : c.red(p->hb2), p->opt.deterministic));
     } else {
         RC(launch_upsample2x_fwd(c.f(L.ah2), c.f(L.up2), B, 48, 48, 32, c.stream));   // (the forward pass does not keep it)
-        RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream));
+        RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream,
+                                 c.dslab()));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
     Act dyh = dyact(S[0], 0);
@@ -785,7 +789,7 @@ void simq_plan_options_default(simq_plan_options* o) {
     o->winograd_f4_grad = 2; o->winograd_f4_fwd_grad_min_cc = 512 * 512; o->winograd_wgrad = 1; o->winograd_wgrad_f4 = 1;
     o->stem_bf16 = 1; o->bf16_act_grads = 1; o->keep_fp32_activations = 0; o->fold_eval_bn_bf16 = 1;
     o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
-    o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1;
+    o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1; o->deterministic = 0;
 }
 
 int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out) {
@@ -916,6 +920,42 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
     if (byte_offset) *byte_offset = off;
     if (elems) *elems = cnt;
     if (channels) *channels = ch;
+    return 0;
+}
+
+int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels, int* storage) {
+    SIMQ_REQUIRE(plan && name && batch >= 1, "workspace_tensor_ex: bad argument");
+    const Layout L = make_layout(plan, batch);
+    const bool mc = plan->precision != SIMQ_PREC_FP32, ybf = plan->precision == SIMQ_PREC_BF16;
+    const bool planes_only = mc && !plan->opt.keep_fp32_activations && plan->opt.fuse_bn_backward_sums;
+    int li = 0, bi = 0;
+    char what[32] = "";
+    int64_t off = -1, cnt = 0;
+    int ch = 0, st = 0;
+    if (sscanf(name, "layer%d.%d.%31s", &li, &bi, what) == 3 && li >= 1 && li <= 4 && bi >= 0 && bi <= 1) {
+        const int i = (li - 1) * 2 + bi;
+        const BlockL& b = plan->blocks[i];
+        const Layout::Blk& o = L.blk[i];
+        const std::string w(what);
+        ch = b.planes; cnt = (int64_t)batch * 576 * ch;
+        auto bnaux = [&](const BnL& bn) { off = L.aux + bn.aux_off * (int64_t)sizeof(float); cnt = 4 * (int64_t)bn.C; ch = bn.C; st = 0; };
+        if (w == "y1") { off = o.y1; st = ybf; }
+        else if (w == "y2") { off = o.y2; st = ybf; }
+        else if (w == "yd" && b.has_ds) { off = o.yd; st = ybf; }
+        else if (w == "a1") { off = planes_only ? o.p_a1 : o.a1; st = planes_only ? 1 : 0; }
+        else if (w == "out") { off = planes_only ? o.p_out : o.out; st = planes_only ? 1 : 0; }
+        else if (w == "bn1") bnaux(b.b1);
+        else if (w == "bn2") bnaux(b.b2);
+        else if (w == "bnd" && b.has_ds) bnaux(b.bds);
+        if ((w == "a1") && plan->precision == SIMQ_PREC_FP32 && plan->opt.fuse_bn1_apply && plan->opt.fuse_bn_backward_sums) off = -1;   // never stored
+    } else if (std::string(name) == "stem.pool.plane" && mc) {
+        off = L.p_pooled; ch = 64; cnt = (int64_t)batch * 576 * 64; st = 1;
+    }
+    SIMQ_REQUIRE(off >= 0, "workspace_tensor_ex: '%s' is not a tensor this plan stores", name);
+    if (byte_offset) *byte_offset = off;
+    if (elems) *elems = cnt;
+    if (channels) *channels = ch;
+    if (storage) *storage = st;
     return 0;
 }
 
@@ -1253,6 +1293,45 @@ int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     RC(launch_wino_weight(d_w, d_scratch, cout, cin, st));
     return launch_conv_winograd(d_x, d_scratch, d_y, g, e, d_scratch + (size_t)16 * cout * cin, st);
+}
+
+int simq_bn_relu_apply(const void* d_y, const double* d_stats, const float* d_gamma, const float* d_beta, const void* d_res, int relu, void* d_out,
+                       int64_t rows, int channels, int storage, float* d_saved, float* d_running, void* stream) {
+    SIMQ_REQUIRE(d_y && d_stats && d_gamma && d_beta && d_out && d_saved && d_running && rows >= 1 && channels >= 4, "bn_relu_apply: bad argument");
+    SIMQ_REQUIRE(storage == 0 || storage == 1, "bn_relu_apply: storage %d (0 fp32, 1 bf16)", storage);
+    BnRef r;
+    r.stats = d_stats; r.gamma = d_gamma; r.beta = d_beta;
+    r.rmean = d_running; r.rvar = d_running + channels;
+    r.save_scale = d_saved; r.save_shift = d_saved + channels; r.save_mean = d_saved + 2 * channels; r.save_invstd = d_saved + 3 * channels;
+    r.rows = (double)rows; r.inv_rows = 1.0 / r.rows; r.C = channels;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (storage == 0)
+        return launch_bn_apply(static_cast<const float*>(d_y), r, static_cast<const float*>(d_res), nullptr, relu, static_cast<float*>(d_out), rows, channels, st);
+    Planes out, res;
+    out.hi = static_cast<uint16_t*>(d_out);
+    res.hi = static_cast<uint16_t*>(const_cast<void*>(d_res));
+    return launch_bn_apply(static_cast<const float*>(d_y), r, nullptr, nullptr, relu, nullptr, rows, channels, st, out, res, 1);
+}
+
+int simq_bn_relu_backward(const void* d_g, const void* d_mask, int mask_kind, const void* d_y, const float* d_saved, const float* d_gamma,
+                          const double* d_red, void* d_dy, void* d_dz_out, float* d_dgamma, float* d_dbeta, int64_t rows, int channels,
+                          int storage, void* stream) {
+    SIMQ_REQUIRE(d_g && d_y && d_saved && d_gamma && d_red && d_dy && d_dgamma && d_dbeta && rows >= 1 && channels >= 4, "bn_relu_backward: bad argument");
+    SIMQ_REQUIRE((storage == 0 || storage == 1) && mask_kind >= 0 && mask_kind <= 2 && (mask_kind != 1 || d_mask), "bn_relu_backward: storage %d / mask_kind %d", storage, mask_kind);
+    const float* mean = d_saved + 2 * channels;
+    const float* invstd = d_saved + 3 * channels;
+    const float* msc = mask_kind == 2 ? d_saved : nullptr;
+    const float* msh = mask_kind == 2 ? d_saved + channels : nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (storage == 0)
+        return launch_bn_bwd_apply(static_cast<const float*>(d_g), mask_kind == 1 ? static_cast<const float*>(d_mask) : nullptr, static_cast<const float*>(d_y),
+                                   mean, invstd, d_gamma, d_red, static_cast<float*>(d_dy), static_cast<float*>(d_dz_out), d_dgamma, d_dbeta, rows, channels,
+                                   st, Planes(), nullptr, 0, 0.0, 1.f, 0, msc, msh);
+    Planes dy;
+    dy.hi = static_cast<uint16_t*>(d_dy);
+    return launch_bn_bwd_apply(static_cast<const float*>(d_g), nullptr, static_cast<const float*>(d_y), mean, invstd, d_gamma, d_red, nullptr,
+                               static_cast<float*>(d_dz_out), d_dgamma, d_dbeta, rows, channels, st, dy,
+                               mask_kind == 1 ? static_cast<const uint16_t*>(d_mask) : nullptr, 1, 0.0, 1.f, 1, msc, msh);
 }
 
 int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_w, const float* d_bias,

@@ -47,7 +47,7 @@ class PlanOptions(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
         'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
-        'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'bn1_mask_from_preact')]
+        'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'deterministic', 'bn1_mask_from_preact')]
 
 
 class TrainArgs(ctypes.Structure):
@@ -83,6 +83,7 @@ _SIGS = {
     'simq_bn_layer_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int)]),
     'simq_workspace_bytes': (c_int64, [c_void_p, c_int]),
     'simq_workspace_tensor': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
+    'simq_workspace_tensor_ex': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
     'simq_wcache_bytes': (c_int64, [c_void_p]),
     'simq_weights_prepare': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_forward': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -121,6 +122,8 @@ _SIGS = {
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_bn_relu_apply': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'simq_bn_relu_backward': (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_void_p]),
     'simq_conv2d_fwd_bnrelu_in': (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
     'simq_conv2d_wgrad_bnrelu_in': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_stem_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),

@@ -330,6 +330,21 @@ class FCN(torch.nn.Module):
         hw = int(round((n.value // (batch * ch.value)) ** 0.5))
         return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(batch, hw, hw, ch.value)
 
+    def stored_tensor(self, name, batch, slot='train'):
+        """A block-internal tensor of the last forward in workspace `slot` (simq_workspace_tensor_ex: 'layer<l>.<b>.<y1|a1|y2|yd|out>' as
+        [B,24,24,C] fp32 or bf16, 'layer<l>.<b>.<bn1|bn2|bnd>' as [4,C] = scale | shift | mean | invstd, 'stem.pool.plane') -- teacher-forced tests."""
+        import ctypes
+        off, n, ch, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+        lib.call('simq_workspace_tensor_ex', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch), ctypes.byref(st))
+        ws = self._ws[slot]
+        if st.value:
+            t = ws[off.value:off.value + 2 * n.value].view(torch.bfloat16)
+        else:
+            t = ws[off.value:off.value + 4 * n.value].view(torch.float32)
+        if n.value == 4 * ch.value:
+            return t.view(4, ch.value)
+        return t.view(batch, 24, 24, ch.value)
+
     def infer_argmax_batch(self, states, need_q=False):
         """Eval-mode forward of several HWC states (numpy [96,96,C] or device tensors [1,96,96,C]) in ONE batch + one
         argmax launch: the multi-robot form of infer_argmax (batched multi-env inference)."""

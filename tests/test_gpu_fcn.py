@@ -583,10 +583,11 @@ def test_onehot_backward_equals_dense_backward(simq_mod, cout):
     assert num < 1e-4, num
 
 
-@pytest.mark.parametrize('fixture,case_list', [('grad_study.npz', cases.GRAD_STUDY_CASES), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES),
-                                               ('grad_study_b32.npz', cases.GRAD_STUDY_B32_CASES)],
-                         ids=['b8_b32', 'b64', 'b32x12'])
-def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
+@pytest.mark.parametrize('fixture,case_list,worst', [('grad_study.npz', cases.GRAD_STUDY_CASES, 10.0), ('grad_study_b64.npz', cases.GRAD_STUDY_B64_CASES, 10.0),
+                                                     ('grad_study_b32.npz', cases.GRAD_STUDY_B32_CASES, 10.0),
+                                                     ('grad_study_b128.npz', cases.GRAD_STUDY_B128_CASES, 3.0)],
+                         ids=['b8_b32', 'b64', 'b32x12', 'b128x12'])
+def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list, worst):
     """SURVEY section 0's criterion for gradients, err_build <= k * err_reference-fp32, judged as a DISTRIBUTION (fixture
     tests/golden/grad_study.npz, written by oracle/gen_golden.py from the imported reference: 10 seeded B=8 and 3 seeded B=32 batches,
     each with the fp64 oracle's gradient / first-update / second-step-loss and the error the REFERENCE's own fp32 train.train makes on
@@ -598,7 +599,9 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     Second fixture (grad_study_b64.npz, six seeded batches of 64 = configs[3]'s per-GPU batch, where the fp32 plans pick their large-batch
     tiles and 36-plane Winograd problems): the same bars.  Third fixture (grad_study_b32.npz, twelve seeded batches of the headline workload's
     own shape -- 32 transitions, Cin 4, Cout 2): the same bars; it is the sample the choice of F(4x4,3x3) for the grad-mode forward of
-    layer4's 512->512 convolutions rests on (tests/diag_f4_grad_layers.py)."""
+    layer4's 512->512 convolutions rests on (tests/diag_f4_grad_layers.py).  Fourth fixture (grad_study_b128.npz, round 4: twelve
+    batches of 128 = configs[2] / configs[4]'s per-GPU shape, Cin 5, Cout 2): median <= 2 x and NO case beyond 3 x the reference's own error
+    -- the single sized fixture train_c5o2_b128 sits at 2.6 x (tests/test_gpu_sized.py); the distribution says whether that is one batch."""
     from oracle import learner as olearner
     g = np.load('%s/%s' % (golden_dir, fixture))
     rows = []
@@ -612,7 +615,7 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
         coef = min(1.0, cases.CLIP / (tn + 1e-6))
         grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
         p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
-        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < 3 or B <= 8 else (None, None)
+        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < (3 if B >= 128 else 6) or B <= 8 else (None, None)
         info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
         if sd1 is not None:     # the second call per transition against the fp64 oracle run from the post-step-1 state (tests/step2_oracle.py)
             step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)
@@ -640,14 +643,20 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list):
     for k, rk in (('grad', 'ref_grad'), ('dparam', 'ref_dparam')):
         assert med(k) <= 2.0 * med(rk), (k, med(k), med(rk))
         for r in rows:
-            assert r[k] <= 10.0 * max(r[rk], med(rk)), (k, r)
+            assert r[k] <= worst * max(r[rk], med(rk)), (k, r)
     # The second step's loss against the fp64 TRAJECTORY is the first update's error seen through a chaotic synthetic problem: in the
     # fixture the reference's own fp32 second-step loss is off by up to 15 x its update error (0.10 on gs_b8_03), with a heavy tail
     # (13 samples: 2e-5 .. 1e-1), and one summation order against another moves it by several per cent (tests/diag_step2_sensitivity.py).
-    # What "the second call is right" means is checked above per transition against the oracle (every B = 8 case and the first three of
-    # each fixture); the trajectory keeps a distribution bar: median within 4 x the reference's median, no case beyond 25 %.
+    # What "the second call is right" means is checked above per transition against the oracle (every B = 8 case and the first six of
+    # each fixture, three at B = 128); the trajectory keeps a distribution bar -- median within 4 x the reference's median, no case beyond 25 % --
+    # AND a reference-relative bar per case: the reference's own fp32 turns its first-update error into a second-step loss error with some
+    # amplification (ref_loss2 / ref_dparam, 2 .. 80 over the fixtures); no HIP case may exceed the LARGEST amplification the reference itself
+    # shows in the fixture applied to its own update error, with a floor of the reference's median second-step error.
     assert med('loss2') <= 4.0 * med('ref_loss2'), (med('loss2'), med('ref_loss2'))
     assert all(r['loss2'] < 0.25 for r in rows), [r['loss2'] for r in rows]
+    amp = max(r['ref_loss2'] / max(r['ref_dparam'], 1e-12) for r in rows)
+    for r in rows:
+        assert r['loss2'] <= 2.0 * amp * r['dparam'] + 4.0 * med('ref_loss2') + 1e-4, ('second-step loss beyond the reference\'s own amplification', r, amp)
 
 
 def test_optimizer_state_is_interchangeable_with_the_reference_layout(simq_mod, tmp_path):
