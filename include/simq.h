@@ -105,7 +105,7 @@ typedef struct simq_plan_options {
                                    * gradients whose pixel reduction is split over blocks leave per-split partial tiles in a slab (64 MB more
                                    * workspace) that a second launch adds in split order, instead of fp32 atomics; the one-hot head backward walks the
                                    * transitions in order.  Forward, TD targets, loss and BatchNorm statistics are bit-reproducible in either setting
-                                   * (tools/determinism_probe.py): their fp64 accumulators round to the same fp32 value whatever the order. */
+                                   * (tests/diag/diag_determinism.py): their fp64 accumulators round to the same fp32 value whatever the order. */
     int bn1_mask_from_preact;     /* 1 (plain-bf16 plans): the backward pass takes that ReLU mask from the saved pre-BN output (scale*y+shift > 0)
                                    * instead of reading the activation's plane -- one bf16 plane less in bn_bwd_apply and in the dgrad epilogue */
 } simq_plan_options;
@@ -133,6 +133,9 @@ int simq_bn_layer_info(const simq_plan* plan, int index, char* name, int name_ca
 
 /* Bytes of workspace simq_forward/simq_backward need for `batch` samples. */
 int64_t simq_workspace_bytes(const simq_plan* plan, int batch);
+/* ... when the workspace only ever serves forward passes (the target net's, the no-grad forward's `ws_tmp`, policy.step): the same
+ * layout without the scratch slabs of the weight-gradient kernels at its end (75.5 MB per workspace in plain-bf16 plans). */
+int64_t simq_workspace_bytes_forward(const simq_plan* plan, int batch);
 
 /* Weight cache: derived copies of the convolution weights (flipped/transposed for dgrad; bf16 planes for the matrix-core
  * precisions).  Caller-owned buffer of simq_wcache_bytes(); call simq_weights_prepare after EVERY change of d_params
@@ -258,7 +261,8 @@ typedef struct simq_train_args {
     void* opt_scratch; float* total_norm;
     void* stream; void* side_stream;
     int global_nonfinal;         /* sync_bn: non-final next states over all ranks (the double-DQN forward's global row count) */
-    int reserved3_;
+    int struct_bytes;            /* sizeof(simq_train_args) of the caller's header: checked, so that a struct from another version is refused
+                                  * instead of misread (the field sits where round 2's reserved3_ was) */
     struct simq_comm* comm;      /* NULL: single process.  Otherwise the data-parallel form: `batch` is this rank's shard of a
                                   * minibatch of `global_batch` transitions; head + layer4 gradients (simq_grad_bucket_split) are
                                   * summed over the ranks while layers 3..1 + stem are still being differentiated, then the rest
@@ -270,7 +274,9 @@ typedef struct simq_train_args {
                                   * loss.item() without waiting for backward + SGD, so that the next step is enqueued while this one runs */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
-/* blocks until the loss_host copy of the calling thread's last simq_train_step on the current device has landed */
+/* blocks until the loss_host copy of the calling thread's last simq_train_step on the current device has landed.  The step's streams
+ * must belong to the device that was current when simq_train_step was called (checked); per host thread and device the library keeps one
+ * copy stream and two events for the life of the process. */
 int simq_train_loss_wait(void);
 
 /* ---- gradient exchange between data-parallel ranks (replaces the reduce-add of nn.DataParallel, policies.py:39) --------------

@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...);
 // Kernel-selection / tuning / timing-ablation switches.  They never change WHAT is computed (beyond fp32 summation order) and they are
 // not part of the product: libsimq.so is built without SIMQ_ABLATIONS, every SIMQ_TUNE_INT is then its default as a compile-time
 // constant (the environment is not read, the switch's name is not even in the binary) and the ablation instantiations of the
-// ping-pong kernels are not compiled.  `make ablate` builds libsimq_ablate.so with -DSIMQ_ABLATIONS for tools/ (tools/_ablate.py).
+// ping-pong kernels are not compiled.  `make ablate` builds libsimq_ablate.so with -DSIMQ_ABLATIONS for tools/ (tools/ab_step.py and the *_check.py probes select it through SIMQ_LIBRARY).
 // Switches that change the ARITHMETIC of a plan (Winograd forms, storage precisions, fusions) are simq_plan_options (include/simq.h).
 #ifdef SIMQ_ABLATIONS
 int tune_env_int(const char* name, int dflt);

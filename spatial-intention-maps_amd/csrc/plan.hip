@@ -154,6 +154,7 @@ struct Layout {
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
     int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
     int64_t dslab;   // deterministic plans: per-split partial tiles of the pixel-split weight-gradient kernels (64 MB), -1 otherwise
+    int64_t fwd_total;   // bytes a workspace needs when only forward passes use it (no weight-gradient slabs)
     int64_t total;
 };
 
@@ -196,9 +197,10 @@ Layout make_layout(const simq_plan* p, int B) {
         L.DP[0] = take((int64_t)B * 294912 * h);
         L.DP[1] = take((int64_t)B * 294912 * h);
     }
+    L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
+    L.fwd_total = off;          // everything a FORWARD pass touches ends here; what follows is scratch of the backward pass only
     L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
     L.dslab = p->opt.deterministic ? take(kWgradDetSlabFloats * f) : -1;
-    L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.total = off;
     return L;
 }
@@ -894,6 +896,11 @@ int64_t simq_workspace_bytes(const simq_plan* plan, int batch) {
     return make_layout(plan, batch).total;
 }
 
+int64_t simq_workspace_bytes_forward(const simq_plan* plan, int batch) {
+    if (!plan || batch < 1) return -1;
+    return make_layout(plan, batch).fwd_total;
+}
+
 int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels) {
     SIMQ_REQUIRE(plan && name && batch >= 1, "workspace_tensor: bad argument");
     const Layout L = make_layout(plan, batch);
@@ -1096,6 +1103,11 @@ int loss_copy(const float* d_out4, float* h_out4, hipStream_t producer, bool own
     int dev = 0;
     SIMQ_CHECK_HIP(hipGetDevice(&dev));
     SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+    if (producer) {                         // the copy stream / events are created on the CURRENT device: it must be the producer stream's
+        hipDevice_t sdev = 0;
+        SIMQ_CHECK_HIP(hipStreamGetDevice(producer, &sdev));
+        SIMQ_REQUIRE((int)sdev == dev, "train_step: the stream belongs to device %d, the calling thread's current device is %d", (int)sdev, dev);
+    }
     LossCopy& c = g_loss_copy[dev];
     if (!c.copy) {
         SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
@@ -1128,6 +1140,8 @@ int simq_train_loss_wait(void) {
 
 int simq_train_step(const simq_train_args* a) {
     SIMQ_REQUIRE(a && a->plan, "train_step: NULL argument");
+    SIMQ_REQUIRE(a->struct_bytes == (int)sizeof(simq_train_args), "train_step: simq_train_args.struct_bytes = %d, this library's struct has %d bytes",
+                 a->struct_bytes, (int)sizeof(simq_train_args));
     SIMQ_REQUIRE(a->params && a->wcache && a->bnbuf && a->grads && a->momentum_buf && a->ws_train && a->ws_tmp && a->t_params &&
                  a->t_wcache && a->t_bnbuf && a->t_ws && a->state && a->next_state && a->action && a->reward && a->nonfinal_pos &&
                  a->q && a->q_tgt && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,

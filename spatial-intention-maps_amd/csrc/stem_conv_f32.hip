@@ -19,6 +19,8 @@
 // Arithmetic: exact fp32 FMA chains (the fp32 parity bars apply unchanged); only the summation order differs from the generic kernel.
 #include <cstdint>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace simq {
@@ -196,10 +198,14 @@ int launch_stem_conv_f32(const float* x, const float* w_ohwi, float* y, double* 
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;                 // persistent blocks
     void (*kern)(const StemF32Args) = nss == 1 ? stem_conv_f32_kernel<1> : nss == 2 ? stem_conv_f32_kernel<2>
                                     : nss == 3 ? stem_conv_f32_kernel<3> : stem_conv_f32_kernel<4>;
-    static int attr_smem[5] = {0, 0, 0, 0, 0};
-    if (smem > attr_smem[nss]) {
+    // (the attribute is per device and per function: remembered per device, and a racing second thread only repeats the call)
+    static std::atomic<int> attr_smem[64][5];
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    SIMQ_REQUIRE(dev >= 0 && dev < 64, "stem_conv_f32: device index %d out of range", dev);
+    if (smem > attr_smem[dev][nss].load(std::memory_order_relaxed)) {
         SIMQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_smem[nss] = smem;
+        attr_smem[dev][nss].store(smem, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVE * 64), smem, stream, p);
     SIMQ_CHECK_LAUNCH();

@@ -61,7 +61,7 @@ class TrainArgs(ctypes.Structure):
                     't_params', 't_wcache', 't_bnbuf', 't_ws',
                     'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
                     'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
-                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('reserved3_', c_int), ('comm', c_void_p), ('loss_host', c_void_p)]
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('struct_bytes', c_int), ('comm', c_void_p), ('loss_host', c_void_p)]
 
 
 _SIGS = {
@@ -82,6 +82,7 @@ _SIGS = {
     'simq_bn_num_layers': (c_int, [c_void_p]),
     'simq_bn_layer_info': (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int)]),
     'simq_workspace_bytes': (c_int64, [c_void_p, c_int]),
+    'simq_workspace_bytes_forward': (c_int64, [c_void_p, c_int]),
     'simq_workspace_tensor': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     'simq_workspace_tensor_ex': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
     'simq_wcache_bytes': (c_int64, [c_void_p]),
@@ -179,12 +180,20 @@ class Lib:
     build_flags = _c.simq_build_flags()          # 0: the product; 1: the ablation build (tools only)
     path = LIB_PATH
 
+
     @staticmethod
     def call(name, *args):
         check(getattr(_c, name)(*args), name)
 
 
 lib = Lib()
+
+if Lib.build_flags != 0:
+    # the ablation build's KERNEL SELECTION follows SIMQ_* environment switches: fine for tools/, never silently for a training run
+    import warnings
+    warnings.warn('simq: SIMQ_LIBRARY selected the ablation build %s (simq_build_flags = %d): kernel selection follows SIMQ_* environment '
+                  'variables; bench.py and the parity tests refuse it -- unset SIMQ_LIBRARY for anything but tools/' % (LIB_PATH, Lib.build_flags),
+                  RuntimeWarning, stacklevel=2)
 
 
 # in-process default overrides for every Plan created afterwards (tools/ and diagnostics set entries here; never read from the
@@ -229,8 +238,9 @@ class Plan:
             check(_c.simq_bn_layer_info(h, i, buf, 128, ctypes.byref(off), ctypes.byref(ch)), 'simq_bn_layer_info')
             self.bn_layers.append((buf.value.decode(), off.value, ch.value))
 
-    def workspace_bytes(self, batch):
-        n = _c.simq_workspace_bytes(self.handle, int(batch))
+    def workspace_bytes(self, batch, forward_only=False):
+        """Bytes of a workspace for `batch` samples; forward_only: one that never serves a backward pass (no weight-gradient slabs)."""
+        n = (_c.simq_workspace_bytes_forward if forward_only else _c.simq_workspace_bytes)(self.handle, int(batch))
         if n < 0:
             raise SimqError('simq_workspace_bytes(%d) failed' % batch)
         return n

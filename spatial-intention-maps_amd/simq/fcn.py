@@ -218,7 +218,8 @@ class FCN(torch.nn.Module):
 
     # ------------------------------------------------------------------ raw kernels over flat buffers
     def _workspace(self, slot, batch):
-        need = self.plan.workspace_bytes(batch)
+        # 'train' is the only slot a backward pass reads; every other slot (no-grad / eval forwards) does without the weight-gradient slabs
+        need = self.plan.workspace_bytes(batch, forward_only=(slot != 'train'))
         ws = self._ws.get(slot)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device_)

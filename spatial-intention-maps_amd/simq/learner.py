@@ -545,6 +545,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else None
     a = TrainArgs()
+    a.struct_bytes = ctypes.sizeof(TrainArgs)
     a.plan = policy_net.plan.handle
     a.batch, a.num_nonfinal, a.global_batch = B, Nn_real, gB
     a.comm = comm.handle if comm is not None else None
@@ -613,10 +614,15 @@ def train_step_dataparallel(policy_net, target_net, global_batch, discount_facto
     dev = policy_net.device_
     g = assemble_batch(global_batch, dev)
     gB = g.state.shape[0]
+    # every rank holds the same minibatch, so every rank reaches the same verdict BEFORE any collective: torch.chunk (DataParallel's
+    # scatter) hands out ceil(gB / world) rows per replica, and with gB <= chunk * (world - 1) the last replicas get none -- DataParallel
+    # would simply use fewer devices; one process per device cannot drop out of the all-reduces, so this is an error on ALL ranks
+    chunk = -(-gB // world)
+    if chunk * (world - 1) >= gB:
+        raise SimqError('train_step_dataparallel: a %d-transition minibatch in chunks of %d leaves rank(s) from %d on (of %d) without rows'
+                        % (gB, chunk, -(-gB // chunk), world))
     lo, hi = sdist.shard_bounds(gB, world, rank)
     B = hi - lo
-    if B < 1:
-        raise SimqError('train_step_dataparallel: rank %d of %d has no rows of a %d-transition minibatch' % (rank, world, gB))
     st = stream_ptr(dev)
     n = policy_net.num_output_channels * W * W
     st_opt = opt_state if opt_state is not None else _opt_state(policy_net, None)
@@ -635,7 +641,7 @@ def train_step_dataparallel(policy_net, target_net, global_batch, discount_facto
     k1 = sum(1 for p in pos if p < hi)
     nsv = torch.empty(B, dtype=torch.float32, device=dev)
     vals = torch.empty(max(k1 - k0, 1), dtype=torch.float32, device=dev)
-    own_pos = torch.tensor([p - lo for p in pos[k0:k1]] or [0], dtype=torch.int32).to(dev)
+    own_pos, = _upload_packed(dev, [np.asarray([p - lo for p in pos[k0:k1]] or [0], dtype=np.int32)])   # (pinned, asynchronous: no stream stall)
     if k1 > k0:
         q_tgt = target_net._forward_raw(g.next_state[k0:k1], MODE_EVAL)                              # train.py:122
         lib.call('simq_q_gather', ptr(q_tgt), k1 - k0, n, ptr(best[k0:k1].contiguous()), ptr(vals), st)

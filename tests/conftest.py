@@ -12,6 +12,12 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: minutes of spawned environment processes around the hot path (the collector / trainer loop on '
+                                       'synthetic environments); out of the default run, SIMQ_RUN_SLOW=1 or --runslow includes them')
+
+
+def pytest_addoption(parser):
+    parser.addoption('--runslow', action='store_true', default=False, help='also run the tests marked slow')
 
 
 def pytest_sessionstart(session):
@@ -43,8 +49,16 @@ def _product_library_only():
 
 def pytest_collection_modifyitems(config, items):
     """GPU tests must FAIL (not skip) on a GPU box whose HIP library is missing;
-    on a box without any GPU they are deselected by -m "not gpu"."""
-    return
+    on a box without any GPU they are deselected by -m "not gpu".  Tests marked slow (the out-of-scope Trainer-loop re-creation around
+    the collector hand-off) are deselected unless asked for."""
+    if config.getoption('--runslow') or os.environ.get('SIMQ_RUN_SLOW') == '1':
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker('slow') else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope='session')

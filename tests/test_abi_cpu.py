@@ -70,6 +70,8 @@ def test_argument_errors_are_reported_not_thrown(L):
     args = L.TrainArgs()
     args.plan = plan.handle
     args.batch, args.num_nonfinal, args.global_batch = 4, 4, 4
+    assert L.lib.c.simq_train_step(ctypes.byref(args)) != 0 and 'struct_bytes' in L.last_error()      # a struct of another version is refused
+    args.struct_bytes = ctypes.sizeof(L.TrainArgs)
     assert L.lib.c.simq_train_step(ctypes.byref(args)) != 0 and 'NULL buffer' in L.last_error()
     assert L.lib.c.simq_bce_with_logits(None, None, 10, None, None, None) != 0 and 'bad argument' in L.last_error()
     assert L.lib.c.simq_split_last_channel(None, None, None, 10, 1, None) != 0

@@ -148,3 +148,14 @@ def test_dataparallel_literal_scatter_of_the_compacted_next_states(tmp_path, gol
     for r in range(world):
         got = np.load(tmp_path / ('rank%d.npz' % r))
         assert np.array_equal(got['best'], g['best']), (r, got['best'], g['best'])
+
+
+def test_mgpu_selftest_reports_instead_of_crashing_without_two_gpus():
+    """tools/mgpu_selftest.py on a box without two GPUs: stage 1 says so in its table and the tool exits non-zero -- no traceback."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'mgpu_selftest.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 1, r.stdout
+    assert '1 environment' in r.stdout and 'needs at least two visible GPUs' in r.stdout and 'Traceback' not in r.stdout, r.stdout

@@ -259,7 +259,7 @@ def test_deterministic_plans_repeat_bit_for_bit(precision, batch):
     """simq_plan_options.deterministic = 1: two TD steps from identical state give bit-identical Q-maps, TD targets, loss sums, BatchNorm
     buffers, gradients and updated parameters -- the pixel-split weight-gradient kernels leave per-split slabs summed in split order instead of
     fp32 atomics, the one-hot head backward walks the transitions in order.  (Default plans repeat everything but those weight gradients:
-    tools/determinism_probe.py.)  The deterministic gradient is the default plan's gradient to summation-order round-off."""
+    tests/diag/diag_determinism.py.)  The deterministic gradient is the default plan's gradient to summation-order round-off."""
     a = _train_once({'deterministic': 1}, precision, batch)
     b = _train_once({'deterministic': 1}, precision, batch)
     assert a['options']['deterministic'] == 1

@@ -274,6 +274,7 @@ def test_reference_style_main_loop_on_synthetic_env(simq_mod, tmp_path, intentio
     assert os.path.basename(checkpoint3) == 'checkpoint_00000055.pth.tar' and not os.path.exists(checkpoint_path)
 
 
+@pytest.mark.slow
 def test_multiprocess_collector_round_robin_and_batched(simq_mod):
     """train_multiprocess.py:147-275 on the drop-ins: environments step in spawned worker processes (CPU only), the learner
     process serves them.  (1) Collector.step is the reference's round-robin and, for the same seeds, produces exactly the
@@ -338,6 +339,7 @@ def test_multiprocess_collector_round_robin_and_batched(simq_mod):
         assert np.isfinite(info['loss']) and np.isfinite(info['td_error'])
 
 
+@pytest.mark.slow
 def test_multiprocess_trainer_loop_on_synthetic_envs(simq_mod, tmp_path):
     """train_multiprocess.py:main on the drop-ins (tools/train_synthetic.py::run_multiprocess): 3 spawned environment processes,
     batched service, HBM rings, training, target sync, checkpoints -- and a resumed second run continues from the files."""

@@ -212,3 +212,34 @@ def test_data_parallel_emulation_golden(name, golden_dir):
     assert (num / den) ** 0.5 <= max(10 * float(g['ref_fp32_grad_relerr']), 5e-3)
     assert int(g['all_terminal_shards']) == (3 if name.endswith('w8') else 0)
     assert float(g['shard_vs_single_replica_relerr']) > 0.5      # per-replica BN statistics are NOT SyncBN
+
+
+def test_bf16_points_model_is_the_fp64_oracle_when_its_points_are_off():
+    """oracle/bf16_points.py (the rounded-operand model the GPU bf16 tests compare against): with every rounding point switched off it IS
+    oracle.learner.train_step / oracle.fcn.fcn_forward in fp64 -- loss, TD targets, gradient, BatchNorm buffers at 1e-12 -- and with the points
+    on it differs (the roundings are real) while staying inside the reference's own bf16-autocast calibration of these small batches
+    (fixture G8: train-mode Q-maps 4.6-8.7e-2).  The committed fixtures tests/golden/bf16pts_*.npz carry the model's output."""
+    import numpy as np
+    from oracle import bf16_points as bp
+    cin, cout, B, ws, ds = 4, 2, 3, 31, 41
+    cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, ds), fcn.state_spec(cin, cout)
+    gk = learner.grad_keys(spec)
+
+    def run(fn, **kw):
+        st, tg = cases.oracle_state(cin, cout, ws, torch.float64), cases.oracle_state(cin, cout, ws + 1000, torch.float64)
+        ex = {}
+        info = fn(cfg, st, tg, spec, [None] * len(gk), batch, cases.GAMMA, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, extras=ex, **kw)
+        return info, ex, st
+    i0, e0, s0 = run(learner.train_step, dtype=torch.float64)
+    i1, e1, s1 = run(bp.train_step, points=False)
+    i2, e2, s2 = run(bp.train_step, points=True)
+    cat = lambda e: torch.cat([g.reshape(-1) for g in e['grads'].values()])
+    assert abs(i1['loss'] - i0['loss']) <= 1e-12 * abs(i0['loss']) and abs(i1['td_error'] - i0['td_error']) <= 1e-12 * abs(i0['td_error'])
+    assert float((cat(e1) - cat(e0)).norm() / cat(e0).norm()) < 1e-10
+    assert float((e1['output'] - e0['output']).abs().max() / e0['output'].abs().max()) < 1e-12
+    assert np.abs(cases.bn_buffer_vector(s1) - cases.bn_buffer_vector(s0)).max() < 1e-12
+    dq = float((e2['output'] - e0['output']).abs().max() / e0['output'].abs().max())
+    assert 1e-4 < dq < 0.2, dq
+    for k in s2:
+        if k.endswith('num_batches_tracked'):
+            assert int(s2[k]) == int(s0[k])
