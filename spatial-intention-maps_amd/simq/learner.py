@@ -574,7 +574,6 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
         if loss_host is None:
             loss_host = policy_net._loss_host = torch.empty(4, dtype=torch.float32).pin_memory()
         a.loss_host = loss_host.data_ptr()
-    import ctypes
     lib.call('simq_train_step', ctypes.byref(a))
     if side is not None:
         q_tgt.record_stream(side)
