@@ -231,6 +231,8 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, hipSt
 // ---- head conv3 (32 -> Cout<=4, NHWC in, NCHW out) (head.hip) ----------------------------------------
 int launch_head_conv3_fwd(const float* x, const float* w, const float* bias, float* q, int B, int HW, int Cin,
                           int Cout, hipStream_t stream);
+// z (NCHW 48x48, no bias) = conv3(relu(bilinear x2 of z2)) in one pass, z2 = [B][24][24][32] (folded eval head, head.hip)
+int launch_head_up_relu_conv3(const float* z2, const float* w, float* z, int B, int Cout, hipStream_t stream);
 // q (NCHW 96x96) = bilinear x2 of z (NCHW 48x48) + bias: the commuted last layer (head.hip)
 int launch_head_upsample_q(const float* z, const float* bias, float* q, int B, int Cout, hipStream_t stream);
 int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* action, const float* q_sa, const float* y,

@@ -108,6 +108,44 @@ __device__ __forceinline__ void lerp2x(int o, int in_size, float scale, int& i0,
     l0 = 1.f - l1;
 }
 
+// Eval-mode head tail in one pass (folded BatchNorm plans: the target net, policy.step): z2 is conv2's output at 24x24 with the folded
+// BatchNorm-2 affine map already applied; networks.py:21-26 then is  upsample x2 -> ReLU -> conv3 (-> upsample x2 + bias, head_upsample_q).
+// The 48x48x32 activation between the upsample and conv3 (37.7 MB at B = 128: one write, one read) is never stored: 8 lanes share an
+// output pixel (one float4 of the 32 channels each), interpolate, rectify and reduce.  Same expressions as upsample2x_fwd_kernel /
+// head_conv3_fwd_kernel, so the result is bit-identical to the two launches it replaces.
+__global__ void __launch_bounds__(256) head_up_relu_conv3_kernel(const float* __restrict__ z2, const float* __restrict__ w, float* __restrict__ z,
+                                                                  int B, int Cout) {
+    constexpr int CIN = 32, L = CIN / 4, W1 = 24, W2 = 48;
+    const int sub = threadIdx.x % L;
+    float4 wv[MAX_COUT];
+    for (int co = 0; co < MAX_COUT; ++co)
+        wv[co] = co < Cout ? *reinterpret_cast<const float4*>(w + co * CIN + sub * 4) : make_float4(0, 0, 0, 0);
+    const float sc = (float)(W1 - 1) / (float)(W2 - 1);
+    const unsigned total = (unsigned)B * W2 * W2, ppb = 256 / L;
+    for (unsigned pix = blockIdx.x * ppb + threadIdx.x / L; pix < total; pix += gridDim.x * ppb) {
+        const unsigned b = pix / (W2 * W2), p = pix - b * (W2 * W2);
+        const int oy = (int)(p / W2), ox = (int)(p - (unsigned)oy * W2);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        lerp2x(oy, W1, sc, y0, y1, ly0, ly1);
+        lerp2x(ox, W1, sc, x0, x1, lx0, lx1);
+        const float* base = z2 + (size_t)b * W1 * W1 * CIN + sub * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + (y0 * W1 + x0) * CIN), v01 = *reinterpret_cast<const float4*>(base + (y0 * W1 + x1) * CIN);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + (y1 * W1 + x0) * CIN), v11 = *reinterpret_cast<const float4*>(base + (y1 * W1 + x1) * CIN);
+        float4 v;
+        v.x = fmaxf(ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x), 0.f);
+        v.y = fmaxf(ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y), 0.f);
+        v.z = fmaxf(ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z), 0.f);
+        v.w = fmaxf(ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w), 0.f);
+        for (int co = 0; co < Cout; ++co) {
+            float s = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
+#pragma unroll
+            for (int o = L / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            if (sub == 0) z[((size_t)b * Cout + co) * (W2 * W2) + p] = s;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(32) head_onehot_bwd_kernel(const float* __restrict__ ah2, const float* __restrict__ w3,
                                                              const int64_t* __restrict__ action, const float* __restrict__ q_sa,
                                                              const float* __restrict__ y, float grad_scale, float* ds1, float* dw3,
@@ -212,6 +250,16 @@ int launch_head_onehot_bwd(const float* ah2, const float* w3, const int64_t* act
     SIMQ_CHECK_HIP(hipMemsetAsync(ds1, 0, sizeof(float) * (size_t)B * 48 * 48 * 32, stream));
     hipLaunchKernelGGL(head_onehot_bwd_kernel, dim3(serial ? 1 : B), dim3(32), 0, stream, ah2, w3, action, q_sa, y, grad_scale, ds1, dw3, db3, Cout,
                        ypre, ypre_bf16, mean, invstd, red, B);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_head_up_relu_conv3(const float* z2, const float* w, float* z, int B, int Cout, hipStream_t stream) {
+    SIMQ_REQUIRE(Cout >= 1 && Cout <= MAX_COUT, "head_up_relu_conv3: Cout=%d unsupported", Cout);
+    SIMQ_REQUIRE((size_t)B * 2304 < 2147483648ull / 32, "head_up_relu_conv3: too many pixels for 32-bit indexing");
+    size_t blocks = ((size_t)B * 2304 + 31) / 32;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(head_up_relu_conv3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z2, w, z, B, Cout);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }

@@ -523,7 +523,8 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         }
     }
     if (folded) {
-        RC(launch_upsample2x_fwd(z2, c.f(L.ah2), B, 24, 24, 32, c.stream, Planes(), nullptr, 1));          // ... the ReLU does not
+        // ... the ReLU does not: upsample -> ReLU -> conv3 (no bias) in one pass, the 48x48x32 activation is never stored
+        RC(launch_head_up_relu_conv3(z2, c.params + p->h3.w_off, c.f(L.up2), B, p->cout, c.stream));
     } else {
         double* rep = reinterpret_cast<double*>(c.ws + L.red) + p->hb2_rep_off;
         RC(launch_upsample2x_fwd(z2, c.f(L.yh2), B, 24, 24, 32, c.stream, Planes(), mode != SIMQ_MODE_EVAL ? rep : nullptr, 0, kStatReplicas));
@@ -536,8 +537,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         RC(launch_head_bn_relu_conv3(c.f(L.yh2), bnref(c, p->hb2, mode, rows2), c.params + p->h3.w_off,
                                      mode == SIMQ_MODE_TRAIN ? c.f(L.ah2) : nullptr, c.f(L.up2), B, 2304, p->cout, c.stream));
     }
-    // folded forwards: z = conv3(ah2) without bias at 48x48; everywhere: q = upsample(z) + bias
-    if (folded) RC(launch_head_conv3_fwd(c.f(L.ah2), c.params + p->h3.w_off, nullptr, c.f(L.up2), B, 2304, 32, p->cout, c.stream));
+    // everywhere: q = upsample(z) + bias
     RC(launch_head_upsample_q(c.f(L.up2), c.params + p->h3.b_off, d_q, B, p->cout, c.stream));
     return 0;
 }

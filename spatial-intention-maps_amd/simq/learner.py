@@ -16,6 +16,7 @@ Additions for the MI355X path:
   train_step(...)          the fused step over flat buffers (no torch autograd), used by train()
 All arithmetic goes through libsimq (HIP); there is no torch/CPU fallback.
 """
+import ctypes
 import os
 import random
 from collections import namedtuple
