@@ -32,29 +32,39 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int HW = 24, PW = 26;                          // feature map / halo patch width
-constexpr int BM = HW * HW, BN = 128, NW = 8, WM = 4, WN = 2;
-constexpr int WTM = BM / WM, WTN = BN / WN;              // 144 x 64
-constexpr int TM = WTM / 16, TN = WTN / 16;              // 9 x 4 MFMA tiles per wave
+constexpr int HW = 24;                                   // feature map width (halo patch: 26 columns in 32-pixel rows)
+constexpr int BN = 128, NW = 8;
 constexpr int BK = 32;                                   // K-tile = (32 channels, one tap) = one MFMA k-step
 constexpr int TAPS = 9;
-
 constexpr int PPITCH = 32;                               // patch rows are stored 32 pixels apart (26 used): a row = two 1-KB DMA pieces
 constexpr int PROW = PPITCH * 64;                        // 2 048 B per patch row: [pixel][4 slots of 16 B = 32 channels]
-constexpr int A_BYTES = PW * PROW;                       // 53 248 B per patch buffer
-constexpr int PPIECES = 2 * PW;                          // 52 DMA pieces (16 pixels x 64 B) per 32-channel chunk
-constexpr int XSLOTS = (PPIECES + NW - 1) / NW;          // patch pieces per wave and channel chunk (7: pieces q = slot * 8 + wave < 52)
 constexpr int B_STAGES = 4;
 constexpr int B_BYTES = BN * 64;                         // 8 192 B per weight tile: one 1-KB piece per wave
-constexpr int B_BASE = 2 * A_BYTES;
-constexpr int OFF_DUMMY = B_BASE + B_STAGES * B_BYTES;   // 1 KB the zero-fill DMAs of empty slots land in
-constexpr int SMEM_LOOP = OFF_DUMMY + 1024;              // 140 288 B
-constexpr int SMEM_EPI = staged_epilogue_smem<BN, TN, WM, NW, 3>();
-constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
-
 static_assert(BN / 16 == NW, "one weight piece per wave and K-tile");
-static_assert(XSLOTS <= TAPS - 2, "the next chunk's patch is issued during taps 0 .. XSLOTS - 1: the last piece two K-tiles before the chunk ends");
-static_assert(SMEM <= 160 * 1024, "LDS budget");
+
+// ROWS = image rows per block: 24 (the whole map, 576 pixels: 4 x 2 waves of 144 x 64) or 12 (half a map, 288 pixels: 2 x 4 waves of
+// 144 x 32) -- the half-map form doubles the block count where whole maps x Cout / 128 do not fill the 256 CUs (round 4: the
+// 128-channel layers at B = 128, the 256-channel layers at B = 64), at 11 instead of 13 fragment reads per 18 instead of 36 MFMAs.
+template <int ROWS>
+struct ImgCfg {
+    static_assert(ROWS == 24 || ROWS == 12, "whole or half feature maps");
+    static constexpr int BM = ROWS * HW;
+    static constexpr int WM = ROWS == 24 ? 4 : 2, WN = NW / WM;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;       // 144 x 64 | 144 x 32
+    static constexpr int TM = WTM / 16, TN = WTN / 16;       // 9 x 4 | 9 x 2 MFMA tiles per wave
+    static constexpr int PR = ROWS + 2;                      // patch rows (one halo row above and below)
+    static constexpr int A_BYTES = PR * PROW;                // 53 248 | 28 672 B per patch buffer
+    static constexpr int PPIECES = 2 * PR;                   // 52 | 28 DMA pieces (16 pixels x 64 B) per 32-channel chunk
+    static constexpr int XSLOTS = (PPIECES + NW - 1) / NW;   // patch pieces per wave and channel chunk (7 | 4: pieces q = slot * 8 + wave < PPIECES)
+    static constexpr int B_BASE = 2 * A_BYTES;
+    static constexpr int OFF_DUMMY = B_BASE + B_STAGES * B_BYTES;   // 1 KB the zero-fill DMAs of empty slots land in
+    static constexpr int SMEM_LOOP = OFF_DUMMY + 1024;       // 140 288 | 91 136 B
+    static constexpr int SMEM_EPI = staged_epilogue_smem<BN, TN, WM, NW, 3>();
+    static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+    static_assert(WTM == 144, "nine 16-pixel tiles per wave");
+    static_assert(XSLOTS <= TAPS - 2, "the next chunk's patch is issued during taps 0 .. XSLOTS - 1: the last piece two K-tiles before the chunk ends");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -86,8 +96,11 @@ __device__ __forceinline__ bf16x8 lds_read16(int addr) {
 
 // DBG (timing ablations, libsimq_ablate.so only; results are wrong by construction): 1 no DMA, 2 no barriers, 8 no fragment reads,
 // 16 no MFMAs, 32 epilogue only, 64 DMA issued with every lane out of range, 128 no s_setprio, 256 / 512 no patch / weight pieces
-template <int DBG = 0>
+template <int ROWS, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmBfArgs p) {
+    using C = ImgCfg<ROWS>;
+    constexpr int BM = C::BM, WM = C::WM, WN = C::WN, WTM = C::WTM, WTN = C::WTN, TM = C::TM, TN = C::TN, A_BYTES = C::A_BYTES,
+                  PPIECES = C::PPIECES, XSLOTS = C::XSLOTS, B_BASE = C::B_BASE, OFF_DUMMY = C::OFF_DUMMY, SMEM = C::SMEM;
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,8 +108,9 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmB
     const int group = wave >> 2;                            // waves w and w + 4 share a SIMD: group 1 runs one barrier behind
     int tile = blockIdx.x;
     if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
-    const int img = tile / p.tilesN, tile_n = tile % p.tilesN;
-    const int m0 = img * BM, n0 = tile_n * BN;
+    const int rb = tile / p.tilesN, tile_n = tile % p.tilesN;              // row block = (image, part of the image)
+    const int img = rb / (HW / ROWS), y0 = (rb % (HW / ROWS)) * ROWS;      // first image row of this block
+    const int m0 = rb * BM, n0 = tile_n * BN;
     const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);     // LDS byte address of smem[0]
 
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x[0]), 0, p.x_bytes, 0x00020000);
@@ -116,10 +130,11 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmB
     for (int i = 0; i < XSLOTS; ++i) {
         const int q = i * NW + wave;
         const int py = q >> 1, px = (q & 1) * 16 + (lane >> 2);
+        const int iy = y0 + py - 1;                               // image row of patch row py
         const int chunk16 = (lane & 3) ^ (3 * ((px >> 2) & 1));
-        const bool ok = q < PPIECES && py >= 1 && py <= HW && px >= 1 && px <= HW;
+        const bool ok = q < PPIECES && iy >= 0 && iy < HW && px >= 1 && px <= HW;
         // (invalid pixels: 2 GiB, beyond any tensor this kernel accepts -- adding the chunk offsets below keeps them out of range)
-        abase[i] = ok ? (unsigned)((((img * HW + py - 1) * HW + px - 1) * p.Cin) * 2 + chunk16 * 16) : 0x80000000u;
+        abase[i] = ok ? (unsigned)((((img * HW + iy) * HW + px - 1) * p.Cin) * 2 + chunk16 * 16) : 0x80000000u;
     }
     const int nchunks = p.Cin / BK;
     auto issue_patch = [&](int slot, int chunk, int abuf) {     // slot: compile-time after unrolling; chunk / abuf: block-uniform
@@ -235,8 +250,9 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmB
 }
 
 template <int DBG>
-void launch(const IgemmBfArgs& p, unsigned blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(igemm_bf16_img_kernel<DBG>, dim3(blocks), dim3(NW * 64), 0, stream, p);
+void launch(const IgemmBfArgs& p, unsigned blocks, int rows, hipStream_t stream) {
+    if (rows == 12) hipLaunchKernelGGL((igemm_bf16_img_kernel<12, DBG>), dim3(blocks), dim3(NW * 64), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_bf16_img_kernel<24, DBG>), dim3(blocks), dim3(NW * 64), 0, stream, p);
 }
 
 }  // namespace
@@ -244,7 +260,7 @@ void launch(const IgemmBfArgs& p, unsigned blocks, hipStream_t stream) {
 // returns 1 when the launch was taken, 0 when the shape is not covered, < 0 on error
 int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.Hin != HW || a.Win != HW || a.Hout != HW || a.Wout != HW) return 0;
-    if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.M % BM != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
+    if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.M % (HW * HW) != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_IMG", 1);   // 0 = off
     if (mode == 0) return 0;
 #ifdef SIMQ_ABLATIONS      // SIMQ_BF16_IMG=2: the four-wave form (conv_igemm_bf16_img4.hip; measured slower) exists in libsimq_ablate.so only
@@ -252,11 +268,22 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
 #endif
     int fbm = 0, fbn = 0;
     const bool forced = tune_forced_tile(&fbm, &fbn);
-    if (forced && !(fbm == BM && fbn == BN)) return 0;
-    const long blocks = (long)(a.M / BM) * (a.Cout / BN);
-    const long rounds = (blocks + 255) / 256;
-    // one block per CU: worth it when the tiles fill (nearly) whole rounds of the 256 CUs
-    if (!forced && (blocks < 200 || (double)blocks / (double)(rounds * 256) < 0.85)) return 0;
+    // (forced tiles, tests / tools: "576 x 128" = whole maps; "1288 x 128" = half maps -- 288 x 128 itself names the LDS-DMA kernel's tile)
+    constexpr int kForcedHalf = 1288;
+    if (forced && !((fbm == HW * HW || fbm == kForcedHalf) && fbn == BN)) return 0;
+    // one block per CU: worth it when the tiles fill (nearly) whole rounds of the 256 CUs -- with whole maps, or else with half maps
+    // (twice the blocks, wave tile 144 x 32: more fragment reads per MFMA, so only where the whole-map form leaves CUs idle)
+    static const int half_mode = SIMQ_TUNE_INT("SIMQ_BF16_IMG_HALF", 1);   // 0: whole maps only (ablation build)
+    int rows = 0;
+    for (int r : {24, 12}) {
+        if (r == 12 && !half_mode) break;
+        if (forced && fbm != (r == 24 ? HW * HW : kForcedHalf)) continue;
+        const long blk = (long)(a.M / (r * HW)) * (a.Cout / BN);
+        const long rnd = (blk + 255) / 256;
+        if (forced || (blk >= 200 && (double)blk / (double)(rnd * 256) >= 0.85)) { rows = r; break; }
+    }
+    if (!rows) return 0;
+    const long blocks = (long)(a.M / (rows * HW)) * (a.Cout / BN);
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
     p.xcd_chunk = bf16_xcd_chunk((int)blocks, p.tilesN);
@@ -265,21 +292,21 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
 #ifdef SIMQ_ABLATIONS      // timing ablations (tools/pp_check.py): compiled into libsimq_ablate.so only
     static const int dbg = SIMQ_TUNE_INT("SIMQ_BF16_IMG_DBG", 0);   // timing ablations (tools/pp_check.py)
     switch (dbg) {
-        case 1: launch<1>(p, (unsigned)blocks, stream); break;      // no DMA
-        case 2: launch<2>(p, (unsigned)blocks, stream); break;      // no barriers
-        case 8: launch<8>(p, (unsigned)blocks, stream); break;      // no fragment reads
-        case 16: launch<16>(p, (unsigned)blocks, stream); break;    // no MFMAs
-        case 32: launch<32>(p, (unsigned)blocks, stream); break;    // epilogue only
-        case 64: launch<64>(p, (unsigned)blocks, stream); break;    // DMA issued with every lane out of range
-        case 80: launch<80>(p, (unsigned)blocks, stream); break;    // masked DMA, no MFMA
-        case 17: launch<17>(p, (unsigned)blocks, stream); break;    // no DMA, no MFMA
-        case 128: launch<128>(p, (unsigned)blocks, stream); break;  // no s_setprio
-        case 256: launch<256>(p, (unsigned)blocks, stream); break;  // no patch pieces (vmcnt(0) waits)
-        case 512: launch<512>(p, (unsigned)blocks, stream); break;  // no weight pieces (vmcnt(0) waits)
-        default: launch<0>(p, (unsigned)blocks, stream);
+        case 1: launch<1>(p, (unsigned)blocks, rows, stream); break;      // no DMA
+        case 2: launch<2>(p, (unsigned)blocks, rows, stream); break;      // no barriers
+        case 8: launch<8>(p, (unsigned)blocks, rows, stream); break;      // no fragment reads
+        case 16: launch<16>(p, (unsigned)blocks, rows, stream); break;    // no MFMAs
+        case 32: launch<32>(p, (unsigned)blocks, rows, stream); break;    // epilogue only
+        case 64: launch<64>(p, (unsigned)blocks, rows, stream); break;    // DMA issued with every lane out of range
+        case 80: launch<80>(p, (unsigned)blocks, rows, stream); break;    // masked DMA, no MFMA
+        case 17: launch<17>(p, (unsigned)blocks, rows, stream); break;    // no DMA, no MFMA
+        case 128: launch<128>(p, (unsigned)blocks, rows, stream); break;  // no s_setprio
+        case 256: launch<256>(p, (unsigned)blocks, rows, stream); break;  // no patch pieces (vmcnt(0) waits)
+        case 512: launch<512>(p, (unsigned)blocks, rows, stream); break;  // no weight pieces (vmcnt(0) waits)
+        default: launch<0>(p, (unsigned)blocks, rows, stream);
     }
 #else
-    launch<0>(p, (unsigned)blocks, stream);
+    launch<0>(p, (unsigned)blocks, rows, stream);
 #endif
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();

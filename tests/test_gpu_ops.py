@@ -314,9 +314,11 @@ def test_conv_bf16_register_staged_wgrad_at_config_batch_sizes(L, B, Cin, Cout):
 
 @pytest.mark.parametrize('B,Cin,Cout,tile', [(8, 256, 256, (576, 128)), (7, 128, 256, (576, 128)), (8, 256, 512, (288, 256)), (7, 64, 256, (288, 256)),
                                              (7, 64, 64, (144, 64)), (128, 256, 256, (576, 128)), (128, 64, 64, (144, 64)),
-                                             (7, 64, 64, (288, 64)), (3, 64, 128, (288, 64)), (128, 64, 64, (288, 64))],
+                                             (7, 64, 64, (288, 64)), (3, 64, 128, (288, 64)), (128, 64, 64, (288, 64)),
+                                             (7, 128, 128, (1288, 128)), (128, 128, 128, (1288, 128)), (5, 256, 256, (1288, 128)), (64, 64, 128, (1288, 128))],
                          ids=['image_tile_l3', 'image_tile_l3a_b7', 'pingpong_l4a', 'pingpong_ragged', 'dma_144x64_layer1',
-                              'image_tile_l3_b128', 'dma_144x64_layer1_b128', 'resident_c64_b7', 'resident_c64_to128_b3', 'resident_c64_b128'])
+                              'image_tile_l3_b128', 'dma_144x64_layer1_b128', 'resident_c64_b7', 'resident_c64_to128_b3', 'resident_c64_b128',
+                              'half_image_tile_l2_b7', 'half_image_tile_l2_b128', 'half_image_tile_l3_b5', 'half_image_tile_64to128_b64'])
 def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile):
     """The two ping-pong bf16 kernels of the 3x3 layers on the 24x24 maps -- conv_igemm_bf16_img.hip (tile "576x128": one image x 128
     channels per block, halo patch staged once per 32-channel chunk, nine taps read shifted fragments) and conv_igemm_bf16_pp.hip
@@ -324,7 +326,9 @@ def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile)
     products, fp32 accumulation in a different K order, so outputs agree to fp32 round-off; bias + batch statistics through the
     staged epilogue.  Odd batches: ragged M for the 288-row tile, an odd image count for the image tile.  "144 x 64": the LDS-DMA tile of
     the 64-channel layer1 (conv_igemm_bf16_dma.hip); "288 x 64": conv_igemm_bf16_c64.hip, which large-batch plans use for the
-    64-input-channel layers instead (half an image x 64 channels per block, patch and all nine taps of the weights resident in LDS)."""
+    64-input-channel layers instead (half an image x 64 channels per block, patch and all nine taps of the weights resident in LDS);
+    "1288 x 128": the HALF-map form of the image-tile kernel (12 image rows x 128 channels per block, 2 x 4 waves of 144 x 32: round 4, the
+    128-channel layers at B = 128 where whole maps give only 128 blocks)."""
     H, k = 24, 3
     g = torch.Generator().manual_seed(11 + Cin + Cout + B)
     x = torch.randn(B, H, H, Cin, generator=g).cuda()
