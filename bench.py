@@ -79,6 +79,7 @@ def parse():
     ap.add_argument('--precision', default=None, choices=['fp32', 'bf16x3', 'bf16'], help="override the workload's arithmetic (tools only)")
     ap.add_argument('--batch', type=int, default=None, help='override: transitions per GPU (and net) per step (tools only)')
     ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
+    ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
     ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
@@ -192,8 +193,8 @@ def cpu_baseline(cin, cout, batch):
 
 
 PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summaries newest first, kernel whose bytes per launch `roofline.traffic` quotes)
-    'fp32': (('r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true>'),
-    'bf16': (('r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
+    'fp32': (('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),   # (name prefix)
+    'bf16': (('r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
 }
 DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
 
@@ -210,8 +211,9 @@ def pmc_traffic(precision):
             t = json.load(open(os.path.join(ROOT, 'profiles', f)))
         except (OSError, ValueError):
             continue
-        if kernel is not None and kernel in t:
-            return round(t[kernel]['bytes_per_launch']), 'profiles/' + f
+        hits = [v for k, v in t.items() if kernel is not None and k.startswith(kernel)]
+        if hits:
+            return round(max(hits, key=lambda v: v['launches'])['bytes_per_launch']), 'profiles/' + f
         cand = [(v['launches'] * v['bytes_per_launch'], v) for k, v in t.items() if k.startswith(DOMINANT_BF16) or k.startswith('igemm_bf16_dma_kernel')]
         if kernel is None and cand:
             return round(max(cand, key=lambda kv: kv[0])[1]['bytes_per_launch']), 'profiles/' + f
@@ -284,6 +286,9 @@ def main():
     from simq import dist as sdist, synth
     from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
     from simq.learner import _opt_state, train_step
+    if args.no_overlap:
+        import simq.learner as _sl
+        _sl.OVERLAP_TARGET_FORWARD = False
     if lib.build_flags != 0:
         sys.exit('bench.py: %s is the ablation build (simq_build_flags = %d); the benchmark runs the product library only' % (lib.path, lib.build_flags))
 

@@ -33,7 +33,9 @@ def pytest_sessionstart(session):
         if not os.path.exists(lib):
             raise pytest.UsageError('libsimq.so is missing and there is no hipcc to build it')
         return
-    r = subprocess.run(['make', '-C', os.path.join(PKG, 'csrc'), '-j16'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # both targets, as __graft_entry__.build(): the product library and the ablation build one child-process test loads (a stale
+    # libsimq_ablate.so lacks whatever entry points were added since it was built)
+    r = subprocess.run(['make', '-C', os.path.join(PKG, 'csrc'), '-j16', 'all', 'ablate'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise pytest.UsageError('libsimq build failed (make rc %d):\n%s' % (r.returncode, r.stdout[-3000:]))
 
