@@ -95,7 +95,11 @@ __device__ __forceinline__ bf16x8 lds_read16(int addr) {
 }
 
 // DBG (timing ablations, libsimq_ablate.so only; results are wrong by construction): 1 no DMA, 2 no barriers, 8 no fragment reads,
-// 16 no MFMAs, 32 epilogue only, 64 DMA issued with every lane out of range, 128 no s_setprio, 256 / 512 no patch / weight pieces
+// 16 no MFMAs, 32 epilogue only, 64 DMA issued with every lane out of range, 128 no s_setprio, 256 / 512 no patch / weight pieces,
+// 1024 the COST MODEL of a BatchNorm + ReLU applied to the landed patch (round 4: what fusing bn1 into this kernel's operand staging would
+// add): in the load segment two taps behind a patch piece's DMA the wave reads its own 1-KB piece back, reads 64 B of per-channel
+// coefficients, unpacks / fma / max / packs its 8 values and writes the piece in place -- the real instruction mix at the real point of the
+// pipeline, on garbage coefficients
 template <int ROWS, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmBfArgs p) {
     using C = ImgCfg<ROWS>;
@@ -213,6 +217,33 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_bf16_img_kernel(const IgemmB
             }
             constexpr bool patch_tap = tap < XSLOTS;
             if constexpr (patch_tap) issue_patch(tap, chunk + 1, abuf ^ 1);
+            if constexpr ((DBG & 1024) != 0 && tap >= 2 && tap - 2 < XSLOTS) {
+                constexpr int slot = tap - 2;                      // its DMA was waited for at the end of the previous load segment
+                const int q = slot * NW + wave;
+                if (q < PPIECES) {                                 // wave-uniform
+                    const int pa = lds0 + (abuf ^ 1) * A_BYTES + q * 1024 + lane * 16;
+                    const int ca = lds0 + OFF_DUMMY + (lane & 15) * 64;            // (stand-in for a 4-KB coefficient table)
+                    bf16x8 v = lds_read16<0>(pa);
+                    const bf16x8 c0 = lds_read16<0>(ca), c1 = lds_read16<16>(ca), c2 = lds_read16<32>(ca), c3 = lds_read16<48>(ca);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const floatx4 s0 = __builtin_bit_cast(floatx4, c0), s1 = __builtin_bit_cast(floatx4, c1);
+                    const floatx4 h0 = __builtin_bit_cast(floatx4, c2), h1 = __builtin_bit_cast(floatx4, c3);
+                    typedef unsigned uintx4r __attribute__((ext_vector_type(4)));
+                    const uintx4r raw = __builtin_bit_cast(uintx4r, v);
+                    const unsigned rw[4] = {raw[0], raw[1], raw[2], raw[3]};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(rw[k] << 16), hi = __uint_as_float(rw[k] & 0xffff0000u);
+                        const float a = fmaxf(__builtin_fmaf(lo, k < 2 ? s0[2 * k] : s1[2 * k - 4], k < 2 ? h0[2 * k] : h1[2 * k - 4]), 0.f);
+                        const float b = fmaxf(__builtin_fmaf(hi, k < 2 ? s0[2 * k + 1] : s1[2 * k - 3], k < 2 ? h0[2 * k + 1] : h1[2 * k - 3]), 0.f);
+                        ow[k] = (unsigned)__builtin_bit_cast(uint16_t, (__bf16)a) | ((unsigned)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+                    }
+                    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                    const uintx4 o = {ow[0], ow[1], ow[2], ow[3]};
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(pa), "v"(o) : "memory");
+                }
+            }
             // counted wait: everything issued two K-tiles ago or earlier has landed = at most the loads of this K-tile and of the one
             // before may be outstanding (one weight piece each, + one patch piece in taps 1 .. XSLOTS)
             constexpr int tp = (tap + TAPS - 1) % TAPS;
@@ -303,6 +334,7 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
         case 128: launch<128>(p, (unsigned)blocks, rows, stream); break;  // no s_setprio
         case 256: launch<256>(p, (unsigned)blocks, rows, stream); break;  // no patch pieces (vmcnt(0) waits)
         case 512: launch<512>(p, (unsigned)blocks, rows, stream); break;  // no weight pieces (vmcnt(0) waits)
+        case 1024: launch<1024>(p, (unsigned)blocks, rows, stream); break;  // cost model of BatchNorm + ReLU on the landed patch
         default: launch<0>(p, (unsigned)blocks, rows, stream);
     }
 #else

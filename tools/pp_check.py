@@ -40,7 +40,7 @@ def run(B, name, tile, reps=5):
 
 if os.environ.get('SIMQ_BF16_PP_DBG') or os.environ.get('SIMQ_BF16_IMG_DBG'):   # timing ablations (results are wrong by construction)
     for name in ('l4', 'l3'):
-        tile = (288, 256) if os.environ.get('SIMQ_BF16_PP_DBG') else (576, 128)
+        tile = (288, 256) if os.environ.get('SIMQ_BF16_PP_DBG') else ((1288, 128) if os.environ.get('SIMQ_PP_CHECK_HALF') else (576, 128))
         _, _, ms, fl = run(128, name, tile)
         print('DBG=%s B=128 %s %dx%d %.1f us' % (os.environ.get('SIMQ_BF16_PP_DBG') or os.environ.get('SIMQ_BF16_IMG_DBG'), name, tile[0], tile[1], ms * 1e3), flush=True)
     sys.exit(0)
