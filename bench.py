@@ -420,8 +420,9 @@ def main():
         sustained = None
         if args.sustained_seconds > 0:
             per = max(1, int(round(0.5 / (dt / steps))))
-            rates, n_done, t_s0 = [], 0, time.perf_counter()
-            while time.perf_counter() - t_s0 < args.sustained_seconds or len(rates) < 2:
+            # (every loop decision is taken on rank-agreed numbers -- the max-reduced window times -- so that all ranks run the same windows)
+            rates, n_done, total = [], 0, 0.0
+            while total < args.sustained_seconds or len(rates) < 2:
                 t_w = time.perf_counter()
                 for i in range(per):
                     dog.arm('%s sustained window %d step %d' % (precision, len(rates) + 1, i + 1))
@@ -432,9 +433,9 @@ def main():
                     dw = sdist.max_over_ranks(dw, dev, pg)
                 rates.append(gB * len(groups) * per / dw)
                 n_done += per
+                total += dw
                 if len(rates) >= 64:
                     break
-            total = time.perf_counter() - t_s0
             sustained = {'transitions_per_s': round(gB * len(groups) * n_done / total, 1), 'seconds': round(total, 2), 'steps': n_done,
                          'window_steps': per, 'windows': len(rates), 'window_min': round(min(rates), 1), 'window_max': round(max(rates), 1),
                          'vs_timed_window': round(gB * len(groups) * n_done / total / value, 4), 'last_loss': info_s['loss']}
