@@ -108,7 +108,7 @@ class Watchdog:
 
     def __init__(self, rank, seconds, enabled, progress=None):
         self.rank, self.seconds, self.enabled, self.progress = rank, seconds, enabled, progress
-        self.label, self.timer = None, None
+        self.label, self.deadline, self.thread = None, None, None
 
     def _fire(self):
         extra = ''
@@ -121,20 +121,26 @@ class Watchdog:
               file=sys.stderr, flush=True)
         os._exit(3)
 
+    def _watch(self):
+        while True:
+            time.sleep(1.0)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                self._fire()
+
     def arm(self, label):
-        self.disarm()
+        """(Re)start the countdown: two attribute stores on the timed path -- ONE watcher thread polls the deadline once a second."""
         if not self.enabled:
             return
-        import threading
         self.label = label
-        self.timer = threading.Timer(self.seconds, self._fire)
-        self.timer.daemon = True
-        self.timer.start()
+        self.deadline = time.monotonic() + self.seconds
+        if self.thread is None:
+            import threading
+            self.thread = threading.Thread(target=self._watch, daemon=True)
+            self.thread.start()
 
     def disarm(self):
-        if self.timer is not None:
-            self.timer.cancel()
-            self.timer = None
+        self.deadline = None
 
 
 def cpu_baseline(cin, cout, batch):
