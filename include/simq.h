@@ -417,6 +417,9 @@ int simq_tune_force_tile(int bm, int bn);
 /* tuning aid: switch the fp32 implicit-GEMM kernel's balanced last round (K-sliced tail tiles + fix-up kernel) on (1) /
  * off (0); default off (it pays only when the forwards run serialised) */
 int simq_tune_tail_split(int on);
+/* tuning aid (A/B): the batched transform-domain GEMMs of the Winograd layers walk whole planes per XCD (1, default) or planes in launch
+ * order with the per-plane tile remap of round 1 (0).  Scheduling only: results are bit-identical. */
+int simq_tune_plane_xcd(int on);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,8 @@ struct IgemmArgs {
     // the next N-tile's first K-steps are in flight while the last MFMAs of the current one run), so a short K = Cin (16-32
     // K-steps) does not pay the pipeline prologue per tile (tools/probes/shortk_probe.py); measured neutral, default 1 (see run())
     int nt_run;
+    // batched launches: 1 = whole planes per XCD (see plane_xcd_map in the kernel)
+    int plane_xcd;
     // XBN: x is the pre-BatchNorm output of the producing convolution; the A operand is relu(x * scale[ci] + shift[ci]) (common.h InBn)
     InBn in;
 };
@@ -91,7 +93,31 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tile = blockIdx.x, piece = -1, kbeg = 0;
-    if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
+    int plane = blockIdx.y;
+    if constexpr (BATCHED) {
+        // Whole planes per XCD (round 4).  Workgroups are dispatched in linear order (x fastest) round-robin over the 8 XCDs, each with its
+        // own L2; with blockIdx.y = plane every XCD touched EVERY plane's weight matrix U[g] (1 MB at 512 x 512) and the L2-miss traffic of a
+        // launch was 232 MB read for ~120 MB of operands.  Here the j-th block an XCD receives works on plane k + 8 (j / tiles) -- a plane's
+        // V and U live in ONE L2 --, and the planes left over when their count is not a multiple of 8 (36 = 4 x 8 + 4) are shared by
+        // 8 / rem XCDs each, a contiguous range of row blocks per XCD.
+        if (p.plane_xcd) {
+            const unsigned gx = gridDim.x, P = gridDim.y;
+            const unsigned lin = blockIdx.y * gx + blockIdx.x, k = lin & 7u, j = lin >> 3;
+            const unsigned full = P >> 3, rem = P & 7u;
+            if (j < full * gx) {
+                plane = (int)(k + 8u * (j / gx));
+                tile = (int)(j % gx);
+            } else {
+                const unsigned share = 8u / rem, jj = j - full * gx;      // jj < gx / share
+                plane = (int)(8u * full + (k % rem));
+                tile = (int)((k / rem) * (gx / share) + jj);
+            }
+        } else if (tile < 8 * p.xcd_chunk) {
+            tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
+        }
+    } else {
+        if (tile < 8 * p.xcd_chunk) tile = (tile & 7) * p.xcd_chunk + (tile >> 3);
+    }
     int nk = VEC ? (p.K / BK) : ((p.K + BK - 1) / BK);
     if constexpr (VEC && !BATCHED) {
         if (tile >= p.full_tiles) {                   // a K-slice of one of the last round's tiles
@@ -161,8 +187,8 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
     }
     // VEC: this thread's rows (pixel base / top-left input coordinate) live in registers; invalid rows can never
     // pass the bounds test
-    const float* px = BATCHED ? p.x + blockIdx.y * p.gx : p.x;
-    const float* pw = BATCHED ? p.w + blockIdx.y * p.gw : p.w;
+    const float* px = BATCHED ? p.x + plane * p.gx : p.x;
+    const float* pw = BATCHED ? p.w + plane * p.gw : p.w;
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px), 0, p.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pw), 0, p.w_bytes, 0x00020000);
     // VEC: per row of this thread, the byte offset of tap (0,0) / channel 0 and the bit mask of the filter taps that fall
@@ -304,7 +330,7 @@ __global__ void __launch_bounds__(256, (BM * BN <= 96 * 64) ? 5 : (BM * BN <= 96
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[SET][i][e], bf[SET][j][e], acc[i][j], 0, 0, 0);
     };
     // batched launches: plain bounds-checked buffer stores of the finished N-tile (rows past M get offset 0xFFFFFFFF and are dropped)
-    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(BATCHED ? p.epi.y + blockIdx.y * p.gy : p.epi.y, 0,
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(BATCHED ? p.epi.y + plane * p.gy : p.epi.y, 0,
                                                                      BATCHED ? (unsigned)p.M * (unsigned)p.Cout * 4u : 0u, 0x00020000);
     const int st_row0 = m0 + wm * (BM / 2) + 4 * fq;             // this lane's first output row; + i * 16 + r
     auto store_plain = [&](int ncol0) {
@@ -464,6 +490,7 @@ float* tail_scratch(hipStream_t stream) {
 }
 
 int g_xcd_remap = -1;    // SIMQ_XCD_REMAP=0: tiles in launch order (A-B runs)
+int g_plane_xcd = 1;     // batched launches: whole planes per XCD (simq_tune_plane_xcd)
 int g_tail_split = -1;   // SIMQ_TAIL_SPLIT=1 switches the balanced last round on
 
 template <int BM, int BN, bool VEC, bool BATCHED = false>
@@ -524,6 +551,12 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     }
     if (g_xcd_remap < 0) g_xcd_remap = SIMQ_TUNE_INT("SIMQ_XCD_REMAP", 1) != 0 ? 1 : 0;
     p.xcd_chunk = (g_xcd_remap && p.tilesN / p.nt_run > 1 && p.full_tiles >= 64) ? p.full_tiles / 8 : 0;
+    p.plane_xcd = 0;
+    if constexpr (BATCHED) {
+        const int rem = batch & 7;
+        const bool rem_ok = rem == 0 || ((rem == 1 || rem == 2 || rem == 4) && p.full_tiles % (8 / rem) == 0);
+        if (g_plane_xcd && g_xcd_remap && batch >= 8 && rem_ok && ((long)p.full_tiles * batch) % 8 == 0) p.plane_xcd = 1;
+    }
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant kernel of the headline workload (the batched transform-domain GEMM of the Winograd
@@ -597,7 +630,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
-    a.gx = a.gw = a.gy = 0; a.xcd_chunk = 0; a.nt_run = 1;
+    a.gx = a.gw = a.gy = 0; a.xcd_chunk = 0; a.nt_run = 1; a.plane_xcd = 0;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     const double xb = 4.0 * g.B * g.Hin * g.Win * g.Cin, wb = 4.0 * g.Cout * a.K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm: tensor exceeds the 4 GiB buffer-addressing limit");
@@ -637,7 +670,7 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
     a.epi = make_epi(y, e);
     a.Hin = M; a.Win = 1; a.Cin = K; a.Hout = M; a.Wout = 1; a.Cout = N; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
     a.M = M; a.K = K; a.tilesN = 0;
-    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N; a.xcd_chunk = 0; a.nt_run = 1;
+    a.gx = (long)M * K; a.gw = (long)N * K; a.gy = (long)M * N; a.xcd_chunk = 0; a.nt_run = 1; a.plane_xcd = 0;
     const double xb = 4.0 * M * K, wb = 4.0 * N * K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "gemm_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
@@ -657,6 +690,8 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
 int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }
 
 void tune_tail_split(int on) { g_tail_split = on ? 1 : 0; }
+
+void tune_plane_xcd(int on) { g_plane_xcd = on ? 1 : 0; }
 
 void tune_force_tile(int bm, int bn) { g_forced_bm = bm > 0 ? bm : 0; g_forced_bn = bn; }
 

@@ -76,4 +76,9 @@ int simq_tune_tail_split(int on) {
     return 0;
 }
 
+int simq_tune_plane_xcd(int on) {
+    simq::tune_plane_xcd(on);
+    return 0;
+}
+
 }  // extern "C"

@@ -119,10 +119,15 @@ def test_b128_bf16_config_runs_and_is_consistent(simq_mod):
     trs = synth.make_transitions(B, cin, cout, 31, terminal_frac=0.1)
     pol_a, info_a = run_step(simq_mod, cin, cout, trs, B, 13, precision='bf16')
     pol_f, info_f = run_step(simq_mod, cin, cout, trs, B, 13, precision='fp32')
-    assert np.isfinite(info_a['loss']) and abs(info_a['loss'] - info_f['loss']) <= 5e-2 * abs(info_f['loss'])
-    assert abs(info_a['td_error'] - info_f['td_error']) <= 5e-2 * abs(info_f['td_error'])
+    # Bars from tests/diag/diag_b128_bf16_loss.py (round 4, six seed pairs, this shape): bf16-vs-fp32 loss / TD error 0.2-5.0 %, Q of the
+    # taken actions 3.6-9.9 % of their range -- and the summation order alone (half-map vs whole-map kernels on the 128-channel layers,
+    # same operands) moves THIS batch's loss from 2.7 % to 5.0 % off fp32: train-mode bf16 storage flips roundings of stored activations
+    # and the batch statistics carry them to every pixel.  The tight bf16 statement is the teacher-forced, elementwise
+    # bit-exact comparison with the rounded-operand oracle (tests/test_gpu_bf16_points.py); this test only says "same model, finite".
+    assert np.isfinite(info_a['loss']) and abs(info_a['loss'] - info_f['loss']) <= 1e-1 * abs(info_f['loss'])
+    assert abs(info_a['td_error'] - info_f['td_error']) <= 1e-1 * abs(info_f['td_error'])
     # bf16 Q-values of the taken actions vs the exact-fp32 path on the same batch
-    assert float((pol_a._last['q_sa'] - pol_f._last['q_sa']).abs().max() / pol_f._last['q_sa'].abs().max()) < 5e-2
+    assert float((pol_a._last['q_sa'] - pol_f._last['q_sa']).abs().max() / pol_f._last['q_sa'].abs().max()) < 2e-1
     sd = pol_a.state_dict()
     assert all(int(sd[k]) == 2 for k in sd if k.endswith('num_batches_tracked'))
     assert all(torch.isfinite(v).all() for k, v in sd.items() if v.dtype.is_floating_point)

@@ -519,6 +519,37 @@ def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
     assert rel(s1, sref) < 1e-5
 
 
+@pytest.mark.parametrize('f4,B,H,Cin,Cout', [(False, 5, 24, 512, 512), (True, 5, 24, 512, 512), (True, 32, 24, 512, 512), (True, 3, 24, 256, 512),
+                                             (True, 7, 12, 256, 256), (False, 29, 24, 256, 256), (True, 1, 24, 128, 128)],
+                         ids=['f2_l4', 'f4_l4', 'f4_l4_b32', 'f4_l4a', 'f4_small_map_odd_tiles', 'f2_l3_b29', 'f4_one_image'])
+def test_winograd_gemm_plane_per_xcd_walk_is_bit_identical(L, f4, B, H, Cin, Cout):
+    """conv_igemm.hip's batched transform-domain GEMM hands whole planes to one XCD (16 planes: two per XCD; 36: four per XCD and the
+    last four shared by two XCDs each, a contiguous half of the row blocks per XCD).  It is a permutation of (plane, tile) over the
+    launch's blocks: every block must be covered exactly once -- the output equals the launch-order walk (simq_tune_plane_xcd 0) BIT FOR
+    BIT, with a NaN-filled destination to catch an uncovered tile.  Shapes whose tile count does not divide (odd row-block counts)
+    fall back to the launch-order walk inside the launcher and are covered by the same equality."""
+    g = torch.Generator().manual_seed(23 + Cin + Cout + B)
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    nb, T = (36, B * (H // 4) ** 2) if f4 else (16, B * (H // 2) ** 2)
+    scratch = torch.empty(nb * Cout * Cin + nb * T * (Cin + Cout) + 64, device='cuda')
+    name = 'simq_conv2d_fwd_winograd4' if f4 else 'simq_conv2d_fwd_winograd'
+    ys = []
+    try:
+        for on in (0, 1):
+            L.lib.call('simq_tune_plane_xcd', on)
+            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+            scratch.fill_(float('nan'))
+            L.lib.call(name, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, None, L.ptr(scratch), L.stream_ptr())
+            torch.cuda.synchronize()
+            ys.append(y)
+    finally:
+        L.lib.call('simq_tune_plane_xcd', 1)
+    assert torch.isfinite(ys[1]).all()
+    assert torch.equal(ys[0], ys[1])
+
+
 @pytest.mark.parametrize('B,H,Cin,Cout', [(5, 24, 512, 512), (3, 24, 256, 512), (4, 24, 128, 256), (6, 12, 256, 256), (29, 24, 256, 256),
                                           (9, 24, 128, 128)],
                          ids=['l4', 'l4a', 'l3a', 'l3_small_map', 'l3_b29', 'l2'])
