@@ -561,7 +561,7 @@ __device__ __forceinline__ void w4_a(const floatx4 (&y)[4], floatx4 (&r)[6]) {  
 
 template <bool DY, bool XBN = false>
 __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int H, int W, int C, int T,
-                                                       const InBn in) {
+                                                       const InBn in, int Kc, int S) {
     static_assert(!(DY && XBN), "the BatchNorm-on-load form is for the activation operand");
     __shared__ float tbuf[4][32][33];
     const int tl = threadIdx.x >> 3, cq = threadIdx.x & 7;
@@ -610,6 +610,9 @@ __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__
         }
     }
     const int wr = threadIdx.x >> 5, wc = threadIdx.x & 31;
+    // K-split of the contraction (S > 1): the tile range is cut into S chunks of Kc tiles (a multiple of this block's 32), chunk s of
+    // transform element g is plane g * S + s, [C][Kc] -- the batched GEMM sees 36 S independent problems of depth Kc
+    const int ks = t0 / Kc, kt = t0 - ks * Kc;
 #pragma unroll
     for (int gp = 0; gp < 9; ++gp) {
         __syncthreads();
@@ -622,7 +625,7 @@ __global__ void __launch_bounds__(256) wino4_tr_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = wr + 8 * i, k = row >> 5, cc = row & 31;
-                out[((size_t)(gp * 4 + k) * C + c0 + cc) * T + t0 + wc] = tbuf[k][cc][wc];
+                out[(((size_t)(gp * 4 + k) * S + ks) * C + c0 + cc) * Kc + kt + wc] = tbuf[k][cc][wc];
             }
         }
     }
@@ -635,7 +638,7 @@ __device__ __forceinline__ void w4_gt(const float (&u)[6], float (&s)[3]) {
     s[1] = (1.f / 6.f) * m + (1.f / 12.f) * n;
     s[2] = -(1.f / 6.f) * p + (1.f / 6.f) * q + u[5];
 }
-__global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin) {
+__global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout, int cin, int S) {
     const int total = cout * cin;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int co = i / cin, ci = i - co * cin;
@@ -644,7 +647,12 @@ __global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__
         for (int c = 0; c < 6; ++c) {
             float u[6], s3[3];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) u[r] = dU[(size_t)(r * 6 + c) * total + i];
+            for (int r = 0; r < 6; ++r) {             // (the K-split's partial planes of an element, in chunk order)
+                const float* pl = dU + (size_t)(r * 6 + c) * S * total + i;
+                float acc = pl[0];
+                for (int ks = 1; ks < S; ++ks) acc += pl[(size_t)ks * total];
+                u[r] = acc;
+            }
             w4_gt(u, s3);
             t[0][c] = s3[0]; t[1][c] = s3[1]; t[2][c] = s3[2];
         }
@@ -811,6 +819,10 @@ bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4) {
     return (long)g.Cin * g.Cout >= ((allow_f4 && winograd_wgrad_f4(g)) ? 128L * 256 : 256L * 256);
 }
 
+int g_wgrad_ksplit = 0;   // 0: by shape; 1 / 2 / 4: forced (simq_tune_wgrad_ksplit, A-B runs)
+
+void tune_wgrad_ksplit(int s) { g_wgrad_ksplit = (s == 1 || s == 2 || s == 4) ? s : 0; }
+
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4,
                                const InBn& in) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
@@ -821,18 +833,39 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
     static const int direct_form = SIMQ_TUNE_INT("SIMQ_WINOGRAD_WGRAD_SPLITK", 0);     // (kernel-form ablation)
     const int T4 = g.B * (g.Hin / 4) * (g.Win / 4);
     if (!direct_form && allow_f4 && winograd_wgrad_f4(g)) {   // F(4x4,3x3): 36 GEMMs over T4 = T / 4 tiles
-        float* Vt4 = scratch;                                   // [36][Cin][T4]
-        float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][Cout][T4]
-        float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][Cout][Cin]
+        // K-split (round 4): 36 GEMMs of (Cout / 64) x (Cin / 64) tiles are 576 blocks at 256 x 256 channels -- 2.25 per CU where the
+        // 64 x 64 tile wants 6-8 -- over a contraction of T4 = 1152+ tiles.  S chunks of the tile range become 36 S planes (the transposing
+        // transforms write them, wino4_dw_kernel adds them in chunk order: deterministic); the partial planes use the part of the
+        // documented scratch the F(4x4,3x3) operands leave free.
+        int S = 1;
+        {
+            const long blocks = 36L * (g.Cout / 64) * (g.Cin / 64);
+            const long room = (long)winograd_scratch_floats(g) - 36L * T4 * (g.Cin + g.Cout);      // floats behind the operands, beside dU4's own 36 planes
+            for (int cand = 4; cand >= 2; cand >>= 1) {
+                if (g_wgrad_ksplit > 0 && cand != g_wgrad_ksplit) continue;
+                const bool fits = T4 % (cand * 32) == 0 && 36L * (cand - 1) * g.Cout * g.Cin <= room;
+                // by shape (tools/wgrad_ksplit_check.py, whole launch sequence, S = 1 | 2 | 4): B = 32 256 -> 256 108 | 104 | 119 us,
+                // 128 -> 256 87 | 83 | 94; B = 128 256 -> 256 370 | 332 | 338, 128 -> 256 268 | 231 | 229, 256 -> 512 555 | 526 | 548;
+                // 512 -> 512 (2304 blocks) loses at every batch size -- shorter chains only pay while the CUs are short of blocks
+                const int kc = T4 / cand;
+                const bool pays = cand == 4 ? (blocks <= 288 && kc >= 1152) : ((blocks <= 576 && kc >= 512) || (blocks <= 1152 && kc >= 1152));
+                if (fits && (g_wgrad_ksplit > 0 || pays)) { S = cand; break; }
+            }
+            if (g_wgrad_ksplit == 1) S = 1;
+        }
+        const int Kc = T4 / S;
+        float* Vt4 = scratch;                                   // [36][S][Cin][Kc]
+        float* dMt4 = scratch + (size_t)36 * T4 * g.Cin;        // [36][S][Cout][Kc]
+        float* dU4 = dMt4 + (size_t)36 * T4 * g.Cout;           // [36][S][Cout][Cin]
         const int tb = (T4 + 31) / 32;
-        if (in.on()) hipLaunchKernelGGL((wino4_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in);
-        else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in);
-        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, InBn());
+        if (in.on()) hipLaunchKernelGGL((wino4_tr_kernel<false, true>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in, Kc, S);
+        else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in, Kc, S);
+        hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, InBn(), Kc, S);
         SIMQ_CHECK_LAUNCH();
-        if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, T4, 36, stream)) return rc;
+        if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, Kc, 36 * S, stream)) return rc;
         int blocks4 = (g.Cout * g.Cin + 255) / 256;
         if (blocks4 > 2048) blocks4 = 2048;
-        hipLaunchKernelGGL(wino4_dw_kernel, dim3(blocks4), dim3(256), 0, stream, dU4, dw, g.Cout, g.Cin);
+        hipLaunchKernelGGL(wino4_dw_kernel, dim3(blocks4), dim3(256), 0, stream, dU4, dw, g.Cout, g.Cin, S);
         SIMQ_CHECK_LAUNCH();
         return 0;
     }

@@ -76,6 +76,11 @@ int simq_tune_tail_split(int on) {
     return 0;
 }
 
+int simq_tune_wgrad_ksplit(int splits) {
+    simq::tune_wgrad_ksplit(splits);
+    return 0;
+}
+
 int simq_tune_plane_xcd(int on) {
     simq::tune_plane_xcd(on);
     return 0;

@@ -602,6 +602,40 @@ def test_conv_winograd_wgrad_matches_direct(L, B, H, Cin, Cout):
     assert rel(d1, ref) < (1e-4 if B % 4 == 0 else 1e-5) and rel(d0, ref) < 1e-5
 
 
+@pytest.mark.parametrize('B,Cin,Cout,splits', [(32, 256, 256, 0), (32, 256, 256, 2), (32, 256, 256, 4), (32, 128, 256, 4), (16, 256, 512, 2),
+                                                (8, 256, 256, 4), (32, 512, 512, 0), (12, 256, 256, 0)],
+                         ids=['l3_auto', 'l3_s2', 'l3_s4', 'l3a_s4', 'l4a_s2', 'l3_b8_s4_no_room_or_short', 'l4_auto_stays_whole', 'b12_tiles_not_divisible'])
+def test_conv_winograd_wgrad_ksplit(L, B, Cin, Cout, splits):
+    """K-split of the F(4x4,3x3) weight-gradient GEMMs (conv_winograd.hip: S chunks of the tile range as 36 S planes, summed in chunk order
+    by wino4_dw_kernel): forced and shape-chosen splits against fp64 and against the unsplit form -- same 1e-4 per-kernel bar as the
+    unsplit F(4x4,3x3) gradient (the split shortens every accumulation chain), NaN-filled destination and scratch, and a second call that
+    must reproduce the first bit for bit (no atomics)."""
+    g = torch.Generator().manual_seed(31 + Cin + Cout + B)
+    H = 24
+    x = torch.randn(B, H, H, Cin, generator=g).cuda()
+    dy = torch.randn(B, H, H, Cout, generator=g).cuda()
+    T = B * (H // 2) ** 2
+    scratch = torch.empty(36 * Cout * Cin + 16 * T * (Cin + Cout), device='cuda')
+    st = L.stream_ptr()
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
+                                      padding=1).permute(0, 2, 3, 1)
+    out = {}
+    try:
+        for s in (1, splits, splits):
+            L.lib.call('simq_tune_wgrad_ksplit', s)
+            d = torch.full((Cout, 3, 3, Cin), float('nan'), device='cuda')
+            scratch.fill_(float('nan'))
+            L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d), B, H, H, Cin, Cout, L.ptr(scratch), st)
+            torch.cuda.synchronize()
+            assert torch.isfinite(d).all()
+            assert rel(d, ref) < 1e-4
+            out.setdefault(s, []).append(d)
+    finally:
+        L.lib.call('simq_tune_wgrad_ksplit', 0)
+    assert torch.equal(out[splits][0], out[splits][1])
+    assert rel(out[splits][0], out[1][0]) < 6e-5               # (two summation orders of a gradient whose own error is 0.6-3e-5)
+
+
 def test_conv_winograd_rejects_unsupported_geometry(L):
     """Odd map sizes / channel counts the transform kernels cannot tile are refused with a message, not mis-computed."""
     x = torch.zeros(1, 23, 23, 64, device='cuda'); w = torch.zeros(64, 3, 3, 64, device='cuda'); y = torch.zeros(1, 23, 23, 64, device='cuda')
