@@ -80,6 +80,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='override: transitions per GPU (and net) per step (tools only)')
     ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
+    ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
@@ -295,6 +296,8 @@ def main():
     from simq.learner import _opt_state, train_step
     if args.plane_xcd is not None:
         lib.call('simq_tune_plane_xcd', args.plane_xcd)
+    if args.wgrad_xcd_group is not None:
+        lib.call('simq_tune_wgrad_xcd_group', args.wgrad_xcd_group)
     if args.no_overlap:
         import simq.learner as _sl
         _sl.OVERLAP_TARGET_FORWARD = False

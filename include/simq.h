@@ -420,6 +420,10 @@ int simq_tune_tail_split(int on);
 /* tuning aid (A/B): the batched transform-domain GEMMs of the Winograd layers walk whole planes per XCD (1, default) or planes in launch
  * order with the per-plane tile remap of round 1 (0).  Scheduling only: results are bit-identical. */
 int simq_tune_plane_xcd(int on);
+/* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
+ * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.
+ * Scheduling only. */
+int simq_tune_wgrad_xcd_group(int on);
 /* tuning aid (A/B): K-split of the transform-domain weight-gradient GEMMs (the wgrad half of loss.backward(), train.py:132, of the
  * 128->256- and 256-channel 3x3 convolutions): 0 = chosen by shape (default), 1 = none, 2 / 4 = forced where the tile count divides.
  * Changes the summation order of those gradients (fixed per setting: deterministic), nothing else. */

@@ -111,6 +111,8 @@ void prof_launch_end(hipStream_t stream);
 void tune_force_tile(int bm, int bn);   // conv_igemm.hip: force one tile of the menu (0 = automatic)
 void tune_tail_split(int on);           // conv_igemm.hip: balanced last round on / off
 void tune_wgrad_ksplit(int s);          // conv_winograd.hip: K-split of the transform-domain weight-gradient GEMMs, 0 = by shape (default), 1 / 2 / 4
+void tune_wgrad_xcd_group(int on);      // conv_wgrad.hip / conv_wgrad_bf16.hip: the tiles of a pixel range on one XCD, on (default) / off
+bool wgrad_xcd_group_enabled();
 void tune_plane_xcd(int on);            // conv_igemm.hip: batched GEMMs, whole planes per XCD on (default) / off
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,

@@ -29,6 +29,7 @@ struct WgradArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesI, tilesJ, rows_per_split;
+    int splits, xcd_group;   // xcd_group: the tiles of a pixel range on one XCD (see the kernel's block decomposition)
     unsigned x_bytes, dy_bytes;
     long gx, gdy, gdw;   // batched launch (blockIdx.y = g): element offsets of the g-th x / dy / dw (conv_winograd.hip)
     float* slab;         // NULL, or [splits][Cout][K] partial tiles (deterministic plans: plain stores, summed in split order afterwards)
@@ -46,10 +47,25 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / WJ, wj = wave % WJ;
-    int id = blockIdx.x;
-    const int tj = id % p.tilesJ; id /= p.tilesJ;
-    const int ti = id % p.tilesI;
-    const int split = id / p.tilesI;
+    // Block -> (pixel range, tile).  The tiles of one pixel range read the same rows of dY and (shifted by their tap) of X; in launch order
+    // (tile fastest) consecutive blocks go to the 8 XCDs round-robin and every L2 fetches those rows for itself.  With xcd_group the j-th
+    // block an XCD receives (b = 8 j + k) is tile j % tiles of pixel range 8 (j / tiles) + k -- the tiles of a range run back to back on one
+    // XCD (conv_wgrad_bf16.hip has the measurement); the grid is rounded up to whole groups of 8 ranges, blocks past the last range leave.
+    int id = blockIdx.x, split;
+    {
+        const int tiles = p.tilesI * p.tilesJ;
+        if (p.xcd_group) {
+            const int k = id & 7, j = id >> 3;
+            split = (j / tiles) * 8 + k;
+            id = (j + k) % tiles;                    // (staggered: the 8 XCDs do not add into the same tile of dw at the same time)
+            if (split >= p.splits) return;
+        } else {
+            split = id / tiles;
+            id -= split * tiles;
+        }
+    }
+    const int tj = id % p.tilesJ;
+    const int ti = id / p.tilesJ;
     const int i0 = ti * TI;
     const int rbeg = split * p.rows_per_split;
     const int rend = min(p.M, rbeg + p.rows_per_split);
@@ -247,6 +263,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     }
 }
 
+int g_wgrad_xcd_group = 1;   // tiles of a pixel range on one XCD: 0 off, 1 the bf16 kernel only (default), 2 fp32 too (simq_tune_wgrad_xcd_group)
+
 template <int TI, int TJ, int WI, int WJ, bool VEC>
 int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     static_assert(256 % (TJ / 4) == 0, "a lane keeps its channel quad across the passes of the x loader");
@@ -281,14 +299,20 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     rps = ((rps + BR - 1) / BR) * BR;
     splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
+    p.splits = splits;
+    // fp32: measured and left OFF by default (2 = forced on, A-B runs): three alternating bench pairs each on two boxes, 3453 -> 3435 and
+    // 3382 -> 3361 tr/s with the grouping, with or without the stagger -- the fp32 launches are short (22-72 us, 18 MB of operands at
+    // B = 32) and are not bound by their L2 misses, unlike the bf16 kernel's at B = 128 (conv_wgrad_bf16.hip: 237 -> 63 MB, + 0.5-1 %)
+    p.xcd_group = (g_wgrad_xcd_group == 2 && batch == 1 && splits >= 8 && tiles > 1) ? 1 : 0;
+    const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
     if constexpr (VEC) {
-        if (p.xscale) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC, true>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+        if (p.xscale) hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC, true>), dim3((unsigned)(tiles * launch_splits), (unsigned)batch), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * launch_splits), (unsigned)batch), dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * splits), (unsigned)batch), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, VEC>), dim3((unsigned)(tiles * launch_splits), (unsigned)batch), dim3(256), 0, stream, p);
     }
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
@@ -305,6 +329,9 @@ __global__ void __launch_bounds__(256) wgrad_slab_sum_kernel(const float* __rest
 }
 
 }  // namespace
+
+void tune_wgrad_xcd_group(int on) { g_wgrad_xcd_group = (on == 2) ? 2 : (on ? 1 : 0); }
+bool wgrad_xcd_group_enabled() { return g_wgrad_xcd_group != 0; }
 
 int launch_wgrad_slab_sum(const float* slab, float* dw, int64_t n, int splits, hipStream_t stream) {
     int blocks = (int)((n + 255) / 256);

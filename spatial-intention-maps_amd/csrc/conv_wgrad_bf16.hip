@@ -30,6 +30,7 @@ struct WgradBfArgs {
     int Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
     int M, K;
     int tilesI, tilesJ, rows_per_split;
+    int splits, xcd_group;   // xcd_group: the tiles of a pixel range on one XCD (see the kernel's block decomposition)
     float* slab;         // NULL, or [splits][Cout][K] partial tiles (deterministic plans, see conv_wgrad.hip)
     unsigned x_bytes, dy_bytes;
 };
@@ -58,10 +59,27 @@ __global__ void __launch_bounds__(256, NP == 1 ? 3 : 2) wgrad_bf16_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    int id = blockIdx.x;
-    const int tj = id % p.tilesJ; id /= p.tilesJ;
-    const int ti = id % p.tilesI;
-    const int split = id / p.tilesI;
+    // Block -> (pixel range, tile).  The tilesI x tilesJ tiles of one pixel range read the SAME rows of dY and (shifted by their tap) of X.
+    // Launch order (tile fastest) deals consecutive blocks to the 8 XCDs round-robin: the nine tap tiles of a 128 -> 128 layer sat on
+    // eight different L2s and the launch fetched 237 MB for 38 MB of operands (PMC, B = 128) at 4 TB/s -- bound by exactly that.  With
+    // xcd_group the j-th block an XCD receives (b = 8 j + k) is tile j % tiles of pixel range 8 (j / tiles) + k: the tiles of a range run
+    // back to back on one XCD and re-read its rows from that L2.  The grid is rounded up to whole groups of 8 ranges; blocks past the last
+    // range leave at once.
+    int id = blockIdx.x, split;
+    {
+        const int tiles = p.tilesI * p.tilesJ;
+        if (p.xcd_group) {
+            const int k = id & 7, j = id >> 3;
+            split = (j / tiles) * 8 + k;
+            id = (j + k) % tiles;                    // (staggered: the 8 XCDs do not add into the same tile of dw at the same time)
+            if (split >= p.splits) return;
+        } else {
+            split = id / tiles;
+            id -= split * tiles;
+        }
+    }
+    const int tj = id % p.tilesJ;
+    const int ti = id / p.tilesJ;
     const int i0 = ti * TI;
     const int rbeg = split * p.rows_per_split;
     const int rend = min(p.M, rbeg + p.rows_per_split);
@@ -265,10 +283,14 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
     rps = ((rps + BRB - 1) / BRB) * BRB;
     splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
+    p.splits = splits;
+    static const int group_env = SIMQ_TUNE_INT("SIMQ_WGRAD_BF16_XCD_GROUP", 1);      // (ablation build: 0 = launch order)
+    p.xcd_group = (group_env && wgrad_xcd_group_enabled() && splits >= 8 && tiles > 1) ? 1 : 0;
+    const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);
-    hipLaunchKernelGGL((wgrad_bf16_kernel<TI, TJ, NP>), dim3((unsigned)(tiles * splits)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<TI, TJ, NP>), dim3((unsigned)(tiles * launch_splits)), dim3(256), 0, stream, p);
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     if (p.slab) return launch_wgrad_slab_sum(p.slab, p.dw, (int64_t)p.Cout * p.K, splits, stream);

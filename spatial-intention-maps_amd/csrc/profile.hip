@@ -81,6 +81,11 @@ int simq_tune_wgrad_ksplit(int splits) {
     return 0;
 }
 
+int simq_tune_wgrad_xcd_group(int on) {
+    simq::tune_wgrad_xcd_group(on);
+    return 0;
+}
+
 int simq_tune_plane_xcd(int on) {
     simq::tune_plane_xcd(on);
     return 0;
