@@ -79,6 +79,7 @@ def parse():
     ap.add_argument('--precision', default=None, choices=['fp32', 'bf16x3', 'bf16'], help="override the workload's arithmetic (tools only)")
     ap.add_argument('--batch', type=int, default=None, help='override: transitions per GPU (and net) per step (tools only)')
     ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
+    ap.add_argument('--plan-option', action='append', default=[], metavar='NAME=INT', help='tools only: a simq_plan_options override for every plan of the run (A/B), e.g. deterministic=1')
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
     ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
@@ -377,8 +378,9 @@ def main():
             # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
             # stay O(1) so that many steps of synthetic training remain finite
             torch.manual_seed(20260928 + gi)
-            policy = simq.FCN(cin, cout, device=dev, precision=precision)
-            target = simq.FCN(cin, cout, device=dev, precision=precision)
+            popt = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.plan_option} or None
+            policy = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
+            target = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
             target.copy_state_from(policy)
             policy.train()
             target.eval()
