@@ -420,6 +420,11 @@ int simq_tune_tail_split(int on);
 /* tuning aid (A/B): the batched transform-domain GEMMs of the Winograd layers walk whole planes per XCD (1, default) or planes in launch
  * order with the per-plane tile remap of round 1 (0).  Scheduling only: results are bit-identical. */
 int simq_tune_plane_xcd(int on);
+/* tuning aid (A/B): inside simq_train_step the weight gradient of every residual-block convolution (the wgrad half of loss.backward(),
+ * train.py:132) runs on the side stream beside the dgrads: 1 (default) = fp32 plans only, until the end of the residual block; 3 = fp32,
+ * beside the dgrad of the same convolution only; 2 = every precision (measured slower for bf16); 0 = behind it on the main stream.
+ * Same kernels on the same operands: results are bit-identical for deterministic kernels. */
+int simq_tune_wgrad_overlap(int on);
 /* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
  * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.
  * Scheduling only. */

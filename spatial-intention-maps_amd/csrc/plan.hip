@@ -152,6 +152,7 @@ struct Layout {
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
     int64_t p_pooled, p_up1, DP[2];
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
+    int64_t wino2;   // a second one for the weight gradients that run beside the dgrads on the side stream (backward only), -1 otherwise
     int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
     int64_t dslab;   // deterministic plans: per-split partial tiles of the pixel-split weight-gradient kernels (64 MB), -1 otherwise
     int64_t fwd_total;   // bytes a workspace needs when only forward passes use it (no weight-gradient slabs)
@@ -199,6 +200,7 @@ Layout make_layout(const simq_plan* p, int B) {
     }
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.fwd_total = off;          // everything a FORWARD pass touches ends here; what follows is scratch of the backward pass only
+    L.wino2 = L.wino >= 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
     L.dslab = p->opt.deterministic ? take(kWgradDetSlabFloats * f) : -1;
     L.total = off;
@@ -248,6 +250,9 @@ struct Ctx {
     char* wc = nullptr;      // weight cache
     WLayout W = WLayout();
     const simq_sync* sync = nullptr;   // cross-rank BatchNorm statistics (simq_forward_sync / simq_backward_sync)
+    // backward inside simq_train_step: the weight gradients run on this stream beside the dgrads of the same layer (fork / join events)
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
     double bn_rows(int64_t rows) const { return sync ? (double)rows / (double)B * (double)sync->global_batch : (double)rows; }
     int sync_reduce(double* buf, int64_t count) const { return sync ? sync->reduce(sync->user, buf, count, stream) : 0; }
@@ -616,10 +621,32 @@ constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that be
 // one-hot form of the upstream gradient (the TD loss): dQ[b][action[b]] = clamp(q_sa[b] - y[b], -1, 1) * grad_scale
 struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
 
+int g_wgrad_overlap = 1;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads inside simq_train_step
+
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
     const int B = c.B;
+    // Weight gradient beside dgrad (round 4).  The two halves of a convolution's backward read the same dy and nothing of each other;
+    // in the transform-domain form each is [HBM-bound transforms | matrix-bound GEMM | HBM-bound transform], so side by side one's
+    // transforms run under the other's GEMM.  cw = this context on the side stream with its own Winograd scratch; fork() after dy is
+    // final, join() before the buffer that holds dy is written again (the next BatchNorm backward of the walk).
+    // fp32 plans only: the bf16 kernels of both halves hold 140-160 KB of LDS per block, two of them cannot share a CU, and side by side
+    // they only take turns (measured: 13 893 -> 13 516 tr/s on configs[2]; fp32 configs[1] 3466 -> 3524 in the pairwise form below)
+    const bool ov = c.wstream != nullptr && (g_wgrad_overlap == 2 || ((g_wgrad_overlap == 1 || g_wgrad_overlap == 3) && !c.mc()));
+    // ... and in fp32 the gradient w.r.t. conv1's output (dy1) is formed IN PLACE over bn1's incoming gradient (an elementwise pass), so that
+    // dy2 stays alive and conv2's weight gradient may run until the end of the block instead of until bn1's backward
+    const bool wide = ov && !c.mc() && g_wgrad_overlap != 3;       // (3: the pairwise form, A-B runs)
+    Ctx cw = c;
+    if (ov) { cw.stream = c.wstream; if (L.wino2 >= 0) cw.L.wino = L.wino2; }
+    auto fork = [&]() -> int {
+        if (ov) { SIMQ_CHECK_HIP(hipEventRecord(c.ev_wfork, c.stream)); SIMQ_CHECK_HIP(hipStreamWaitEvent(c.wstream, c.ev_wfork, 0)); }
+        return 0;
+    };
+    auto join = [&]() -> int {
+        if (ov) { SIMQ_CHECK_HIP(hipEventRecord(c.ev_wjoin, c.wstream)); SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wjoin, 0)); }
+        return 0;
+    };
     if (phase != 2) {
         SIMQ_CHECK_HIP(hipMemsetAsync(c.grads, 0, p->nparams * sizeof(float), c.stream));
         SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
@@ -716,11 +743,12 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
         RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out, -1, gb));
         if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out, -1, gb));
+        RC(fork());
         if (c.lazy1()) {                                     // (a1 was never stored: the weight gradient re-applies bn1 + ReLU to y1)
             Act y1; y1.f = c.f(o.y1);
-            RC(conv_wgrad(c, b.c2, y1, T0, 24, c.inbn_saved(b.b1)));
+            RC(conv_wgrad(cw, b.c2, y1, T0, 24, c.inbn_saved(b.b1)));
         } else {
-            RC(conv_wgrad(c, b.c2, a1, T0, 24));
+            RC(conv_wgrad(cw, b.c2, a1, T0, 24));
         }
         ConvEpilogue f1;   // bn1 of this block consumes the gradient w.r.t. a1
         if (!no_fuse) {
@@ -729,16 +757,21 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1, gb));
-        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), T0, nullptr, rows, !no_fuse, m16_a1, -1, gb, mfy));
-        RC(conv_wgrad(c, b.c1, xin, T0, 24));
+        Act D1 = T0;                                         // dy1: over dy2, or (wide) in place over the gradient bn1 receives
+        if (wide) { D1 = Act(); D1.f = T2; }
+        else RC(join());                                     // (bn1's backward writes dy1 over dy2)
+        RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), D1, nullptr, rows, !no_fuse, m16_a1, -1, gb, mfy));
+        RC(fork());
+        RC(conv_wgrad(cw, b.c1, xin, D1, 24));
         const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {
-            RC(conv_wgrad(c, b.ds, xin, T1, 24));
+            RC(conv_wgrad(cw, b.ds, xin, T1, 24));
             RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24, ConvEpilogue(), gb));
-            RC(conv_dgrad(c, b.c1, T0, G, G, 24, fin, gb));
+            RC(conv_dgrad(c, b.c1, D1, G, G, 24, fin, gb));
         } else {
-            RC(conv_dgrad(c, b.c1, T0, G, T1.f, 24, fin, gb));
+            RC(conv_dgrad(c, b.c1, D1, G, T1.f, 24, fin, gb));
         }
+        RC(join());                                          // (the next block's BatchNorm backwards and dgrad reuse T0 / T1 / T2)
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
     if (phase == 1) return 0;
@@ -1052,6 +1085,20 @@ int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnb
     return 0;
 }
 
+// simq_backward_sync with the stream / events of the weight-gradient overlap (simq_train_step only: its side stream is idle by then)
+static int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                              const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
+                              void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
+                              hipEvent_t ev_wjoin) {
+    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    c.sync = sync;
+    if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; }
+    if (d_dq) return backward_impl(c, d_dq, phase);
+    const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
+    return backward_impl(c, nullptr, phase, &oh);
+}
+
 int simq_backward_sync(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                        const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                        void* d_workspace, int phase, void* stream, const simq_sync* sync) {
@@ -1059,12 +1106,8 @@ int simq_backward_sync(const simq_plan* plan, int batch, const float* d_params, 
     SIMQ_REQUIRE(phase >= 0 && phase <= 2, "backward: bad phase %d", phase);
     SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
     RC(check_sync(sync, batch));
-    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
-    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
-    c.sync = sync;
-    if (d_dq) return backward_impl(c, d_dq, phase);
-    const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
-    return backward_impl(c, nullptr, phase, &oh);
+    return backward_sync_side(plan, batch, d_params, d_wcache, d_dq, d_action, d_q_sa, d_y, grad_scale, d_grads, d_workspace, phase, stream, sync,
+                              nullptr, nullptr, nullptr);
 }
 
 int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
@@ -1156,8 +1199,8 @@ int simq_train_step(const simq_train_args* a) {
     hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
     const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
     // fork / join events, one pair per device and host thread (events belong to the device they were created on)
-    static thread_local hipEvent_t ev_pairs[64][2] = {};
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static thread_local hipEvent_t ev_pairs[64][4] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr;
     if (side) {
         int dev = 0;
         SIMQ_CHECK_HIP(hipGetDevice(&dev));
@@ -1165,8 +1208,10 @@ int simq_train_step(const simq_train_args* a) {
         if (!ev_pairs[dev][0]) {
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][0], hipEventDisableTiming));
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][1], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][2], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][3], hipEventDisableTiming));
         }
-        ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1];
+        ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1]; ev_wfork = ev_pairs[dev][2]; ev_wjoin = ev_pairs[dev][3];
     }
     // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
     simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
@@ -1208,7 +1253,9 @@ int simq_train_step(const simq_train_args* a) {
     if (a->loss_host && !a->comm) RC(loss_copy(a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
-        return simq_backward_sync(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync);
+        if (int rc = check_sync(sync, B)) return rc;
+        return backward_sync_side(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync,
+                                  side, ev_wfork, ev_wjoin);
     };
     if (!a->comm) {
         RC(backward(0));
@@ -1227,6 +1274,11 @@ int simq_train_step(const simq_train_args* a) {
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);
+}
+
+int simq_tune_wgrad_overlap(int on) {
+    g_wgrad_overlap = (on == 2 || on == 3) ? on : (on ? 1 : 0);
+    return 0;
 }
 
 int64_t simq_grad_bucket_split(const simq_plan* plan) { return plan ? plan->blocks[kPhaseSplitBlock].c1.w_off : -1; }
