@@ -82,7 +82,8 @@ def parse():
     ap.add_argument('--plan-option', action='append', default=[], metavar='NAME=INT', help='tools only: a simq_plan_options override for every plan of the run (A/B), e.g. deterministic=1')
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
     ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
-    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3], help='tools only: simq_tune_wgrad_overlap, A/B')
+    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_tune_wgrad_overlap, A/B')
+    ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = timing only)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
@@ -298,6 +299,8 @@ def main():
     from simq.learner import _opt_state, train_step
     if args.plane_xcd is not None:
         lib.call('simq_tune_plane_xcd', args.plane_xcd)
+    if args.fwd_overlap is not None:
+        lib.call('simq_tune_fwd_overlap', args.fwd_overlap)
     if args.wgrad_overlap is not None:
         lib.call('simq_tune_wgrad_overlap', args.wgrad_overlap)
     if args.wgrad_xcd_group is not None:

@@ -422,9 +422,14 @@ int simq_tune_tail_split(int on);
 int simq_tune_plane_xcd(int on);
 /* tuning aid (A/B): inside simq_train_step the weight gradient of every residual-block convolution (the wgrad half of loss.backward(),
  * train.py:132) runs on the side stream beside the dgrads: 1 (default) = fp32 plans only, until the end of the residual block; 3 = fp32,
- * beside the dgrad of the same convolution only; 2 = every precision (measured slower for bf16); 0 = behind it on the main stream.
+ * beside the dgrad of the same convolution only; 2 = every precision (measured slower for bf16); 0 = behind it on the main stream;
+ * 4 = as 1, with a second set of gradient temporaries so that the main stream waits for a block's weight gradients two blocks later.
  * Same kernels on the same operands: results are bit-identical for deterministic kernels. */
 int simq_tune_wgrad_overlap(int on);
+/* tuning aid (A/B, timing): where simq_train_step forks its no-grad forwards (train.py:119-122).  0 (default) = the target-net forward
+ * on the side stream behind the policy's grad-mode forward; 1 = at the start of the step; 2 = TIMING ONLY: all three forwards side by side
+ * (the policy's two train-mode forwards then update the BatchNorm running statistics in no particular order). */
+int simq_tune_fwd_overlap(int on);
 /* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
  * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.
  * Scheduling only. */

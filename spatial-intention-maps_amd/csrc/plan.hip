@@ -153,6 +153,8 @@ struct Layout {
     int64_t p_pooled, p_up1, DP[2];
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
     int64_t wino2;   // a second one for the weight gradients that run beside the dgrads on the side stream (backward only), -1 otherwise
+    int64_t S2[3];   // fp32 plans, backward only: a second set of gradient temporaries, so that a block's weight gradients may still run
+                     // on the side stream while the next block's BatchNorm backwards / dgrads write theirs (-1 otherwise)
     int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
     int64_t dslab;   // deterministic plans: per-split partial tiles of the pixel-split weight-gradient kernels (64 MB), -1 otherwise
     int64_t fwd_total;   // bytes a workspace needs when only forward passes use it (no weight-gradient slabs)
@@ -201,6 +203,7 @@ Layout make_layout(const simq_plan* p, int B) {
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.fwd_total = off;          // everything a FORWARD pass touches ends here; what follows is scratch of the backward pass only
     L.wino2 = L.wino >= 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
+    for (int i = 0; i < 3; ++i) L.S2[i] = p->precision == SIMQ_PREC_FP32 ? take(smax) : -1;
     L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
     L.dslab = p->opt.deterministic ? take(kWgradDetSlabFloats * f) : -1;
     L.total = off;
@@ -253,6 +256,7 @@ struct Ctx {
     // backward inside simq_train_step: the weight gradients run on this stream beside the dgrads of the same layer (fork / join events)
     hipStream_t wstream = nullptr;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
+    hipEvent_t ev_wdone[2] = {nullptr, nullptr};   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
     // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
     double bn_rows(int64_t rows) const { return sync ? (double)rows / (double)B * (double)sync->global_batch : (double)rows; }
     int sync_reduce(double* buf, int64_t count) const { return sync ? sync->reduce(sync->user, buf, count, stream) : 0; }
@@ -621,6 +625,7 @@ constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that be
 // one-hot form of the upstream gradient (the TD loss): dQ[b][action[b]] = clamp(q_sa[b] - y[b], -1, 1) * grad_scale
 struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
 
+int g_fwd_overlap = 0;     // simq_tune_fwd_overlap (A-B / timing runs): where the no-grad forwards of simq_train_step are forked
 int g_wgrad_overlap = 1;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads inside simq_train_step
 
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr) {
@@ -633,10 +638,13 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     // final, join() before the buffer that holds dy is written again (the next BatchNorm backward of the walk).
     // fp32 plans only: the bf16 kernels of both halves hold 140-160 KB of LDS per block, two of them cannot share a CU, and side by side
     // they only take turns (measured: 13 893 -> 13 516 tr/s on configs[2]; fp32 configs[1] 3466 -> 3524 in the pairwise form below)
-    const bool ov = c.wstream != nullptr && (g_wgrad_overlap == 2 || ((g_wgrad_overlap == 1 || g_wgrad_overlap == 3) && !c.mc()));
+    const bool ov = c.wstream != nullptr && (g_wgrad_overlap == 2 || ((g_wgrad_overlap == 1 || g_wgrad_overlap == 3 || g_wgrad_overlap == 4) && !c.mc()));
     // ... and in fp32 the gradient w.r.t. conv1's output (dy1) is formed IN PLACE over bn1's incoming gradient (an elementwise pass), so that
     // dy2 stays alive and conv2's weight gradient may run until the end of the block instead of until bn1's backward
     const bool wide = ov && !c.mc() && g_wgrad_overlap != 3;       // (3: the pairwise form, A-B runs)
+    // ... and (4) with a second set of gradient temporaries the blocks alternate between, the main stream does not wait for a block's weight
+    // gradients at the end of the block but only before the set is written again, two blocks later: the side stream runs up to one block behind
+    const bool piped = wide && g_wgrad_overlap == 4 && L.S2[0] >= 0 && c.ev_wdone[0] && c.ev_wdone[1];
     Ctx cw = c;
     if (ov) { cw.stream = c.wstream; if (L.wino2 >= 0) cw.L.wino = L.wino2; }
     auto fork = [&]() -> int {
@@ -731,6 +739,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         Act T0 = dyact(S[(gi + 1) & 3], 0);
         Act T1 = dyact(S[(gi + 2) & 3], 1);
         float* T2 = S[(gi + 3) & 3];
+        const int set = (i_hi - i) & 1;                      // (piped) the temporaries of this block: the S buffers or the second set
+        if (piped) {
+            if (set) { T0 = Act(); T0.f = c.f(L.S2[0]); T1 = Act(); T1.f = c.f(L.S2[1]); T2 = c.f(L.S2[2]); }
+            if (i_hi - i >= 2) SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wdone[set], 0));   // block i + 2's weight gradients read them
+        }
         // planes-only mode: the BN input gradients are consumed as planes (wgrad / dgrad operands), the ReLU masks come from
         // the activations' planes
         const bool po = c.planes_only();
@@ -771,9 +784,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         } else {
             RC(conv_dgrad(c, b.c1, D1, G, T1.f, 24, fin, gb));
         }
-        RC(join());                                          // (the next block's BatchNorm backwards and dgrad reuse T0 / T1 / T2)
+        if (piped) SIMQ_CHECK_HIP(hipEventRecord(c.ev_wdone[set], c.wstream));
+        else RC(join());                                     // (the next block's BatchNorm backwards and dgrad reuse T0 / T1 / T2)
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
+    if (piped) RC(join());                                   // every weight gradient of the walk so far is behind this point
     if (phase == 1) return 0;
     // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient; fp32 kernels ----
     float* G = S[gi];
@@ -1089,11 +1104,11 @@ int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnb
 static int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                               const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                               void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
-                              hipEvent_t ev_wjoin) {
+                              hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr) {
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     c.sync = sync;
-    if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; }
+    if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; c.ev_wdone[0] = ev_wdone0; c.ev_wdone[1] = ev_wdone1; }
     if (d_dq) return backward_impl(c, d_dq, phase);
     const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
     return backward_impl(c, nullptr, phase, &oh);
@@ -1199,8 +1214,8 @@ int simq_train_step(const simq_train_args* a) {
     hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
     const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
     // fork / join events, one pair per device and host thread (events belong to the device they were created on)
-    static thread_local hipEvent_t ev_pairs[64][4] = {};
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr;
+    static thread_local hipEvent_t ev_pairs[64][6] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr, ev_wdone0 = nullptr, ev_wdone1 = nullptr;
     if (side) {
         int dev = 0;
         SIMQ_CHECK_HIP(hipGetDevice(&dev));
@@ -1210,18 +1225,52 @@ int simq_train_step(const simq_train_args* a) {
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][1], hipEventDisableTiming));
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][2], hipEventDisableTiming));
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][3], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][4], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][5], hipEventDisableTiming));
         }
         ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1]; ev_wfork = ev_pairs[dev][2]; ev_wjoin = ev_pairs[dev][3];
+        ev_wdone0 = ev_pairs[dev][4]; ev_wdone1 = ev_pairs[dev][5];
     }
     // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
     simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
     const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
+    // (timing experiment, tools only: all three forwards side by side from the start of the step.  The two train-mode forwards of the
+    // policy net then update the running statistics in no particular order -- NOT a product mode until that update is deferred)
+    const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync && !a->comm;
+    static thread_local hipStream_t third_streams[64] = {};
+    static thread_local hipEvent_t third_events[64] = {};
+    hipStream_t third = nullptr;
+    if (three) {
+        int dev = 0;
+        SIMQ_CHECK_HIP(hipGetDevice(&dev));
+        if (!third_streams[dev]) {
+            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&third_streams[dev], hipStreamNonBlocking));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&third_events[dev], hipEventDisableTiming));
+        }
+        third = third_streams[dev];
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
+        RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side));
+        SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, third, nullptr));
+        RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, third));
+        SIMQ_CHECK_HIP(hipEventRecord(third_events[dev], third));
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, third_events[dev], 0));
+        RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
+    } else {
+    if (g_fwd_overlap == 1 && side) {                      // (A-B: the target-net forward forked at the start of the step)
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
     RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
     // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read.  It is
     // forked BEHIND the policy's train-mode forward so that it overlaps the policy's next-state forward: both run on the
     // ~29 non-final samples, whose tiles do not fill whole rounds of the CUs, and fill each other's tails (+1.7 % on the step
     // over starting it beside the perfectly tiled 32-sample forward)
-    if (side) {
+    if (side && g_fwd_overlap != 1) {
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     }
@@ -1242,6 +1291,7 @@ int simq_train_step(const simq_train_args* a) {
         RC(launch_q_argmax(a->q_tgt, Nn, n, nullptr, a->vals, main));
     }
     }
+    }
     if (Nn == 0 && sync && a->use_double_dqn && a->global_nonfinal > 0) {     // all-terminal shard: zeros into the other ranks' reductions
         simq_sync sync_nf = sync_storage;
         sync_nf.global_batch = a->global_nonfinal;
@@ -1255,7 +1305,7 @@ int simq_train_step(const simq_train_args* a) {
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;
         return backward_sync_side(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync,
-                                  side, ev_wfork, ev_wjoin);
+                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1);
     };
     if (!a->comm) {
         RC(backward(0));
@@ -1276,8 +1326,13 @@ int simq_train_step(const simq_train_args* a) {
     return simq_weights_prepare(p, a->params, a->wcache, main);
 }
 
+int simq_tune_fwd_overlap(int on) {
+    g_fwd_overlap = (on >= 0 && on <= 2) ? on : 0;
+    return 0;
+}
+
 int simq_tune_wgrad_overlap(int on) {
-    g_wgrad_overlap = (on == 2 || on == 3) ? on : (on ? 1 : 0);
+    g_wgrad_overlap = (on >= 2 && on <= 4) ? on : (on ? 1 : 0);
     return 0;
 }
 

@@ -122,6 +122,7 @@ _SIGS = {
     'simq_tune_tail_split': (c_int, [c_int]),
     'simq_tune_plane_xcd': (c_int, [c_int]),
     'simq_tune_wgrad_overlap': (c_int, [c_int]),
+    'simq_tune_fwd_overlap': (c_int, [c_int]),
     'simq_tune_wgrad_xcd_group': (c_int, [c_int]),
     'simq_tune_wgrad_ksplit': (c_int, [c_int]),
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),

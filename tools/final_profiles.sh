@@ -1,11 +1,12 @@
 #!/bin/bash
-# GPU box: the measurements behind profiles/r03_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
+# GPU box: the measurements behind profiles/r04_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
 #   1. python bench.py                      -> bench.json        (the judged line: fp32 configs[1] headline + bf16 configs[2] leg,
 #                                                                  both with a roofline object, cpu_baseline)
 #   per workload W in {b32 = fp32 configs[1], bf16_b128 = bf16 configs[2]}:
 #   2. rocprofv3 --kernel-trace             -> bench_W_kernel_trace.txt   (same bench.py, 7 full steps, nothing else)
 #   3. rocprofv3 --pmc SQ_* (own pass)      -> bench_W_pmc_sq.txt         (matrix-pipe busy cycles)
 #   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> bench_W_pmc_traffic.txt + pmc_traffic[_bf16_b128].json
+#   5. fp32 only: the kernel trace again with the side-stream overlaps off -> bench_b32_kernel_trace_serial.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
@@ -26,6 +27,10 @@ prof() {   # name, extra bench args...
   python tools/pmc_traffic.py $(find $O -name "pf_${name}_results.db") $(find $O -name "pw_${name}_results.db") $O/pmc_traffic_${name}.json > $O/bench_${name}_pmc_traffic.txt
 }
 prof b32
+# the same fp32 step with every kernel alone on the device (target-net forward and weight gradients on the main stream): the per-kernel
+# durations the concurrent trace inflates (two kernels sharing the CUs each look longer) -- the view that matches bench.py's event timing
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $O -o ks_b32 -- python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --sustained-seconds 0 --steps 5 --warmup 2 --no-overlap --wgrad-overlap 0 > $O/ks_b32.out 2> $O/ks_b32.err )
+python tools/rocprof_summary.py $(find $O -name "ks_b32_results.db") 7 > $O/bench_b32_kernel_trace_serial.txt
 prof bf16_b128 --workload configs2
 find $O -name "*.db" -delete
 find $O -type d -empty -delete
