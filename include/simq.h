@@ -420,15 +420,19 @@ int simq_tune_tail_split(int on);
 /* tuning aid (A/B): the batched transform-domain GEMMs of the Winograd layers walk whole planes per XCD (1, default) or planes in launch
  * order with the per-plane tile remap of round 1 (0).  Scheduling only: results are bit-identical. */
 int simq_tune_plane_xcd(int on);
-/* tuning aid (A/B): inside simq_train_step the weight gradient of every residual-block convolution (the wgrad half of loss.backward(),
- * train.py:132) runs on the side stream beside the dgrads: 1 (default) = fp32 plans only, until the end of the residual block; 3 = fp32,
- * beside the dgrad of the same convolution only; 2 = every precision (measured slower for bf16); 0 = behind it on the main stream;
- * 4 = as 1, with a second set of gradient temporaries so that the main stream waits for a block's weight gradients two blocks later.
- * Same kernels on the same operands: results are bit-identical for deterministic kernels. */
+/* tuning aid (A/B): the weight gradient of every residual-block convolution (the wgrad half of loss.backward(), train.py:132) runs on a
+ * side stream beside the dgrads of the walk -- simq_train_step's side stream, or a library-owned one (per device and host thread) when a
+ * backward entry point is called on its own; the caller's stream is joined before the call returns its last launch.  fp32 plans:
+ * 4 (default) = until the temporaries of the block are written again two blocks later (a second set of gradient temporaries in the
+ * workspace), 1 = until the end of the residual block, 3 = beside the dgrad of the same convolution only; 2 = as 1 for every precision
+ * (measured slower for bf16); 0 = behind the dgrad on the caller's stream.  Same kernels on the same operands: results are bit-identical
+ * for deterministic plans. */
 int simq_tune_wgrad_overlap(int on);
-/* tuning aid (A/B, timing): where simq_train_step forks its no-grad forwards (train.py:119-122).  0 (default) = the target-net forward
- * on the side stream behind the policy's grad-mode forward; 1 = at the start of the step; 2 = TIMING ONLY: all three forwards side by side
- * (the policy's two train-mode forwards then update the BatchNorm running statistics in no particular order). */
+/* tuning aid (A/B): where simq_train_step forks its no-grad forwards (train.py:119-122).  2 (default) = all three forwards side by side
+ * from the start of the step: the target net's on the side stream, the policy's no-grad forward on a third (library-owned) stream with its
+ * BatchNorm running-statistics update deferred and applied behind the grad-mode forward's, in the reference's order (bit-identical
+ * buffers); 0 = the target-net forward on the side stream behind the policy's grad-mode forward, the policy's no-grad forward on the main
+ * stream (round 1-3); 1 = as 0 with the target-net forward forked at the start of the step.  Single-process steps without SyncBN only. */
 int simq_tune_fwd_overlap(int on);
 /* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
  * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.

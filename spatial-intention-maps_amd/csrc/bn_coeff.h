@@ -56,6 +56,7 @@ __device__ __forceinline__ void bn_commit(const BnRef& b) {
         b.save_invstd[c] = i;
         if (b.save_scale) { b.save_scale[c] = sc; b.save_shift[c] = sh; }
         const double unbiased = b.rows > 1.0 ? vd * b.rows / (b.rows - 1.0) : vd;
+        if (b.defer) { b.defer[c] = md; b.defer[b.C + c] = unbiased; continue; }     // (applied later, in the reference's order)
         b.rmean[c] = (float)(BN_MOMENTUM * md + (1.0 - BN_MOMENTUM) * (double)b.rmean[c]);
         b.rvar[c] = (float)(BN_MOMENTUM * unbiased + (1.0 - BN_MOMENTUM) * (double)b.rvar[c]);
     }

@@ -89,6 +89,10 @@ struct BnRef {
     float* save_shift = nullptr;     // from the pre-BN output (bn_bwd_apply's mscale / mshift)
     double rows = 0.0, inv_rows = 0.0;
     int C = 0;
+    // deferred running-statistics update (the policy's no-grad forward running BESIDE its grad-mode forward inside simq_train_step): the
+    // committing block leaves [batch mean | unbiased batch variance] here in fp64 instead of touching rmean / rvar; launch_bn_running_deferred
+    // applies them behind the other forward's update, in the reference's order (train.py:114 before train.py:121)
+    double* defer = nullptr;
 };
 // A convolution input that is still the PRE-BatchNorm output y of the producing convolution: the consumer applies
 // relu(y * scale[c] + shift[c]) -- the fma / max sequence of bn_apply -- while it stages its operand, so the train-mode
@@ -226,6 +230,8 @@ int launch_colsum_finish(const double* red, float* out, int C, hipStream_t strea
 int launch_upsample2x_fwd(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes(),
                           double* stats = nullptr, int relu = 0, int replicas = 1);   // stats: `replicas` copies of [sum | sum of squares] of the
                                                                                       // outputs, accumulated into (block b -> copy b % replicas)
+// buf[i] = (float)(0.1 * defer[i] + 0.9 * buf[i]) over a net's whole [running mean | running var] buffer: bn_commit's update, deferred
+int launch_bn_running_deferred(float* bnbuf, const double* defer, int64_t n, hipStream_t stream);
 int launch_stats_fold(const double* rep, double* out, int n, int replicas, hipStream_t stream);   // out[i] = sum_r rep[r][i]
 int launch_upsample2x_bwd(const float* dout, float* din, int B, int H, int W, int C, hipStream_t stream, Planes pl = Planes());
 int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t stream);

@@ -776,6 +776,17 @@ int launch_colsum_rep(const float* x, double* red_scratch, float* out, int64_t r
     return 0;
 }
 
+__global__ void bn_running_deferred_kernel(float* __restrict__ buf, const double* __restrict__ defer, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] = (float)(BN_MOMENTUM * defer[i] + (1.0 - BN_MOMENTUM) * (double)buf[i]);
+}
+
+int launch_bn_running_deferred(float* bnbuf, const double* defer, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_running_deferred_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, bnbuf, defer, n);
+    SIMQ_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_stats_fold(const double* rep, double* out, int n, int replicas, hipStream_t stream) {
     hipLaunchKernelGGL(stats_fold_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, rep, out, n, replicas);
     SIMQ_CHECK_LAUNCH();

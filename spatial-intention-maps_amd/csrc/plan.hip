@@ -148,6 +148,8 @@ struct Layout {
     struct Blk { int64_t y1, a1, y2, yd, out, p_a1, p_out; } blk[8];
     int64_t yh1, ah1, up1, yh2, ah2, up2;
     int64_t aux, red, colsum;
+    int64_t defer;   // [batch mean | unbiased batch variance] per BatchNorm in fp64, laid out like the bn buffer: a forward whose running-
+                     // statistics update is deferred (BnRef::defer) leaves them here
     int64_t S[4];
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
     int64_t p_pooled, p_up1, DP[2];
@@ -184,6 +186,7 @@ Layout make_layout(const simq_plan* p, int B) {
     L.red = take(p->red_total * (int64_t)sizeof(double));
     L.colsum = take(kStatReplicas * 2 * 128 * sizeof(double));   // replicated scratch slots: bias-gradient column sums of the head
                                                                  // convolutions, non-fused BatchNorm-backward sums (C <= 128)
+    L.defer = take(p->nbnbuf * (int64_t)sizeof(double));
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
     for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
     L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = -1;
@@ -253,6 +256,7 @@ struct Ctx {
     char* wc = nullptr;      // weight cache
     WLayout W = WLayout();
     const simq_sync* sync = nullptr;   // cross-rank BatchNorm statistics (simq_forward_sync / simq_backward_sync)
+    bool defer_running = false;        // train-mode forward: batch statistics into L.defer instead of the running-statistics update
     // backward inside simq_train_step: the weight gradients run on this stream beside the dgrads of the same layer (fork / join events)
     hipStream_t wstream = nullptr;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
@@ -354,6 +358,7 @@ BnRef bnref(const Ctx& c, const BnL& bn, int mode, int64_t rows) {
     r.save_mean = c.aux(bn, 2); r.save_invstd = c.aux(bn, 3);
     if (mode != SIMQ_MODE_EVAL) { r.save_scale = c.aux(bn, 0); r.save_shift = c.aux(bn, 1); }     // (backward: mask1_from_y)
     r.rows = c.bn_rows(rows); r.inv_rows = 1.0 / r.rows; r.C = bn.C;
+    if (c.defer_running && mode != SIMQ_MODE_EVAL) r.defer = reinterpret_cast<double*>(c.ws + c.L.defer) + bn.buf_off;
     return r;
 }
 
@@ -625,8 +630,8 @@ constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that be
 // one-hot form of the upstream gradient (the TD loss): dQ[b][action[b]] = clamp(q_sa[b] - y[b], -1, 1) * grad_scale
 struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
 
-int g_fwd_overlap = 0;     // simq_tune_fwd_overlap (A-B / timing runs): where the no-grad forwards of simq_train_step are forked
-int g_wgrad_overlap = 1;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads inside simq_train_step
+int g_fwd_overlap = 2;     // simq_tune_fwd_overlap (A-B runs): where the no-grad forwards of simq_train_step are forked
+int g_wgrad_overlap = 4;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads on a side stream (4: up to one block behind)
 
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr) {
     const simq_plan* p = c.p;
@@ -1100,6 +1105,30 @@ int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnb
     return 0;
 }
 
+// Library-owned side stream + events for the weight-gradient overlap of a backward pass called on its own (simq_backward*,
+// FCN.backward): per device and host thread, created on first use.  fp32 plans only (the overlap is off for the matrix-core
+// precisions, see backward_impl); the calling thread's current device must be the stream's.
+struct BackwardSide { hipStream_t stream = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; };
+static thread_local BackwardSide g_backward_side[64];
+static int attach_backward_side(Ctx& c) {
+    if (c.wstream || g_wgrad_overlap == 0 || (c.mc() && g_wgrad_overlap != 2)) return 0;
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return 0;
+    if (c.stream) {
+        hipDevice_t sdev = 0;
+        SIMQ_CHECK_HIP(hipStreamGetDevice(c.stream, &sdev));
+        if ((int)sdev != dev) return 0;      // (a stream of another device: no overlap rather than events on the wrong device)
+    }
+    BackwardSide& r = g_backward_side[dev];
+    if (!r.stream) {
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    }
+    c.wstream = r.stream; c.ev_wfork = r.ev[0]; c.ev_wjoin = r.ev[1]; c.ev_wdone[0] = r.ev[2]; c.ev_wdone[1] = r.ev[3];
+    return 0;
+}
+
 // simq_backward_sync with the stream / events of the weight-gradient overlap (simq_train_step only: its side stream is idle by then)
 static int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                               const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
@@ -1109,6 +1138,7 @@ static int backward_sync_side(const simq_plan* plan, int batch, const float* d_p
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     c.sync = sync;
     if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; c.ev_wdone[0] = ev_wdone0; c.ev_wdone[1] = ev_wdone1; }
+    else RC(attach_backward_side(c));
     if (d_dq) return backward_impl(c, d_dq, phase);
     const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
     return backward_impl(c, nullptr, phase, &oh);
@@ -1132,6 +1162,7 @@ int simq_backward_phase(const simq_plan* plan, int batch, const float* d_params,
     SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    RC(attach_backward_side(c));
     return backward_impl(c, d_dq, phase);
 }
 
@@ -1144,6 +1175,7 @@ int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
+    RC(attach_backward_side(c));
     return backward_impl(c, nullptr, phase, &oh);
 }
 
@@ -1234,12 +1266,16 @@ int simq_train_step(const simq_train_args* a) {
     // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
     simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
     const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
-    // (timing experiment, tools only: all three forwards side by side from the start of the step.  The two train-mode forwards of the
-    // policy net then update the running statistics in no particular order -- NOT a product mode until that update is deferred)
+    // Three forwards side by side (round 4).  The policy's no-grad forward over the next states (train.py:121) reads nothing the grad-mode
+    // forward (train.py:114) writes except the BatchNorm running statistics, which BOTH update (the policy net is in train mode) and no
+    // forward reads: it runs on a third stream from the start of the step with that update deferred -- its committing blocks leave
+    // [mean | unbiased variance] in fp64 (BnRef::defer) and one launch applies them behind the grad-mode forward's update, the same fp64
+    // expression on the same values in the reference's order: the buffers are bit-identical to the serial order's.  The transform-domain
+    // forwards alternate HBM-bound transforms and matrix-bound GEMMs; side by side the three fill each other's phases
+    // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN / a communicator (their collectives order the streams).
     const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync && !a->comm;
     static thread_local hipStream_t third_streams[64] = {};
     static thread_local hipEvent_t third_events[64] = {};
-    hipStream_t third = nullptr;
     if (three) {
         int dev = 0;
         SIMQ_CHECK_HIP(hipGetDevice(&dev));
@@ -1247,18 +1283,22 @@ int simq_train_step(const simq_train_args* a) {
             SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&third_streams[dev], hipStreamNonBlocking));
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&third_events[dev], hipEventDisableTiming));
         }
-        third = third_streams[dev];
+        hipStream_t third = third_streams[dev];
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
         RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side));
         SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
-        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, third, nullptr));
+        Ctx cn{p, Nn, a->params, nullptr, a->bnbuf, static_cast<char*>(a->ws_tmp), make_layout(p, Nn), third};
+        cn.wc = static_cast<char*>(const_cast<void*>(a->wcache)); cn.W = make_wlayout(p);
+        cn.defer_running = true;
+        RC(forward_impl(cn, SIMQ_MODE_TRAIN_NOGRAD, a->next_state, a->q_next));
         RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, third));
         SIMQ_CHECK_HIP(hipEventRecord(third_events[dev], third));
-        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));
-        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
         SIMQ_CHECK_HIP(hipStreamWaitEvent(main, third_events[dev], 0));
+        RC(launch_bn_running_deferred(a->bnbuf, reinterpret_cast<const double*>(cn.ws + cn.L.defer), p->nbnbuf, main));     // update #2
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
         RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
     } else {
     if (g_fwd_overlap == 1 && side) {                      // (A-B: the target-net forward forked at the start of the step)
@@ -1327,12 +1367,12 @@ int simq_train_step(const simq_train_args* a) {
 }
 
 int simq_tune_fwd_overlap(int on) {
-    g_fwd_overlap = (on >= 0 && on <= 2) ? on : 0;
+    g_fwd_overlap = (on >= 0 && on <= 2) ? on : 2;
     return 0;
 }
 
 int simq_tune_wgrad_overlap(int on) {
-    g_wgrad_overlap = (on >= 2 && on <= 4) ? on : (on ? 1 : 0);
+    g_wgrad_overlap = (on >= 0 && on <= 4) ? on : 4;
     return 0;
 }
 

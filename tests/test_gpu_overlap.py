@@ -1,0 +1,100 @@
+"""GPU: the stream structure of one TD step (round 4) changes WHEN kernels run, never what they compute.
+
+simq_train_step runs the three forwards of train.py:114-122 side by side (the policy's no-grad forward on a third stream with its
+BatchNorm running-statistics update deferred and applied behind the grad-mode forward's, in the reference's order) and the weight
+gradients of the residual blocks on a side stream up to one block behind the dgrads (a second set of gradient temporaries).  On a
+DETERMINISTIC plan (fixed-order reductions everywhere) every result of two consecutive steps -- losses, gradient, parameters and the
+BatchNorm buffers, whose update order is exactly what the deferral has to preserve -- must equal the fully serial order BIT FOR BIT,
+for every setting of the two A-B switches; the standalone backward entry points (FCN.backward, simq_backward*) take the same side
+stream from the library and are held to the same bar.  Against the reference itself the overlapped step is what every golden test
+of tests/test_gpu_fcn.py / test_gpu_sized.py runs (the defaults)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope='module')
+def env():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    import simq
+    import simq.learner as sl
+    from oracle import cases, fcn as ofcn
+    from simq import synth
+    from simq._lib import lib
+    yield dict(simq=simq, sl=sl, cases=cases, ofcn=ofcn, synth=synth, lib=lib)
+    lib.call('simq_tune_wgrad_overlap', 4)
+    lib.call('simq_tune_fwd_overlap', 2)
+
+
+def _nets(e, precision, options, cin=5, cout=2):
+    policy = e['simq'].FCN(cin, cout, precision=precision, options=options)
+    target = e['simq'].FCN(cin, cout, precision=precision, options=options)
+    policy.load_state_dict(e['ofcn'].state_from_numpy(e['synth'].make_state_dict(cin, cout, 3)))
+    target.load_state_dict(e['ofcn'].state_from_numpy(e['synth'].make_state_dict(cin, cout, 4)))
+    policy.train(); target.eval()
+    return policy, target
+
+
+def _two_steps(e, wgrad, fwd, B, precision='fp32', options=None, cin=5, cout=2):
+    c = e['cases']
+    e['lib'].call('simq_tune_wgrad_overlap', wgrad)
+    e['lib'].call('simq_tune_fwd_overlap', fwd)
+    policy, target = _nets(e, precision, options if options is not None else {'deterministic': 1}, cin, cout)
+    losses = []
+    for s in range(2):     # (the second step re-records every event and reuses both sets of temporaries)
+        info = e['sl'].train_step(policy, target, c.make_batch(cin, cout, B, 7 + s), c.GAMMA, B, c.LR, c.MOMENTUM, c.WEIGHT_DECAY, c.CLIP,
+                                  use_double_dqn=True)
+        losses.append((info['loss'], info['td_error']))
+    torch.cuda.synchronize()
+    return dict(loss=losses, grads=policy.flat_grads.clone(), params=policy.flat_params.clone(), bn=policy.bn_buffers.clone())
+
+
+@pytest.mark.parametrize('B', [6, 32])
+def test_overlapped_step_equals_the_serial_step_bit_for_bit(env, B):
+    ref = _two_steps(env, 0, 0, B)                     # weight gradients behind the dgrads, the policy's forwards one after the other
+    assert all(l == l and abs(l) < 1e6 for pair in ref['loss'] for l in pair)
+    for wgrad, fwd in ((4, 2), (1, 2), (3, 1), (4, 0), (0, 2)):
+        r = _two_steps(env, wgrad, fwd, B)
+        assert r['loss'] == ref['loss'], (wgrad, fwd, r['loss'], ref['loss'])
+        assert torch.equal(r['bn'], ref['bn']), 'BatchNorm buffers differ (wgrad_overlap %d, fwd_overlap %d): the deferred update is out of order' % (wgrad, fwd)
+        assert torch.equal(r['grads'], ref['grads']), 'gradient differs (wgrad_overlap %d, fwd_overlap %d)' % (wgrad, fwd)
+        assert torch.equal(r['params'], ref['params']), 'parameters differ (wgrad_overlap %d, fwd_overlap %d)' % (wgrad, fwd)
+
+
+def test_overlapped_bf16_step_keeps_the_buffers_of_the_serial_step(env):
+    # bf16: the weight gradients stay on the main stream (LDS-bound kernels); the three forwards run side by side
+    ref = _two_steps(env, 0, 0, 16, precision='bf16')
+    r = _two_steps(env, 4, 2, 16, precision='bf16')
+    assert r['loss'] == ref['loss']
+    for k in ('bn', 'grads', 'params'):
+        assert torch.equal(r[k], ref[k]), k
+
+
+def test_standalone_backward_on_the_library_side_stream(env):
+    # FCN.backward / simq_backward_phase: dense upstream gradient, weight gradients on the library-owned side stream
+    from simq._lib import MODE_TRAIN
+    e = env
+    B, cin, cout = 8, 4, 2
+    out = {}
+    for wgrad in (0, 4, 1):
+        e['lib'].call('simq_tune_wgrad_overlap', wgrad)
+        policy, _ = _nets(e, 'fp32', {'deterministic': 1}, cin, cout)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 96, 96, cin, generator=g).cuda()
+        for _ in range(2):
+            q = policy._forward_raw(x, MODE_TRAIN)
+            dq = (torch.randn(q.shape, generator=g) * 1e-3).cuda()
+            policy._backward_raw(dq, B)
+        torch.cuda.synchronize()
+        out[wgrad] = (q.detach().clone(), policy.flat_grads.clone())
+    assert float(out[0][1].abs().max()) > 0
+    for wgrad in (4, 1):
+        assert torch.equal(out[wgrad][0], out[0][0])
+        assert torch.equal(out[wgrad][1], out[0][1]), 'standalone backward: gradient differs with wgrad_overlap %d' % wgrad
