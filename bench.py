@@ -83,6 +83,7 @@ def parse():
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
     ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
     ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_tune_wgrad_overlap, A/B')
+    ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
     ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = timing only)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
@@ -299,6 +300,9 @@ def main():
     from simq.learner import _opt_state, train_step
     if args.plane_xcd is not None:
         lib.call('simq_tune_plane_xcd', args.plane_xcd)
+    if args.no_upload_stream:
+        import simq.learner as _sl
+        _sl.UPLOAD_STREAM = False
     if args.fwd_overlap is not None:
         lib.call('simq_tune_fwd_overlap', args.fwd_overlap)
     if args.wgrad_overlap is not None:
@@ -495,10 +499,14 @@ def main():
 
     def roofline_pass(step_fn, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
-        `steps` more steps with the two-stream overlap off, so that every bracket times one kernel alone."""
+        `steps` more steps with every stream overlap of the step off (target-net forward, the policy's no-grad forward and the weight
+        gradients all on the launch stream), so that every bracket times one kernel ALONE on the device: a roofline fraction is a
+        property of the kernel, and two kernels sharing the CUs each look slower than either is."""
         import simq.learner as slearner
         keep = slearner.OVERLAP_TARGET_FORWARD
         slearner.OVERLAP_TARGET_FORWARD = False
+        lib.call('simq_tune_fwd_overlap', 0)
+        lib.call('simq_tune_wgrad_overlap', 0)
         lib.call('simq_profile_start')
         barrier()
         t1 = time.perf_counter()
@@ -509,6 +517,8 @@ def main():
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
         slearner.OVERLAP_TARGET_FORWARD = keep
+        lib.call('simq_tune_fwd_overlap', 2 if args.fwd_overlap is None else args.fwd_overlap)
+        lib.call('simq_tune_wgrad_overlap', 4 if args.wgrad_overlap is None else args.wgrad_overlap)
         dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # kind 0: the dominant kernel of the precision
         wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}       # kind 1: direct weight-gradient launches
         oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # kind 2: every other implicit-GEMM tile
@@ -537,6 +547,10 @@ def main():
             'whole_step_executed_frac': round(executed / (ms_per_step * 1e-3) / (PEAK * 1e12), 4),
             'whole_step_hbm_frac_activation_lower_bound': round(per_gpu_rate * (61.9e6 if precision == 'fp32' else 31.0e6) / (PEAK_HBM_GBS * 1e9), 5),
             'ms_per_step_instrumented': round(dt_inst / steps * 1e3, 3),
+            'timed': 'HIP-event pairs around every launch of the kernel over %d steps behind the timed region, each kernel ALONE on the device '
+                     '(the step\'s stream overlaps off for these steps only; `value` is the overlapped step); the matching rocprofv3 trace is '
+                     'profiles/r04_bench_%s_kernel_trace_serial.txt, the overlapped step\'s profiles/r04_bench_%s_kernel_trace.txt' % (
+                         steps, 'b32' if precision == 'fp32' else 'bf16_b128', 'b32' if precision == 'fp32' else 'bf16_b128'),
         }
 
     def per_rank(roof):

@@ -432,7 +432,7 @@ int simq_tune_wgrad_overlap(int on);
  * from the start of the step: the target net's on the side stream, the policy's no-grad forward on a third (library-owned) stream with its
  * BatchNorm running-statistics update deferred and applied behind the grad-mode forward's, in the reference's order (bit-identical
  * buffers); 0 = the target-net forward on the side stream behind the policy's grad-mode forward, the policy's no-grad forward on the main
- * stream (round 1-3); 1 = as 0 with the target-net forward forked at the start of the step.  Single-process steps without SyncBN only. */
+ * stream (round 1-3); 1 = as 0 with the target-net forward forked at the start of the step.  Steps under SyncBN keep form 0. */
 int simq_tune_fwd_overlap(int on);
 /* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
  * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.

@@ -1272,8 +1272,9 @@ int simq_train_step(const simq_train_args* a) {
     // [mean | unbiased variance] in fp64 (BnRef::defer) and one launch applies them behind the grad-mode forward's update, the same fp64
     // expression on the same values in the reference's order: the buffers are bit-identical to the serial order's.  The transform-domain
     // forwards alternate HBM-bound transforms and matrix-bound GEMMs; side by side the three fill each other's phases
-    // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN / a communicator (their collectives order the streams).
-    const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync && !a->comm;
+    // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN (its collectives order the streams); the plain
+    // data-parallel step has no collective before its backward pass and takes it.
+    const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync;
     static thread_local hipStream_t third_streams[64] = {};
     static thread_local hipEvent_t third_events[64] = {};
     if (three) {

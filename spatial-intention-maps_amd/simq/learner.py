@@ -91,6 +91,8 @@ def assemble_batch(batch, device, allow_all_final=False):
 
 
 _PACK_RINGS = {}        # device -> [pinned uint8 buffers, events, position]
+_UPLOAD_STREAMS = {}    # device -> the stream the packed per-batch uploads run on
+UPLOAD_STREAM = True    # (A-B: False = the upload on the consuming stream, rounds 1-3)
 
 
 def _upload_packed(device, arrays, slots=4):
@@ -114,10 +116,26 @@ def _upload_packed(device, arrays, slots=4):
     for a, o in zip(arrays, offs):
         if a.size:
             host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-    devbuf = torch.empty(total, dtype=torch.uint8, device=device)
-    devbuf.copy_(bufs[i][:total], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
+    main = torch.cuda.current_stream(device)
+    if UPLOAD_STREAM:
+        # the copy depends on nothing the device is doing: on its own stream it runs while the previous step's kernels still do, and the
+        # consuming stream only waits for its event (on the consuming stream it queued behind the whole previous step and the device idled
+        # for the copy's latency at every step boundary).  The buffer comes from the upload stream's pool and is handed to the consumer.
+        up = _UPLOAD_STREAMS.get(device)
+        if up is None:
+            up = _UPLOAD_STREAMS[device] = torch.cuda.Stream(device)
+        with torch.cuda.stream(up):
+            devbuf = torch.empty(total, dtype=torch.uint8, device=device)
+            devbuf.copy_(bufs[i][:total], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        main.wait_event(ev)
+        devbuf.record_stream(main)
+    else:
+        devbuf = torch.empty(total, dtype=torch.uint8, device=device)
+        devbuf.copy_(bufs[i][:total], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
     events[i] = ev
     kinds = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
     return tuple(devbuf[o:o + a.nbytes].view(kinds[a.dtype]) for a, o in zip(arrays, offs))

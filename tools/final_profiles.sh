@@ -6,7 +6,7 @@
 #   2. rocprofv3 --kernel-trace             -> bench_W_kernel_trace.txt   (same bench.py, 7 full steps, nothing else)
 #   3. rocprofv3 --pmc SQ_* (own pass)      -> bench_W_pmc_sq.txt         (matrix-pipe busy cycles)
 #   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> bench_W_pmc_traffic.txt + pmc_traffic[_bf16_b128].json
-#   5. fp32 only: the kernel trace again with the side-stream overlaps off -> bench_b32_kernel_trace_serial.txt
+#   5. the kernel trace again with the stream overlaps of the step off -> bench_W_kernel_trace_serial.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
@@ -27,11 +27,16 @@ prof() {   # name, extra bench args...
   python tools/pmc_traffic.py $(find $O -name "pf_${name}_results.db") $(find $O -name "pw_${name}_results.db") $O/pmc_traffic_${name}.json > $O/bench_${name}_pmc_traffic.txt
 }
 prof b32
-# the same fp32 step with every kernel alone on the device (target-net forward and weight gradients on the main stream): the per-kernel
-# durations the concurrent trace inflates (two kernels sharing the CUs each look longer) -- the view that matches bench.py's event timing
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $O -o ks_b32 -- python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --sustained-seconds 0 --steps 5 --warmup 2 --no-overlap --wgrad-overlap 0 > $O/ks_b32.out 2> $O/ks_b32.err )
-python tools/rocprof_summary.py $(find $O -name "ks_b32_results.db") 7 > $O/bench_b32_kernel_trace_serial.txt
+serial() {   # name, extra bench args...: the same step with every kernel alone on the device (target-net forward, the policy's no-grad forward and
+             # the weight gradients on the main stream): the per-kernel durations the concurrent trace inflates (two kernels sharing the CUs each
+             # look longer) -- the view that matches bench.py's event timing of the roofline kernels
+  local name=$1; shift
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $O -o ks_$name -- python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --sustained-seconds 0 --steps 5 --warmup 2 --no-overlap --wgrad-overlap 0 --fwd-overlap 0 $* > $O/ks_$name.out 2> $O/ks_$name.err )
+  python tools/rocprof_summary.py $(find $O -name "ks_${name}_results.db") 7 > $O/bench_${name}_kernel_trace_serial.txt
+}
+serial b32
 prof bf16_b128 --workload configs2
+serial bf16_b128 --workload configs2
 find $O -name "*.db" -delete
 find $O -type d -empty -delete
 tail -c 1500 $O/bench.json

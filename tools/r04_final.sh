@@ -7,3 +7,4 @@ grep -n "passed\|failed\|^FAILED" gpurun_out/t_all.log | tail -8
 bash tools/final_profiles.sh > gpurun_out/final_profiles.log 2>&1; echo "profiles rc=$?"
 tail -c 600 gpurun_out/final_profiles.log
 ls gpurun_out/final
+bash tools/r04_timeline.sh > gpurun_out/timeline.log 2>&1; echo "timeline rc=$?"
