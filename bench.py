@@ -82,7 +82,7 @@ def parse():
     ap.add_argument('--plan-option', action='append', default=[], metavar='NAME=INT', help='tools only: a simq_plan_options override for every plan of the run (A/B), e.g. deterministic=1')
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
     ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
-    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4, 5], help='tools only: simq_tune_wgrad_overlap, A/B (5 = 4 with the stem behind every weight gradient)')
+    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_tune_wgrad_overlap, A/B')
     ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
     ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = timing only)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')

@@ -425,9 +425,8 @@ int simq_tune_plane_xcd(int on);
  * backward entry point is called on its own; the caller's stream is joined before the call returns its last launch.  fp32 plans:
  * 4 (default) = until the temporaries of the block are written again two blocks later (a second set of gradient temporaries in the
  * workspace), 1 = until the end of the residual block, 3 = beside the dgrad of the same convolution only; 2 = as 1 for every precision
- * (measured slower for bf16); 0 = behind the dgrad on the caller's stream; 5 = 4 with the stem's backward behind every weight gradient
- * (by default block 0's weight gradients run beside it).  Same kernels on the same operands: results are bit-identical for deterministic
- * plans. */
+ * (measured slower for bf16); 0 = behind the dgrad on the caller's stream.  Same kernels on the same operands: results are bit-identical
+ * for deterministic plans. */
 int simq_tune_wgrad_overlap(int on);
 /* tuning aid (A/B): where simq_train_step forks its no-grad forwards (train.py:119-122).  2 (default) = all three forwards side by side
  * from the start of the step: the target net's on the side stream, the policy's no-grad forward on a third (library-owned) stream with its

@@ -631,7 +631,6 @@ constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that be
 struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
 
 int g_fwd_overlap = 2;     // simq_tune_fwd_overlap (A-B runs): where the no-grad forwards of simq_train_step are forked
-int g_wgrad_overlap_stem = 1; // (A-B, simq_tune_wgrad_overlap(5) clears it) block 0's weight gradients beside the stem's backward
 int g_wgrad_overlap = 4;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads on a side stream (4: up to one block behind)
 
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr) {
@@ -794,11 +793,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         else RC(join());                                     // (the next block's BatchNorm backwards and dgrad reuse T0 / T1 / T2)
         // G (same buffer) now holds the gradient w.r.t. the block input
     }
-    // (piped) the stem below writes set 0's buffers and, on deterministic plans, shares the partial-tile slab with the weight gradients: it waits
-    // for the last block that used set 0 -- block 1 -- only, and block 0's weight gradients (set 1) run beside the stem's backward
-    const bool stem_beside = piped && phase != 1 && !p->opt.deterministic && g_wgrad_overlap_stem && ((i_hi - i_lo) & 1);
-    if (stem_beside) SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wdone[0], 0));
-    else if (piped) RC(join());                              // every weight gradient of the walk so far is behind this point
+    if (piped) RC(join());                                   // every weight gradient of the walk so far is behind this point
     if (phase == 1) return 0;
     // ---- stem (resnet.py:94-97 reversed); the input image needs no gradient; fp32 kernels ----
     float* G = S[gi];
@@ -817,7 +812,6 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     if (stem16)                                      // (T0 = dz is dead behind bn_bwd: it holds the partial-sum slabs)
         return launch_stem_wgrad_bf16(x0.f, T1.pl.hi, c.grads + p->stem.w_off, T0, B, 96, 96, p->cin, c.stream);
     RC(conv_wgrad(c, p->stem, x0, T1, 96));
-    if (stem_beside) RC(join());
     return 0;
 }
 
@@ -1379,7 +1373,6 @@ int simq_tune_fwd_overlap(int on) {
 }
 
 int simq_tune_wgrad_overlap(int on) {
-    g_wgrad_overlap_stem = on == 5 ? 0 : 1;
     g_wgrad_overlap = (on >= 0 && on <= 4) ? on : 4;
     return 0;
 }
