@@ -84,7 +84,7 @@ def parse():
     ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
     ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_tune_wgrad_overlap, A/B')
     ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
-    ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = timing only)')
+    ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = default: three forwards side by side)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
