@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured-and-removed experiment: the switch / code path it exercised is no longer in the library -- see DESIGN 4 "streams inside one step")
 # GPU box: stream priorities -- the policy's no-grad forward (third stream) and the side stream at low priority, against equal priorities
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 python - <<'P'

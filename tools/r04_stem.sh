@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a measured-and-removed experiment: the switch / code path it exercised is no longer in the library -- see DESIGN 4 "streams inside one step")
 # GPU box: block 0's weight gradients beside the stem's backward (default) against the stem behind every weight gradient (5)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 python -m pytest tests/test_gpu_overlap.py -m gpu -q -x 2>&1 | tail -3
