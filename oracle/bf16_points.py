@@ -8,7 +8,7 @@ arithmetic between two rounding points.  With `points=False` every rounding is t
 oracle.fcn.fcn_forward / oracle.learner.train_step in fp64 (tests/test_oracle_golden.py holds them to that, and to landing inside
 the reference's autocast calibration with the points on).
 
-The rounding points (spatial-intention-maps_amd/csrc/plan.hip forward_impl / backward_impl), reference layer by layer
+The rounding points (spatial-intention-maps_amd/csrc/forward.hip forward_impl, backward.hip backward_impl), reference layer by layer
 (networks.py:16-26, resnet.py:31-47,93-104):
   * every convolution except the last 1x1 (conv3) multiplies bf16(operand) x bf16(weight), products and sums exact (fp32 accumulate
     in the kernels, fp64 here); the network input is rounded inside the first convolution;

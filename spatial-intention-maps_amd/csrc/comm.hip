@@ -90,7 +90,7 @@ struct simq_comm {
 
 namespace simq {
 
-// used by simq_train_step (plan.hip)
+// used by simq_train_step (train_step.hip)
 int comm_wait(simq_comm* c, hipStream_t consumer);
 
 int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_t producer) {

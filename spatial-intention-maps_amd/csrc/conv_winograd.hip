@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ 
 }  // namespace
 
 // Which convolutions of a plan run in Winograd form, and in which form, is a property of the PLAN: simq_plan_options
-// (include/simq.h), read by plan.hip.  The functions below are pure geometry / cost rules.
+// (include/simq.h), read by layout.hip / forward.hip / backward.hip.  The functions below are pure geometry / cost rules.
 
 // Geometry the kernels handle: 3x3 / stride 1 / pad 1 on an even-sized map, channel counts that fill the float4 lanes of the
 // transform kernels (C / 4 divides 256) and the GEMM's tiles.

@@ -510,7 +510,7 @@ __device__ __forceinline__ Lerp lerp_coord(int o, int in_size, float scale) {
 }
 
 // red != NULL: also accumulates the per-channel sum / sum of squares of the outputs (the train-mode BatchNorm statistics of a layer
-// whose convolution ran BEFORE the upsample, plan.hip head); relu: rectify the outputs
+// whose convolution ran BEFORE the upsample, forward.hip head); relu: rectify the outputs
 __global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, Planes pl, int B, int H, int W,
                                       int C4, double* red, int relu, int replicas) {
     __shared__ double sm[4 * 16 * 8];                 // [wave][channel group <= 16][8]

@@ -1,0 +1,199 @@
+// libsimq: the whole TD step of train.py:108-141 as one library call (simq_train_step) -- three forwards, TD target + Huber loss,
+// backward (with the two gradient all-reduces of the data-parallel form), clip + SGD, weight-cache refresh.
+#include "plan.h"
+
+using namespace simq;
+
+namespace {
+// out4 -> pinned host memory without a stream synchronisation: per device and host thread one copy stream + two events
+struct LossCopy { hipStream_t copy = nullptr; hipEvent_t ready = nullptr, done = nullptr; bool pending = false; };
+thread_local LossCopy g_loss_copy[64];
+
+int loss_copy(const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream) {
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+    if (producer) {                         // the copy stream / events are created on the CURRENT device: it must be the producer stream's
+        hipDevice_t sdev = 0;
+        SIMQ_CHECK_HIP(hipStreamGetDevice(producer, &sdev));
+        SIMQ_REQUIRE((int)sdev == dev, "train_step: the stream belongs to device %d, the calling thread's current device is %d", (int)sdev, dev);
+    }
+    LossCopy& c = g_loss_copy[dev];
+    if (!c.copy) {
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
+    hipStream_t s = producer;
+    if (own_stream) {                       // the copy must not queue behind the backward pass that follows on `producer`
+        SIMQ_CHECK_HIP(hipEventRecord(c.ready, producer));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(c.copy, c.ready, 0));
+        s = c.copy;
+    }
+    SIMQ_CHECK_HIP(hipMemcpyAsync(h_out4, d_out4, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+    SIMQ_CHECK_HIP(hipEventRecord(c.done, s));
+    c.pending = true;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int simq_train_loss_wait(void) {
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_loss_wait: device index %d out of range", dev);
+    LossCopy& c = g_loss_copy[dev];
+    SIMQ_REQUIRE(c.pending, "train_loss_wait: no simq_train_step with loss_host on this thread and device");
+    SIMQ_CHECK_HIP(hipEventSynchronize(c.done));
+    c.pending = false;
+    return 0;
+}
+
+int simq_train_step(const simq_train_args* a) {
+    SIMQ_REQUIRE(a && a->plan, "train_step: NULL argument");
+    SIMQ_REQUIRE(a->struct_bytes == (int)sizeof(simq_train_args), "train_step: simq_train_args.struct_bytes = %d, this library's struct has %d bytes",
+                 a->struct_bytes, (int)sizeof(simq_train_args));
+    SIMQ_REQUIRE(a->params && a->wcache && a->bnbuf && a->grads && a->momentum_buf && a->ws_train && a->ws_tmp && a->t_params &&
+                 a->t_wcache && a->t_bnbuf && a->t_ws && a->state && a->next_state && a->action && a->reward && a->nonfinal_pos &&
+                 a->q && a->q_tgt && a->nsv && a->vals && a->q_sa && a->y && a->td && a->out4 && a->opt_scratch,
+                 "train_step: NULL buffer");
+    SIMQ_REQUIRE(!a->use_double_dqn || a->num_nonfinal == 0 || (a->q_next && a->best), "train_step: double DQN needs q_next and best");
+    SIMQ_REQUIRE(!(a->comm && a->sync_bn) || a->global_nonfinal >= a->num_nonfinal, "train_step: sync_bn needs global_nonfinal (>= num_nonfinal)");
+    // single process: the reference itself fails on a minibatch without any non-final next state (torch.cat([]) at train.py:112);
+    // a data-parallel SHARD may have none and still has to join the collectives
+    SIMQ_REQUIRE(a->batch >= 1 && a->num_nonfinal >= (a->comm ? 0 : 1) && a->num_nonfinal <= a->batch && a->global_batch >= a->batch,
+                 "train_step: batch=%d num_nonfinal=%d global_batch=%d", a->batch, a->num_nonfinal, a->global_batch);
+    const simq_plan* p = a->plan;
+    hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
+    const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
+    // fork / join events, one pair per device and host thread (events belong to the device they were created on)
+    static thread_local hipEvent_t ev_pairs[64][6] = {};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr, ev_wdone0 = nullptr, ev_wdone1 = nullptr;
+    if (side) {
+        int dev = 0;
+        SIMQ_CHECK_HIP(hipGetDevice(&dev));
+        SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+        if (!ev_pairs[dev][0]) {
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][0], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][1], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][2], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][3], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][4], hipEventDisableTiming));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][5], hipEventDisableTiming));
+        }
+        ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1]; ev_wfork = ev_pairs[dev][2]; ev_wjoin = ev_pairs[dev][3];
+        ev_wdone0 = ev_pairs[dev][4]; ev_wdone1 = ev_pairs[dev][5];
+    }
+    // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
+    simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
+    const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
+    // Three forwards side by side (round 4).  The policy's no-grad forward over the next states (train.py:121) reads nothing the grad-mode
+    // forward (train.py:114) writes except the BatchNorm running statistics, which BOTH update (the policy net is in train mode) and no
+    // forward reads: it runs on a third stream from the start of the step with that update deferred -- its committing blocks leave
+    // [mean | unbiased variance] in fp64 (BnRef::defer) and one launch applies them behind the grad-mode forward's update, the same fp64
+    // expression on the same values in the reference's order: the buffers are bit-identical to the serial order's.  The transform-domain
+    // forwards alternate HBM-bound transforms and matrix-bound GEMMs; side by side the three fill each other's phases
+    // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN (its collectives order the streams); the plain
+    // data-parallel step has no collective before its backward pass and takes it.
+    const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync;
+    static thread_local hipStream_t third_streams[64] = {};
+    static thread_local hipEvent_t third_events[64] = {};
+    if (three) {
+        int dev = 0;
+        SIMQ_CHECK_HIP(hipGetDevice(&dev));
+        if (!third_streams[dev]) {
+            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&third_streams[dev], hipStreamNonBlocking));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&third_events[dev], hipEventDisableTiming));
+        }
+        hipStream_t third = third_streams[dev];
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
+        RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side));
+        SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
+        Ctx cn{p, Nn, a->params, nullptr, a->bnbuf, static_cast<char*>(a->ws_tmp), make_layout(p, Nn), third};
+        cn.wc = static_cast<char*>(const_cast<void*>(a->wcache)); cn.W = make_wlayout(p);
+        cn.defer_running = true;
+        RC(forward_impl(cn, SIMQ_MODE_TRAIN_NOGRAD, a->next_state, a->q_next));
+        RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, third));
+        SIMQ_CHECK_HIP(hipEventRecord(third_events[dev], third));
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, third_events[dev], 0));
+        RC(launch_bn_running_deferred(a->bnbuf, reinterpret_cast<const double*>(cn.ws + cn.L.defer), p->nbnbuf, main));     // update #2
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
+    } else {
+    if (g_fwd_overlap == 1 && side) {                      // (A-B: the target-net forward forked at the start of the step)
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
+    // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read.  It is
+    // forked BEHIND the policy's train-mode forward so that it overlaps the policy's next-state forward: both run on the
+    // ~29 non-final samples, whose tiles do not fill whole rounds of the CUs, and fill each other's tails (+1.7 % on the step
+    // over starting it beside the perfectly tiled 32-sample forward)
+    if (side && g_fwd_overlap != 1) {
+        SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    }
+    if (Nn > 0) {
+    RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side ? side : main));
+    if (side) SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
+    if (a->use_double_dqn) {                                                                                          // train.py:119-122
+        // (under SyncBN this forward normalises over the non-final next states of ALL ranks)
+        simq_sync sync_nf = sync_storage;
+        sync_nf.global_batch = a->global_nonfinal;
+        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN_NOGRAD, Nn, a->params, a->wcache, a->bnbuf, a->next_state, a->q_next, a->ws_tmp, main,
+                             sync ? &sync_nf : nullptr));
+        RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, main));
+        if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
+    } else {                                                                                                          // train.py:124
+        if (side) SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
+        RC(launch_q_argmax(a->q_tgt, Nn, n, nullptr, a->vals, main));
+    }
+    }
+    }
+    if (Nn == 0 && sync && a->use_double_dqn && a->global_nonfinal > 0) {     // all-terminal shard: zeros into the other ranks' reductions
+        simq_sync sync_nf = sync_storage;
+        sync_nf.global_batch = a->global_nonfinal;
+        RC(simq_forward_sync_null(p, 1, a->bnbuf, a->ws_tmp, main, &sync_nf));
+    }
+    RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
+    RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
+                       a->out4, a->dq, main));                                                                       // train.py:115,126-129
+    if (a->loss_host && !a->comm) RC(loss_copy(a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
+    const float gscale = 1.0f / (float)a->global_batch;
+    auto backward = [&](int phase) {                                                                                 // train.py:131-132
+        if (int rc = check_sync(sync, B)) return rc;
+        return backward_sync_side(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync,
+                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1);
+    };
+    if (!a->comm) {
+        RC(backward(0));
+    } else {
+        // data parallel (DataParallel's reduce-add, policies.py:39, as RCCL all-reduces): the head + layer4 bucket (75 % of the
+        // bytes) is final after phase 1 and travels on the communicator's stream while phase 2 differentiates layers 3..1 + stem
+        const int64_t split = simq_grad_bucket_split(p);
+        RC(backward(1));
+        RC(comm_allreduce(a->comm, a->grads + split, p->nparams - split, SIMQ_COMM_F32, main));
+        RC(backward(2));
+        RC(comm_allreduce(a->comm, a->grads, split, SIMQ_COMM_F32, main));
+        RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
+        RC(comm_wait(a->comm, main));
+        if (a->loss_host) RC(loss_copy(a->out4, a->loss_host, main, false));            // (summed over the ranks)
+    }
+    RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
+                       a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
+    return simq_weights_prepare(p, a->params, a->wcache, main);
+}
+
+int simq_tune_fwd_overlap(int on) {
+    g_fwd_overlap = (on >= 0 && on <= 2) ? on : 2;
+    return 0;
+}
+
+int64_t simq_grad_bucket_split(const simq_plan* plan) { return plan ? plan->blocks[kPhaseSplitBlock].c1.w_off : -1; }
+
+}  // extern "C"

@@ -864,7 +864,7 @@ def test_replay_push_stages_through_pinned_memory(simq_mod):
 
 def test_bf16_backward_agrees_across_its_storage_switches(simq_mod):
     """Plain-bf16 plans keep the activation gradients between the residual blocks' kernels in bf16, consume ReLU masks / residuals as
-    bf16 planes and fuse the BatchNorm-backward sums into the dgrad epilogues (plan.hip: Ctx::gbf, planes_only, fuse_block_out).  Each
+    bf16 planes and fuse the BatchNorm-backward sums into the dgrad epilogues (plan.h: Ctx::gbf, planes_only; backward.hip: fuse_block_out).  Each
     is a simq_plan_options field whose other setting falls back to the generic kernels (bf16_act_grads = 0: fp32 gradients,
     keep_fp32_activations = 1: fp32 activation copies, fuse_bn_backward_sums = 0: separate reduction launches).  One seeded train step
     in every combination that changes the kernels taken; variants that share a forward must give the same loss and gradients that
