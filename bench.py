@@ -81,11 +81,11 @@ def parse():
     ap.add_argument('--cin', type=int, default=None, help='override: input channels of a single Cout=2 net (tools only)')
     ap.add_argument('--plan-option', action='append', default=[], metavar='NAME=INT', help='tools only: a simq_plan_options override for every plan of the run (A/B), e.g. deterministic=1')
     ap.add_argument('--no-overlap', action='store_true', help='tools only: the target-net forward on the main stream instead of the side stream (A/B of the two-stream overlap)')
-    ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_wgrad_xcd_group, A/B')
-    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_tune_wgrad_overlap, A/B')
+    ap.add_argument('--wgrad-xcd-group', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_plan_options.wgrad_xcd_group of every plan, A/B')
+    ap.add_argument('--wgrad-overlap', type=int, default=None, choices=[0, 1, 2, 3, 4], help='tools only: simq_plan_options.wgrad_overlap of every plan, A/B')
     ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
-    ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_tune_fwd_overlap, A/B (2 = default: three forwards side by side)')
-    ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_tune_plane_xcd (batched GEMM planes per XCD), A/B')
+    ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_plan_options.fwd_overlap of every plan, A/B (2 = default: three forwards side by side)')
+    ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_plan_options.plane_xcd of every plan (batched GEMM planes per XCD), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
     ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
@@ -298,17 +298,14 @@ def main():
     from simq import dist as sdist, synth
     from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
     from simq.learner import _opt_state, train_step
-    if args.plane_xcd is not None:
-        lib.call('simq_tune_plane_xcd', args.plane_xcd)
+    # A/B switches are plan options (include/simq.h simq_plan_options): the library has no process-global state to flip
+    plan_opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.plan_option}
+    for name in ('plane_xcd', 'fwd_overlap', 'wgrad_overlap', 'wgrad_xcd_group'):
+        if getattr(args, name) is not None:
+            plan_opts[name] = getattr(args, name)
     if args.no_upload_stream:
         import simq.learner as _sl
         _sl.UPLOAD_STREAM = False
-    if args.fwd_overlap is not None:
-        lib.call('simq_tune_fwd_overlap', args.fwd_overlap)
-    if args.wgrad_overlap is not None:
-        lib.call('simq_tune_wgrad_overlap', args.wgrad_overlap)
-    if args.wgrad_xcd_group is not None:
-        lib.call('simq_tune_wgrad_xcd_group', args.wgrad_xcd_group)
     if args.no_overlap:
         import simq.learner as _sl
         _sl.OVERLAP_TARGET_FORWARD = False
@@ -388,7 +385,7 @@ def main():
             # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
             # stay O(1) so that many steps of synthetic training remain finite
             torch.manual_seed(20260928 + gi)
-            popt = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.plan_option} or None
+            popt = dict(plan_opts) or None
             policy = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
             target = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
             target.copy_state_from(policy)
@@ -497,16 +494,24 @@ def main():
         return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'B': B, 'gB': gB, 'n_nets': len(groups), 'sustained': sustained,
                 'm1': None if args.no_m1 else gB * len(groups) * steps / dt_m1, 'groups': groups}
 
-    def roofline_pass(step_fn, steps, precision, ms_per_step, per_gpu_rate):
+    def roofline_pass(step_fn, groups_of_step, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
         `steps` more steps with every stream overlap of the step off (target-net forward, the policy's no-grad forward and the weight
         gradients all on the launch stream), so that every bracket times one kernel ALONE on the device: a roofline fraction is a
         property of the kernel, and two kernels sharing the CUs each look slower than either is."""
         import simq.learner as slearner
+        from simq._lib import Plan
         keep = slearner.OVERLAP_TARGET_FORWARD
         slearner.OVERLAP_TARGET_FORWARD = False
-        lib.call('simq_tune_fwd_overlap', 0)
-        lib.call('simq_tune_wgrad_overlap', 0)
+        # a SECOND plan per net -- same network, same buffer layout, fwd_overlap = wgrad_overlap = 0 -- serves these steps: what a plan
+        # schedules is a property of the plan (simq_plan_options), nothing process-global is flipped
+        swapped = []
+        for g in groups_of_step:
+            for net in (g['policy'], g['target']):
+                solo = Plan(net.num_input_channels, net.num_output_channels, net.precision, dict(net.plan.options, fwd_overlap=0, wgrad_overlap=0))
+                assert solo.param_count == net.plan.param_count and solo.workspace_bytes(8) == net.plan.workspace_bytes(8)
+                swapped.append((net, net.plan))
+                net.plan = solo
         lib.call('simq_profile_start')
         barrier()
         t1 = time.perf_counter()
@@ -517,8 +522,9 @@ def main():
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
         slearner.OVERLAP_TARGET_FORWARD = keep
-        lib.call('simq_tune_fwd_overlap', 2 if args.fwd_overlap is None else args.fwd_overlap)
-        lib.call('simq_tune_wgrad_overlap', 4 if args.wgrad_overlap is None else args.wgrad_overlap)
+        torch.cuda.synchronize(dev)
+        for net, plan in swapped:
+            net.plan = plan
         dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # kind 0: the dominant kernel of the precision
         wg = {'launches': out[4], 'ms': out[5], 'flops': out[6], 'bytes': out[7]}       # kind 1: direct weight-gradient launches
         oth = {'launches': out[8], 'ms': out[9], 'flops': out[10], 'bytes': out[11]}    # kind 2: every other implicit-GEMM tile
@@ -573,7 +579,7 @@ def main():
     value, dt, info, gB = w['value'], w['dt'], w['info'], w['gB']
     roof = None
     if not args.no_roofline:
-        roof = roofline_pass(w['step'], args.steps, wl['precision'], dt / args.steps * 1e3, value / world)
+        roof = roofline_pass(w['step'], w['groups'], args.steps, wl['precision'], dt / args.steps * 1e3, value / world)
         ranks_roof = per_rank(roof)
         if ranks_roof is not None:
             roof['per_rank'] = ranks_roof
@@ -604,7 +610,7 @@ def main():
                       'fwd_bwd_only_ms_per_step': None if e['m1'] is None else round(e['dt_m1'] / args.steps * 1e3, 3), 'last_loss': e['info']['loss'],
                       'sustained': e['sustained']}
             if not args.no_roofline:
-                roof_x = roofline_pass(e['step'], args.steps, xl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
+                roof_x = roofline_pass(e['step'], e['groups'], args.steps, xl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
             release(e)
         except Exception as ex:       # the headline line must not depend on the second leg
             if pg is not None:

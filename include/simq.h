@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 301            /* 0.3.1 */
+#define SIMQ_VERSION 400            /* 0.4.0 */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -108,6 +108,29 @@ typedef struct simq_plan_options {
                                    * (tests/diag/diag_determinism.py): their fp64 accumulators round to the same fp32 value whatever the order. */
     int bn1_mask_from_preact;     /* 1 (plain-bf16 plans): the backward pass takes that ReLU mask from the saved pre-BN output (scale*y+shift > 0)
                                    * instead of reading the activation's plane -- one bf16 plane less in bn_bwd_apply and in the dgrad epilogue */
+    /* Round 5: what used to be process-global simq_tune_* switches.  A plan's result and its launch schedule depend on the plan alone. */
+    int wgrad_ksplit;             /* 0.  K-split of the transform-domain weight-gradient GEMMs (the wgrad half of loss.backward(), train.py:132, of the
+                                   * 128->256- and 256-channel 3x3 convolutions): 0 = chosen by shape, 1 = none, 2 / 4 = forced where the tile count
+                                   * divides.  Changes the SUMMATION ORDER of those gradients (fixed per setting: deterministic), nothing else. */
+    /* scheduling only (same kernels on the same operands; results are bit-identical for deterministic plans): */
+    int fwd_overlap;              /* 2.  Where simq_train_step forks its no-grad forwards (train.py:119-122).  2 = all three forwards side by side from
+                                   * the start of the step: the target net's on the side stream, the policy's no-grad forward on a third, plan-owned
+                                   * stream with its BatchNorm running-statistics update deferred and applied behind the grad-mode forward's, in the
+                                   * reference's order (bit-identical buffers); 0 = the target-net forward on the side stream behind the policy's
+                                   * grad-mode forward, the policy's no-grad forward on the main stream; 1 = as 0 with the target-net forward forked at
+                                   * the start of the step.  Steps under SyncBN keep form 0. */
+    int wgrad_overlap;            /* 4.  The weight gradient of every residual-block convolution runs on a side stream beside the dgrads of the walk --
+                                   * simq_train_step's side stream, or a plan-owned one (per device, destroyed with the plan) when a backward entry
+                                   * point is called on its own; the caller's stream is joined before the call returns its last launch.  fp32 plans:
+                                   * 4 = until the temporaries of the block are written again two blocks later (a second set of gradient temporaries
+                                   * in the workspace), 1 = until the end of the residual block, 3 = beside the dgrad of the same convolution only;
+                                   * 2 = as 1 for every precision (measured slower for bf16); 0 = behind the dgrad on the caller's stream: no hidden
+                                   * stream at all (graph capture, profilers that must see every launch on the caller's stream). */
+    int plane_xcd;                /* 1.  The batched transform-domain GEMMs of the Winograd layers walk whole transform elements per XCD; 0 = launch order */
+    int wgrad_xcd_group;          /* 1.  Pixel-split weight-gradient kernels place the tiles that share a pixel range on one XCD: 1 = the bf16 kernel
+                                   * only, 2 = the fp32 kernel too (measured slower there), 0 = launch order */
+    int tail_split;               /* 0.  fp32 implicit GEMM: balanced last round (K-sliced tail tiles + fix-up kernel); pays only when the forwards run
+                                   * serialised; changes the fp32 summation order of the sliced tiles */
 } simq_plan_options;
 void simq_plan_options_default(simq_plan_options* options);
 int simq_plan_create_opts(int num_input_channels, int num_output_channels, int precision, const simq_plan_options* options,
@@ -274,10 +297,11 @@ typedef struct simq_train_args {
                                   * loss.item() without waiting for backward + SGD, so that the next step is enqueued while this one runs */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
-/* blocks until the loss_host copy of the calling thread's last simq_train_step on the current device has landed.  The step's streams
- * must belong to the device that was current when simq_train_step was called (checked); per host thread and device the library keeps one
- * copy stream and two events for the life of the process. */
-int simq_train_loss_wait(void);
+/* blocks until the loss_host copy of the last simq_train_step of `plan` on the current device has landed.  The step's streams must belong
+ * to the device that was current when simq_train_step was called (checked).  The copy stream and its two events belong to the plan (one
+ * set per device, created on first use, destroyed by simq_plan_destroy) -- as do the third stream of fwd_overlap = 2 and the side stream
+ * of a backward pass called on its own (wgrad_overlap).  A plan is used by one host thread at a time. */
+int simq_train_loss_wait(const simq_plan* plan);
 
 /* ---- gradient exchange between data-parallel ranks (replaces the reduce-add of nn.DataParallel, policies.py:39) --------------
  * One process per GPU; RCCL (librccl.so.1, bound at run time) over xGMI.  Rank 0 obtains a SIMQ_COMM_ID_BYTES identifier and
@@ -317,23 +341,36 @@ int simq_sigmoid_concat(const float* d_state, const float* d_logit, float* d_out
 int simq_nchw_to_nhwc(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);
 int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, int hw, void* stream);
 
-/* ---- single-op entry points (unit-test surface; same kernels the plan launches) ------------- */
+/* ---- single-op entry points (unit-test surface; same kernels the plan launches) -------------
+ * The convolution operators end in `const simq_launch_opts* opts` (NULL = what a default plan launches): kernel selection and block
+ * scheduling of THAT call -- the per-kernel parity tests force every tile of a launcher's menu through it (tests/test_gpu_ops.py),
+ * tools/ run their A/Bs through it.  The library keeps no process-global switch of any kind. */
+typedef struct simq_launch_opts {
+    int struct_bytes;             /* sizeof(simq_launch_opts), checked */
+    int force_bm, force_bn;       /* 0 / 0: the launcher's own rule; otherwise the block tile BM x BN of the launcher's menu (a tile the shape does
+                                   * not admit falls back to the rule) */
+    int tail_split;               /* as simq_plan_options.tail_split */
+    int plane_xcd;                /* as simq_plan_options.plane_xcd (1) */
+    int wgrad_xcd_group;          /* as simq_plan_options.wgrad_xcd_group (1) */
+    int wgrad_ksplit;             /* as simq_plan_options.wgrad_ksplit (0) */
+} simq_launch_opts;
+void simq_launch_opts_default(simq_launch_opts* opts);
 int simq_conv2d_fwd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                     int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
-                    double* d_stats /* NULL or [2*cout] zeroed */, void* stream);
+                    double* d_stats /* NULL or [2*cout] zeroed */, void* stream, const simq_launch_opts* opts);
 /* The same 3x3 / stride-1 / pad-1 convolution through the Winograd F(2x2,3x3) path (conv_winograd.hip: input transform,
  * 16 batched transform-domain GEMMs, output transform + epilogue), as the plan uses it for the 512-channel layers.
  * Requirements: hin, win even; cin % 16 == 0; cout % 64 == 0; cin / 4 and cout / 4 divide 256.
  * d_scratch: 16*cout*cin + 16*T*(cin+cout) floats, T = batch*(hin/2)*(win/2) (transformed weights | V | Mt). */
 int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                              int batch, int hin, int win, int cin, int cout,
-                             double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+                             double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream, const simq_launch_opts* opts);
 /* The same convolution in Winograd F(4x4,3x3) form (36 transform-domain GEMMs over a quarter of the tiles; interpolation points
  * {0, 1, -1, 1/2, -2, inf}): the form the plan uses for forwards nothing is differentiated through (target net, double-DQN argmax
  * forward, policy.step).  hin, win multiples of 4.  d_scratch: 36*cout*cin + 36*T4*(cin+cout) floats, T4 = batch*(hin/4)*(win/4). */
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,
                               int batch, int hin, int win, int cin, int cout,
-                              double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream);
+                              double* d_stats /* NULL or [2*cout] zeroed */, float* d_scratch, void* stream, const simq_launch_opts* opts);
 /* The plan's elementwise BatchNorm pass, on its own (per-kernel parity tests): train-mode nn.BatchNorm2d + residual + ReLU
  * (resnet.py:35-36,42-45) with the batch statistics GIVEN as [sum | sum of squares] over `rows` (what the producing convolution's
  * epilogue leaves):  out = [relu]( (y - mean) * invstd * gamma + beta  [+ res] ).
@@ -356,12 +393,12 @@ int simq_bn_relu_backward(const void* d_g, const void* d_mask, int mask_kind, co
  * 2: Winograd F(4x4,3x3) (3x3 / stride 1 / pad 1 geometries of simq_conv2d_fwd_winograd / _winograd4, same d_scratch; NULL for form 0). */
 int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_w_ohwi,
                               const float* d_bias, float* d_y, int batch, int hin, int win, int cin, int cout, int r, int s, int stride,
-                              int pad, int form, float* d_scratch, void* stream);
+                              int pad, int form, float* d_scratch, void* stream, const simq_launch_opts* opts);
 /* ... and that convolution's weight gradient, dW = dY^T * relu(y_pre * in_scale + in_shift) (the activation recomputed on load).
  * form 0: direct (cin % 64 == 0); 1: transform domain (geometry / d_scratch of simq_conv2d_wgrad_winograd). */
 int simq_conv2d_wgrad_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_dy, float* d_dw,
                                 int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
-                                float* d_scratch, void* stream);
+                                float* d_scratch, void* stream, const simq_launch_opts* opts);
 /* The encoder's first convolution (reference resnet.py:94: 7x7, stride 2, pad 3, cin -> 64, no bias) on the bf16 matrix cores with
  * the operands gathered straight from the fp32 NHWC input -- the form plain-bf16 plans use (stem_conv_bf16.hip).  7 * cin <= 63,
  * win a multiple of 32, hin even.  d_y: bf16 [batch][hin/2][win/2][64] (pre-BatchNorm, rounded once from the fp32 accumulators);
@@ -382,26 +419,26 @@ int simq_conv2d_wgrad_stem_bf16(const float* d_x, const uint16_t* d_dy, float* d
  * the tiles, G^T dU G); uses F(4x4,3x3) when hin, win are multiples of 4 and batch*(hin/4)*(win/4) is a multiple of 16.
  * d_scratch: 16*T*(cin+cout) + 36*cout*cin floats. */
 int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw_ohwi,
-                               int batch, int hin, int win, int cin, int cout, float* d_scratch, void* stream);
+                               int batch, int hin, int win, int cin, int cout, float* d_scratch, void* stream, const simq_launch_opts* opts);
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scratch, float* d_dx,
-                      int batch, int hin, int win, int cin, int cout, int r, int s, int pad, void* stream);
+                      int batch, int hin, int win, int cin, int cout, int r, int s, int pad, void* stream, const simq_launch_opts* opts);
 int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* zeroed by callee */,
                       int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad,
-                      void* stream);
+                      void* stream, const simq_launch_opts* opts);
 /* bf16 matrix-core variants: the fp32 inputs are split into bf16 planes in d_scratch first
  * (nplanes 1: plain bf16; 2: split-bf16 hi/lo, 3 MFMA products).  d_scratch: 2*(|x|+|w|) resp. 2*(|x|+|dy|) uint16. */
 int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y, int batch, int hin, int win,
                          int cin, int cout, int r, int s, int stride, int pad, int nplanes, void* d_scratch, double* d_stats,
-                         void* stream);
+                         void* stream, const simq_launch_opts* opts);
 int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
-                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream);
+                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream, const simq_launch_opts* opts);
 /* (the weight-gradient half of loss.backward(), train.py:132, of one nn.Conv2d.)  The same with d_slab =
  * simq_conv2d_wgrad_bf16_slab_bytes() of scratch: the image-tile weight-gradient kernel (3x3 on 24x24 maps, Cout %
  * 256 == 0, Cin % 32 == 0, >= 2 images per block) then leaves per-block partial tiles there and a second launch adds them in a fixed
  * order (deterministic) instead of fp32 atomics -- the form the plans use.  d_slab = NULL: as simq_conv2d_wgrad_bf16. */
 int64_t simq_conv2d_wgrad_bf16_slab_bytes(void);
 int simq_conv2d_wgrad_bf16_slab(const float* d_x, const float* d_dy, float* d_dw_ohwi, int batch, int hin, int win, int cin, int cout,
-                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream);
+                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream, const simq_launch_opts* opts);
 int simq_upsample2x_fwd(const float* d_in, float* d_out, int batch, int h, int w, int c, void* stream);
 int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int w, int c, void* stream);
 
@@ -412,36 +449,6 @@ int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int
  * {launches, total ms, total algorithmic flops (2*M*N*K), total algorithmic bytes}.  Not thread-safe. */
 int simq_profile_start(void);
 int simq_profile_stop(double* out, int max_kinds);
-/* tuning aid (tools/tune_conv.py): force the implicit-GEMM block tile BM x BN; bm = 0 restores the cost model */
-int simq_tune_force_tile(int bm, int bn);
-/* tuning aid: switch the fp32 implicit-GEMM kernel's balanced last round (K-sliced tail tiles + fix-up kernel) on (1) /
- * off (0); default off (it pays only when the forwards run serialised) */
-int simq_tune_tail_split(int on);
-/* tuning aid (A/B): the batched transform-domain GEMMs of the Winograd layers walk whole planes per XCD (1, default) or planes in launch
- * order with the per-plane tile remap of round 1 (0).  Scheduling only: results are bit-identical. */
-int simq_tune_plane_xcd(int on);
-/* tuning aid (A/B): the weight gradient of every residual-block convolution (the wgrad half of loss.backward(), train.py:132) runs on a
- * side stream beside the dgrads of the walk -- simq_train_step's side stream, or a library-owned one (per device and host thread) when a
- * backward entry point is called on its own; the caller's stream is joined before the call returns its last launch.  fp32 plans:
- * 4 (default) = until the temporaries of the block are written again two blocks later (a second set of gradient temporaries in the
- * workspace), 1 = until the end of the residual block, 3 = beside the dgrad of the same convolution only; 2 = as 1 for every precision
- * (measured slower for bf16); 0 = behind the dgrad on the caller's stream.  Same kernels on the same operands: results are bit-identical
- * for deterministic plans. */
-int simq_tune_wgrad_overlap(int on);
-/* tuning aid (A/B): where simq_train_step forks its no-grad forwards (train.py:119-122).  2 (default) = all three forwards side by side
- * from the start of the step: the target net's on the side stream, the policy's no-grad forward on a third (library-owned) stream with its
- * BatchNorm running-statistics update deferred and applied behind the grad-mode forward's, in the reference's order (bit-identical
- * buffers); 0 = the target-net forward on the side stream behind the policy's grad-mode forward, the policy's no-grad forward on the main
- * stream (round 1-3); 1 = as 0 with the target-net forward forked at the start of the step.  Steps under SyncBN keep form 0. */
-int simq_tune_fwd_overlap(int on);
-/* tuning aid (A/B): the pixel-split weight-gradient kernels (the wgrad half of loss.backward(), train.py:132) place the tiles that share
- * a pixel range on one XCD: 1 (default) = the bf16 kernel only, 2 = the fp32 kernel too (measured slower there), 0 = launch order.
- * Scheduling only. */
-int simq_tune_wgrad_xcd_group(int on);
-/* tuning aid (A/B): K-split of the transform-domain weight-gradient GEMMs (the wgrad half of loss.backward(), train.py:132, of the
- * 128->256- and 256-channel 3x3 convolutions): 0 = chosen by shape (default), 1 = none, 2 / 4 = forced where the tile count divides.
- * Changes the summation order of those gradients (fixed per setting: deterministic), nothing else. */
-int simq_tune_wgrad_ksplit(int splits);
 
 #ifdef __cplusplus
 }

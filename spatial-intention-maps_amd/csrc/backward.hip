@@ -34,7 +34,7 @@ int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const
 }
 
 int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int hin, const InBn& in = InBn()) {
-    ConvGeom g = geom(cv, c.B, hin);
+    ConvGeom g = geom(c.p, cv, c.B, hin);
     if (c.mc() && cv.wp_off >= 0) {
         SIMQ_REQUIRE(!in.on(), "conv_wgrad: BatchNorm-on-load exists for fp32 plans only");
         const uint16_t* xs[2] = {x.pl.hi, x.pl.lo ? x.pl.lo : x.pl.hi};
@@ -53,6 +53,7 @@ int conv_wgrad(const Ctx& c, const ConvL& cv, const Act& x, const Act& dy, int h
 int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const float* addend, int hin,
                const ConvEpilogue& fuse = ConvEpilogue(), int g_bf16 = 0) {
     ConvGeom g;
+    g.tune = c.p->tune();
     g.B = c.B; g.Hin = hin; g.Win = hin; g.Cin = cv.cout; g.Cout = cv.cin; g.Hout = hin; g.Wout = hin;
     g.R = cv.k; g.S = cv.k; g.stride = 1; g.pad = cv.k - 1 - cv.pad;
     ConvEpilogue e = fuse;
@@ -75,26 +76,24 @@ int conv_dgrad(const Ctx& c, const ConvL& cv, const Act& dy, float* dx, const fl
 
 namespace simq {
 
-int g_fwd_overlap = 2;     // simq_tune_fwd_overlap (A-B runs): where the no-grad forwards of simq_train_step are forked
-int g_wgrad_overlap = 4;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads on a side stream (4: up to one block behind)
-
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh) {
     const simq_plan* p = c.p;
     const Layout& L = c.L;
     const int B = c.B;
+    const int wov = p->opt.wgrad_overlap;      // simq_plan_options.wgrad_overlap (4: weight gradients up to one block behind the dgrads)
     // Weight gradient beside dgrad (round 4).  The two halves of a convolution's backward read the same dy and nothing of each other;
     // in the transform-domain form each is [HBM-bound transforms | matrix-bound GEMM | HBM-bound transform], so side by side one's
     // transforms run under the other's GEMM.  cw = this context on the side stream with its own Winograd scratch; fork() after dy is
     // final, join() before the buffer that holds dy is written again (the next BatchNorm backward of the walk).
     // fp32 plans only: the bf16 kernels of both halves hold 140-160 KB of LDS per block, two of them cannot share a CU, and side by side
     // they only take turns (measured: 13 893 -> 13 516 tr/s on configs[2]; fp32 configs[1] 3466 -> 3524 in the pairwise form below)
-    const bool ov = c.wstream != nullptr && (g_wgrad_overlap == 2 || ((g_wgrad_overlap == 1 || g_wgrad_overlap == 3 || g_wgrad_overlap == 4) && !c.mc()));
+    const bool ov = c.wstream != nullptr && (wov == 2 || ((wov == 1 || wov == 3 || wov == 4) && !c.mc()));
     // ... and in fp32 the gradient w.r.t. conv1's output (dy1) is formed IN PLACE over bn1's incoming gradient (an elementwise pass), so that
     // dy2 stays alive and conv2's weight gradient may run until the end of the block instead of until bn1's backward
-    const bool wide = ov && !c.mc() && g_wgrad_overlap != 3;       // (3: the pairwise form, A-B runs)
+    const bool wide = ov && !c.mc() && wov != 3;       // (3: the pairwise form, A-B runs)
     // ... and (4) with a second set of gradient temporaries the blocks alternate between, the main stream does not wait for a block's weight
     // gradients at the end of the block but only before the set is written again, two blocks later: the side stream runs up to one block behind
-    const bool piped = wide && g_wgrad_overlap == 4 && L.S2[0] >= 0 && c.ev_wdone[0] && c.ev_wdone[1];
+    const bool piped = wide && wov == 4 && L.S2[0] >= 0 && c.ev_wdone[0] && c.ev_wdone[1];
     Ctx cw = c;
     if (ov) { cw.stream = c.wstream; if (L.wino2 >= 0) cw.L.wino = L.wino2; }
     auto fork = [&]() -> int {
@@ -262,30 +261,29 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
 
 }  // namespace simq
 
-// Library-owned side stream + events for the weight-gradient overlap of a backward pass called on its own (simq_backward*,
-// FCN.backward): per device and host thread, created on first use.  fp32 plans only (the overlap is off for the matrix-core
-// precisions, see backward_impl); the calling thread's current device must be the stream's.
-struct BackwardSide { hipStream_t stream = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; };
-static thread_local BackwardSide g_backward_side[64];
+// Side stream + events for the weight-gradient overlap of a backward pass called on its own (simq_backward*, FCN.backward): the
+// plan's, per device (PlanStreams), created on first use and destroyed with the plan.  fp32 plans only (the overlap is off for the
+// matrix-core precisions, see backward_impl); wgrad_overlap = 0 keeps every launch on the caller's stream.
 static int attach_backward_side(Ctx& c) {
-    if (c.wstream || g_wgrad_overlap == 0 || (c.mc() && g_wgrad_overlap != 2)) return 0;
+    const int wov = c.p->opt.wgrad_overlap;
+    if (c.wstream || wov == 0 || (c.mc() && wov != 2)) return 0;
+    PlanStreams* ps = nullptr;
     int dev = 0;
-    SIMQ_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return 0;
+    RC(plan_streams(c.p, &ps, &dev));
+    if (!ps) return 0;
     if (c.stream) {
         hipDevice_t sdev = 0;
         SIMQ_CHECK_HIP(hipStreamGetDevice(c.stream, &sdev));
         if ((int)sdev != dev) return 0;      // (a stream of another device: no overlap rather than events on the wrong device)
     }
-    BackwardSide& r = g_backward_side[dev];
-    if (!r.stream) {
-        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-        for (int i = 0; i < 4; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    if (!ps->bwd_side) {
+        std::lock_guard<std::mutex> lk(c.p->mu);
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->bwd_side, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->bwd_ev[i], hipEventDisableTiming));
     }
-    c.wstream = r.stream; c.ev_wfork = r.ev[0]; c.ev_wjoin = r.ev[1]; c.ev_wdone[0] = r.ev[2]; c.ev_wdone[1] = r.ev[3];
+    c.wstream = ps->bwd_side; c.ev_wfork = ps->bwd_ev[0]; c.ev_wjoin = ps->bwd_ev[1]; c.ev_wdone[0] = ps->bwd_ev[2]; c.ev_wdone[1] = ps->bwd_ev[3];
     return 0;
 }
-
 
 namespace simq {
 // simq_backward_sync with the stream / events of the weight-gradient overlap (simq_train_step only: its side stream is idle by then)
@@ -344,11 +342,6 @@ int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream) {
     return simq_backward_phase(plan, batch, d_params, d_wcache, d_dq, d_grads, d_workspace, 0, stream);
-}
-
-int simq_tune_wgrad_overlap(int on) {
-    g_wgrad_overlap = (on >= 0 && on <= 4) ? on : 4;
-    return 0;
 }
 
 }  // extern "C"

@@ -43,9 +43,22 @@ int tune_env_int(const char* name, int dflt);
         }                                   \
     } while (0)
 
+// Kernel-selection / scheduling hints of one launch.  They never change WHAT is computed beyond the fp32 summation order.  There is no
+// process-global copy: a plan's launches carry the plan's (simq_plan_options, fixed at creation), a standalone operator's launch carries
+// the caller's simq_launch_opts (include/simq.h), and the defaults below are what both start from.
+struct LaunchTune {
+    int force_bm = 0, force_bn = 0;   // force one tile of a launcher's menu (0: the launcher's own rule); per-kernel tests and tools/
+    int tail_split = 0;               // conv_igemm.hip: balanced last round (measured step-negative)
+    int plane_xcd = 1;                // conv_igemm.hip, batched GEMMs: whole transform elements per XCD
+    int wgrad_xcd_group = 1;          // conv_wgrad*.hip: the tiles of a pixel range on one XCD -- 0 off, 1 the bf16 kernel only, 2 fp32 too
+    int wgrad_ksplit = 0;             // conv_winograd.hip: K-split of the transform-domain weight-gradient GEMMs -- 0 by shape, 1 / 2 / 4 forced
+                                      // (changes the summation order of those gradients: a plan option, never a run-time switch)
+};
+
 // One convolution as an implicit GEMM:  y[M][Cout] = im2col(x)[M][R*S*Cin] * w[Cout][R*S*Cin]^T
 struct ConvGeom {
     int B, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad;
+    LaunchTune tune;
     int M() const { return B * Hout * Wout; }
     int K() const { return R * S * Cin; }
 };
@@ -112,19 +125,13 @@ struct InBn {
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
 void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
 void prof_launch_end(hipStream_t stream);
-void tune_force_tile(int bm, int bn);   // conv_igemm.hip: force one tile of the menu (0 = automatic)
-void tune_tail_split(int on);           // conv_igemm.hip: balanced last round on / off
-void tune_wgrad_ksplit(int s);          // conv_winograd.hip: K-split of the transform-domain weight-gradient GEMMs, 0 = by shape (default), 1 / 2 / 4
-void tune_wgrad_xcd_group(int on);      // conv_wgrad.hip / conv_wgrad_bf16.hip: the tiles of a pixel range on one XCD, on (default) / off
-bool wgrad_xcd_group_enabled();
-void tune_plane_xcd(int on);            // conv_igemm.hip: batched GEMMs, whole planes per XCD on (default) / off
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream, const InBn& in = InBn());
 // conv_igemm.hip: `batch` independent row-major GEMMs y_g = x_g * w_g^T in one launch
 // ping-pong LDS-DMA form (gemm_f32_pp.hip): 1 = launch taken, 0 = shape not covered, < 0 error
 int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
-int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
+int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune = LaunchTune());
 // conv_winograd.hip: Winograd F(2x2,3x3) for the wide 3x3 layers; U = transformed weights [16][Cout][Cin]
 bool winograd_eligible(const ConvGeom& g);
 bool winograd_pays(int cin, int cout, long min_cc);
@@ -146,12 +153,12 @@ constexpr int64_t kWgradDetSlabFloats = 16 << 20;
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom& g, hipStream_t stream, const InBn& in = InBn(), float* det_slab = nullptr);
 int launch_wgrad_slab_sum(const float* slab, float* dw, int64_t n, int splits, hipStream_t stream);   // dw[e] = sum_s slab[s][e], s ascending
 // conv_wgrad.hip: `batch` independent dw_g = dy_g^T * x_g in one launch (dw zeroed by the caller)
-int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream);
+int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune = LaunchTune());
 bool winograd_wgrad_eligible(const ConvGeom& g);
 bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4);
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4 = true,
                                const InBn& in = InBn());
-int tune_forced_tile(int* bm, int* bn);   // 1 when a tile is forced
+int tune_forced_tile(const LaunchTune& t, int* bm, int* bn);   // 1 when a tile is forced (ablation build: also SIMQ_IGEMM_TILE=BMxBN)
 // bf16 / split-bf16 matrix-core paths: operands are bf16 planes (index 0 = hi, 1 = lo; nplanes 1 or 2), fp32 outputs
 int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2], int nplanes, float* y, const ConvGeom& g,
                            const ConvEpilogue& e, hipStream_t stream);

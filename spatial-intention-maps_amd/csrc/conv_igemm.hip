@@ -459,7 +459,7 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-// ---- balanced last round (opt-in: SIMQ_TAIL_SPLIT=1 / simq_tune_tail_split(1)) ----------------------------------------
+// ---- balanced last round (opt-in: LaunchTune::tail_split; SIMQ_TAIL_SPLIT=1 in the ablation build) ----------------------------------------
 // A launch of T tiles on S = 256 CUs x (resident blocks per CU) slots runs floor(T / S) full rounds and then a partial one
 // in which T mod S blocks have the chip to themselves: a 29-sample next-state batch through a 512-channel layer is 1392
 // tiles of 96x64 on 1280 slots, i.e. 112 CUs end with ONE block (4 waves).  With this switch the tiles of that last round
@@ -489,9 +489,7 @@ float* tail_scratch(hipStream_t stream) {
     return static_cast<float*>(ptr);
 }
 
-int g_xcd_remap = -1;    // SIMQ_XCD_REMAP=0: tiles in launch order (A-B runs)
-int g_plane_xcd = 1;     // batched launches: whole planes per XCD (simq_tune_plane_xcd)
-int g_tail_split = -1;   // SIMQ_TAIL_SPLIT=1 switches the balanced last round on
+int g_xcd_remap = -1;    // SIMQ_XCD_REMAP=0: tiles in launch order (A-B runs, ablation build)
 
 template <int BM, int BN, bool VEC, bool BATCHED = false>
 int resident_blocks() {
@@ -508,7 +506,7 @@ int resident_blocks() {
 }
 
 template <int BM, int BN, bool VEC, bool BATCHED = false>
-int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
+int run(const IgemmArgs& a, hipStream_t stream, const LaunchTune& tune, int batch = 1) {
     if constexpr (!VEC || BATCHED) {
         SIMQ_REQUIRE(!a.in.on(), "conv_igemm: BatchNorm-on-load needs the vector loader (Cin %% 16 == 0) of a single convolution");
     }
@@ -519,13 +517,14 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     p.full_tiles = tiles; p.splits = 1; p.kper = 0; p.partial = nullptr;
     int tail = 0;
     if constexpr (VEC && !BATCHED) {
-        if (g_tail_split < 0) g_tail_split = SIMQ_TUNE_INT("SIMQ_TAIL_SPLIT", 0) != 0 ? 1 : 0;
+        static const int env_tail_split = SIMQ_TUNE_INT("SIMQ_TAIL_SPLIT", 0) != 0 ? 1 : 0;      // (ablation build only)
+        const int tail_split = tune.tail_split != 0 ? 1 : env_tail_split;
         const int slots = kNumCU * resident_blocks<BM, BN, VEC>();
         const int rem = tiles % slots, nk = p.K / BK;
         // worth it when the last round leaves a CU with one or two blocks (three or more co-resident blocks already keep the
         // matrix pipe busy: slicing a half-full round of the 64x64 tile measured 4 % slower) and a slice still has a
         // pipeline's worth of K-steps
-        if (g_tail_split && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
+        if (tail_split && tiles > slots && rem > 0 && rem * 2 <= kNumCU * 3) {
             int s = slots / rem;
             if (s > kMaxTailSplits) s = kMaxTailSplits;
             while (s > 1 && nk / s < 24) --s;
@@ -555,7 +554,7 @@ int run(const IgemmArgs& a, hipStream_t stream, int batch = 1) {
     if constexpr (BATCHED) {
         const int rem = batch & 7;
         const bool rem_ok = rem == 0 || ((rem == 1 || rem == 2 || rem == 4) && p.full_tiles % (8 / rem) == 0);
-        if (g_plane_xcd && g_xcd_remap && batch >= 8 && rem_ok && ((long)p.full_tiles * batch) % 8 == 0) p.plane_xcd = 1;
+        if (tune.plane_xcd && g_xcd_remap && batch >= 8 && rem_ok && ((long)p.full_tiles * batch) % 8 == 0) p.plane_xcd = 1;
     }
     dim3 grid((unsigned)(p.full_tiles + tail * p.splits), (unsigned)batch);
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
@@ -591,23 +590,26 @@ constexpr TileCfg kMenu[] = {
     {128, 32, 0.86f, 0.915f}, {64, 32, 0.86f, 0.877f},  {32, 64, 0.86f, 0.854f}, {96, 32, 0.84f, 0.882f}, {128, 128, 0.75f, 0.70f},
     {32, 32, 0.72f, 0.75f},
 };
-int g_forced_bm = -1, g_forced_bn = -1;   // tuning aid (tools/tune_conv.py): simq_tune_force_tile(), or SIMQ_IGEMM_TILE=BMxBN in the ablation build
-
-int forced_tile(int* bm, int* bn) {
-    if (g_forced_bm == -1) {
-        g_forced_bm = 0;
+// a forced tile: LaunchTune::force_bm / force_bn of the launch (simq_launch_opts of a standalone operator call: per-kernel tests,
+// tools/tune_conv.py), or SIMQ_IGEMM_TILE=BMxBN in the ablation build
+int forced_tile(const LaunchTune& t, int* bm, int* bn) {
+    if (t.force_bm > 0) { *bm = t.force_bm; *bn = t.force_bn; return 1; }
 #ifdef SIMQ_ABLATIONS
+    static int env_bm = -1, env_bn = 0;
+    if (env_bm == -1) {
+        env_bm = 0;
         const char* s = getenv("SIMQ_IGEMM_TILE");
-        if (s && sscanf(s, "%dx%d", &g_forced_bm, &g_forced_bn) != 2) g_forced_bm = 0;
-#endif
+        if (s && sscanf(s, "%dx%d", &env_bm, &env_bn) != 2) env_bm = 0;
     }
-    *bm = g_forced_bm; *bn = g_forced_bn;
-    return g_forced_bm > 0;
+    if (env_bm > 0) { *bm = env_bm; *bn = env_bn; return 1; }
+#endif
+    *bm = 0; *bn = 0;
+    return 0;
 }
 
 template <bool VEC>
-int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream) {
-#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream)
+int dispatch(int bm, int bn, const IgemmArgs& a, hipStream_t stream, const LaunchTune& tune) {
+#define SIMQ_TILE(BM_, BN_) if (bm == BM_ && bn == BN_) return run<BM_, BN_, VEC>(a, stream, tune)
     if constexpr (VEC) {
         SIMQ_TILE(128, 128); SIMQ_TILE(96, 128); SIMQ_TILE(64, 128); SIMQ_TILE(128, 64); SIMQ_TILE(96, 64);
         SIMQ_TILE(64, 64); SIMQ_TILE(128, 32); SIMQ_TILE(96, 32); SIMQ_TILE(64, 32); SIMQ_TILE(32, 64); SIMQ_TILE(32, 32);
@@ -639,10 +641,11 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
     const bool vec = (g.Cin % BK) == 0 && g.R * g.S <= 32;   // vector path: 16-channel chunks, tap validity kept as a 32-bit mask
     SIMQ_REQUIRE(vec || g.Cout % 64 == 0, "conv_igemm (generic gather): Cout=%d must be a multiple of 64", g.Cout);
     int bm = 0, bn = 0;
-    if (!forced_tile(&bm, &bn)) {        // the 64-input-channel 3x3 layers on the 24x24 maps: image-tile kernel (conv_img_f32.hip)
+    const bool forced = forced_tile(g.tune, &bm, &bn) != 0;
+    if (!forced) {                       // the 64-input-channel 3x3 layers on the 24x24 maps: image-tile kernel (conv_img_f32.hip)
         if (int rc = try_conv_img_f32(x, w, y, g, e, stream, in)) return rc < 0 ? rc : 0;
     }
-    if (!forced_tile(&bm, &bn) || g.Cout % bn != 0 || (!vec && !(bn == 64 && (bm == 128 || bm == 64 || bm == 32)))) {
+    if (!forced || g.Cout % bn != 0 || (!vec && !(bn == 64 && (bm == 128 || bm == 64 || bm == 32)))) {
         double best = 1e300;
         for (const TileCfg& t : kMenu) {
             if (g.Cout % t.bn != 0) continue;
@@ -654,12 +657,12 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
             if (cost < best) { best = cost; bm = t.bm; bn = t.bn; }
         }
     }
-    return vec ? dispatch<true>(bm, bn, a, stream) : dispatch<false>(bm, bn, a, stream);
+    return vec ? dispatch<true>(bm, bn, a, stream, g.tune) : dispatch<false>(bm, bn, a, stream, g.tune);
 }
 
 // `batch` independent GEMMs  y_g[M][N] = x_g[M][K] * w_g[N][K]^T  (row-major, g-th operand at base + g * rows * cols) in one
 // launch (grid.y = batch): the transform-domain contractions of conv_winograd.hip.  K % 16 == 0, N % 64 == 0.
-int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream) {
+int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune) {
     SIMQ_REQUIRE(M > 0 && K % BK == 0 && N % 64 == 0 && batch >= 1, "gemm_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
 #ifdef SIMQ_ABLATIONS      // the opt-in ping-pong form (gemm_f32_pp.hip, step-neutral: DESIGN 4) exists in libsimq_ablate.so only
     if (int rc = try_gemm_batched_pp(x, w, y, M, N, K, batch, stream)) return rc < 0 ? rc : 0;     // (N % 128 == 0)
@@ -681,19 +684,13 @@ int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, 
 #ifdef SIMQ_ABLATIONS      // tile A/B for the transform-domain GEMMs (tools/ab_step.py): SIMQ_GEMM_BATCHED_TILE=96 | 128 (rows; 64 columns).
     // Whole fp32 step, three alternating runs each: 64 rows 3320 tr/s, 96 rows 3267, 128 rows 3269 -- the 64x64 tile stays.
     static const int bt = SIMQ_TUNE_INT("SIMQ_GEMM_BATCHED_TILE", 64);
-    if (bt == 96 && M % 96 == 0) return run<96, 64, true, true>(a, stream, batch);
-    if (bt == 128 && M % 128 == 0) return run<128, 64, true, true>(a, stream, batch);
+    if (bt == 96 && M % 96 == 0) return run<96, 64, true, true>(a, stream, tune, batch);
+    if (bt == 128 && M % 128 == 0) return run<128, 64, true, true>(a, stream, tune, batch);
 #endif
-    return run<64, 64, true, true>(a, stream, batch);
+    return run<64, 64, true, true>(a, stream, tune, batch);
 }
 
-int tune_forced_tile(int* bm, int* bn) { return forced_tile(bm, bn); }
-
-void tune_tail_split(int on) { g_tail_split = on ? 1 : 0; }
-
-void tune_plane_xcd(int on) { g_plane_xcd = on ? 1 : 0; }
-
-void tune_force_tile(int bm, int bn) { g_forced_bm = bm > 0 ? bm : 0; g_forced_bn = bn; }
+int tune_forced_tile(const LaunchTune& t, int* bm, int* bn) { return forced_tile(t, bm, bn); }
 
 int launch_weight_transpose(const float* w, float* wt, int cout, int taps, int cin, hipStream_t stream) {
     size_t total = (size_t)cout * taps * cin;

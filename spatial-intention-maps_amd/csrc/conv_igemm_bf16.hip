@@ -291,6 +291,7 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     a.Hin = g.Hin; a.Win = g.Win; a.Cin = g.Cin; a.Hout = g.Hout; a.Wout = g.Wout; a.Cout = g.Cout;
     a.R = g.R; a.S = g.S; a.stride = g.stride; a.pad = g.pad;
     a.M = g.M(); a.K = g.K(); a.tilesN = 0;
+    a.force_bm = g.tune.force_bm; a.force_bn = g.tune.force_bn;
     SIMQ_REQUIRE(a.M > 0, "conv: empty problem");
     const double xb = 2.0 * g.B * g.Hin * g.Win * g.Cin, wb = 2.0 * g.Cout * a.K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0, "conv_igemm_bf16: tensor exceeds the 4 GiB buffer-addressing limit");
@@ -299,7 +300,7 @@ int launch_conv_igemm_bf16(const uint16_t* const x[2], const uint16_t* const w[2
     SIMQ_REQUIRE(g.Cout % 32 == 0 && g.Cin % 32 == 0, "conv_igemm_bf16: Cin=%d Cout=%d must be multiples of 32", g.Cin, g.Cout);
     int bm = 0, bn = 0;
     int fbm = 0, fbn = 0;
-    if (tune_forced_tile(&fbm, &fbn) && g.Cout % fbn == 0) { bm = fbm; bn = fbn; }
+    if (bf16_forced_tile(a, &fbm, &fbn) && g.Cout % fbn == 0) { bm = fbm; bn = fbn; }
     else {
         double best = 1e300;
         for (const TileCfg& t : kMenu) {

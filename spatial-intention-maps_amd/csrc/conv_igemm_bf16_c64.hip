@@ -130,7 +130,7 @@ int try_conv_igemm_bf16_c64(const IgemmBfArgs& a, hipStream_t stream) {
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_C64", 1);   // 0 = off (ablation build)
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
-    const bool forced = tune_forced_tile(&fbm, &fbn);
+    const bool forced = bf16_forced_tile(a, &fbm, &fbn);
     if (forced && !(fbm == BM && fbn == BN)) return 0;
     const long blocks = (long)(a.M / BM) * (a.Cout / BN);
     if (!forced && blocks < 200) return 0;                      // one block per CU: needs (nearly) all of them

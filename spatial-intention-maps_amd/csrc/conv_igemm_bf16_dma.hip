@@ -287,7 +287,7 @@ int try_conv_igemm_bf16_dma(const IgemmBfArgs& a, hipStream_t stream) {
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_DMA", 1);   // 0 = off
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
-    if (tune_forced_tile(&fbm, &fbn)) return (a.Cout % fbn == 0) ? dispatch(fbm, fbn, a, stream) : 0;
+    if (bf16_forced_tile(a, &fbm, &fbn)) return (a.Cout % fbn == 0) ? dispatch(fbm, fbn, a, stream) : 0;
     // Measured on MI355X (tools/bf16_tiles.py, B = 32 / 29): the 288x128 eight-wave tile wins where it fills whole rounds
     // of the 256 CUs -- the 512-channel layers (95 vs 132 us on layer4's 3x3, 92 vs 130 us at 29 samples); on the
     // 256/128-channel layers the register-staged 96-row tiles (3-4 blocks per CU) stay ahead, so only that case is taken.

@@ -298,7 +298,7 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     if (mode == 2) { if (int rc = try_conv_igemm_bf16_img4(a, stream)) return rc; }
 #endif
     int fbm = 0, fbn = 0;
-    const bool forced = tune_forced_tile(&fbm, &fbn);
+    const bool forced = bf16_forced_tile(a, &fbm, &fbn);
     // (forced tiles, tests / tools: "576 x 128" = whole maps; "1288 x 128" = half maps -- 288 x 128 itself names the LDS-DMA kernel's tile)
     constexpr int kForcedHalf = 1288;
     if (forced && !((fbm == HW * HW || fbm == kForcedHalf) && fbn == BN)) return 0;

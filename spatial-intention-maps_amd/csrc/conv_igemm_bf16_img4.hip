@@ -251,7 +251,7 @@ int try_conv_igemm_bf16_img4(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.Hin != HW || a.Win != HW || a.Hout != HW || a.Wout != HW) return 0;
     if (a.Cin % (2 * BK) != 0 || a.Cout % BN != 0 || a.M % BM != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
     int fbm = 0, fbn = 0;
-    const bool forced = tune_forced_tile(&fbm, &fbn);
+    const bool forced = bf16_forced_tile(a, &fbm, &fbn);
     if (forced && !(fbm == BM && fbn == BN)) return 0;
     const long blocks = (long)(a.M / BM) * (a.Cout / BN);
     const long rounds = (blocks + 255) / 256;

@@ -217,7 +217,7 @@ int try_conv_igemm_bf16_pp(const IgemmBfArgs& a, hipStream_t stream) {
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_PP", 1);   // 0 = off
     if (mode == 0) return 0;
     int fbm = 0, fbn = 0;
-    const bool forced = tune_forced_tile(&fbm, &fbn);
+    const bool forced = bf16_forced_tile(a, &fbm, &fbn);
     if (forced && !(fbm == BM && fbn == BN)) return 0;
     const long tilesM = (a.M + BM - 1) / BM;
     const long blocks = tilesM * (a.Cout / BN);

@@ -263,10 +263,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     }
 }
 
-int g_wgrad_xcd_group = 1;   // tiles of a pixel range on one XCD: 0 off, 1 the bf16 kernel only (default), 2 fp32 too (simq_tune_wgrad_xcd_group)
-
 template <int TI, int TJ, int WI, int WJ, bool VEC>
-int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
+int run(const WgradArgs& a, hipStream_t stream, const LaunchTune& tune, int batch = 1) {
     static_assert(256 % (TJ / 4) == 0, "a lane keeps its channel quad across the passes of the x loader");
     WgradArgs p = a;
     p.tilesI = p.Cout / TI;
@@ -300,10 +298,10 @@ int run(const WgradArgs& a, hipStream_t stream, int batch = 1) {
     splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
     p.splits = splits;
-    // fp32: measured and left OFF by default (2 = forced on, A-B runs): three alternating bench pairs each on two boxes, 3453 -> 3435 and
+    // fp32: measured and left OFF by default (LaunchTune::wgrad_xcd_group == 2 forces it on, A-B runs): three alternating bench pairs each on two boxes, 3453 -> 3435 and
     // 3382 -> 3361 tr/s with the grouping, with or without the stagger -- the fp32 launches are short (22-72 us, 18 MB of operands at
     // B = 32) and are not bound by their L2 misses, unlike the bf16 kernel's at B = 128 (conv_wgrad_bf16.hip: 237 -> 63 MB, + 0.5-1 %)
-    p.xcd_group = (g_wgrad_xcd_group == 2 && batch == 1 && splits >= 8 && tiles > 1) ? 1 : 0;
+    p.xcd_group = (tune.wgrad_xcd_group == 2 && batch == 1 && splits >= 8 && tiles > 1) ? 1 : 0;
     const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
@@ -329,9 +327,6 @@ __global__ void __launch_bounds__(256) wgrad_slab_sum_kernel(const float* __rest
 }
 
 }  // namespace
-
-void tune_wgrad_xcd_group(int on) { g_wgrad_xcd_group = (on == 2) ? 2 : (on ? 1 : 0); }
-bool wgrad_xcd_group_enabled() { return g_wgrad_xcd_group != 0; }
 
 int launch_wgrad_slab_sum(const float* slab, float* dw, int64_t n, int splits, hipStream_t stream) {
     int blocks = (int)((n + 255) / 256);
@@ -361,21 +356,21 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, const ConvGeom
     if (vec) {
         if (g.Cout % 128 == 0) {
             // few 128x128 tiles (the 128-channel layers: 9) would need a very deep pixel split; 64x64 tiles measured 62 vs 77 us
-            if (g.Cin % 128 == 0) return (g.Cout / 128) * (g.R * g.S * g.Cin / 128) >= 16 ? run<128, 128, 2, 2, true>(a, stream)
-                                                                                            : run<64, 64, 2, 2, true>(a, stream);
-            return run<128, 64, 2, 2, true>(a, stream);
+            if (g.Cin % 128 == 0) return (g.Cout / 128) * (g.R * g.S * g.Cin / 128) >= 16 ? run<128, 128, 2, 2, true>(a, stream, g.tune)
+                                                                                            : run<64, 64, 2, 2, true>(a, stream, g.tune);
+            return run<128, 64, 2, 2, true>(a, stream, g.tune);
         }
-        if (g.Cout % 64 == 0) return run<64, 64, 2, 2, true>(a, stream);
-        if (g.Cin % 128 == 0) return run<32, 128, 1, 4, true>(a, stream);
+        if (g.Cout % 64 == 0) return run<64, 64, 2, 2, true>(a, stream, g.tune);
+        if (g.Cin % 128 == 0) return run<32, 128, 1, 4, true>(a, stream, g.tune);
         SIMQ_REQUIRE(false, "conv_wgrad: unsupported Cout=%d Cin=%d", g.Cout, g.Cin);
     }
     SIMQ_REQUIRE(g.Cout % 64 == 0, "conv_wgrad (generic gather): Cout=%d must be a multiple of 64", g.Cout);
-    return run<64, 64, 2, 2, false>(a, stream);
+    return run<64, 64, 2, 2, false>(a, stream, g.tune);
 }
 
 // `batch` independent contractions over the rows  dw_g[N][K] += dy_g[M][N]^T * x_g[M][K]  (row-major operands, g-th at
 // base + g * rows * cols; dw zeroed by the caller) in one launch: the transform-domain weight gradients of conv_winograd.hip.
-int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream) {
+int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune) {
     SIMQ_REQUIRE(M > 0 && N % 128 == 0 && K % 128 == 0 && batch >= 1, "wgrad_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
     WgradArgs a;
     a.x = x; a.dy = dy; a.dw = dw;
@@ -387,7 +382,7 @@ int launch_wgrad_batched(const float* x, const float* dy, float* dw, int M, int 
     const double xb = 4.0 * M * K, yb = 4.0 * M * N;
     SIMQ_REQUIRE(xb < 4294967000.0 && yb < 4294967000.0, "wgrad_batched: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    return run<128, 128, 2, 2, true>(a, stream, batch);
+    return run<128, 128, 2, 2, true>(a, stream, tune, batch);
 }
 
 }  // namespace simq

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256, NP == 1 ? 3 : 2) wgrad_bf16_kernel(const 
 }
 
 template <int TI, int TJ, int NP>
-int run(const WgradBfArgs& a, hipStream_t stream) {
+int run(const WgradBfArgs& a, hipStream_t stream, int tune_xcd_group) {
     WgradBfArgs p = a;
     p.tilesI = p.Cout / TI;
     p.tilesJ = p.R * p.S * (p.Cin / TJ);
@@ -285,7 +285,7 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
     p.rows_per_split = rps;
     p.splits = splits;
     static const int group_env = SIMQ_TUNE_INT("SIMQ_WGRAD_BF16_XCD_GROUP", 1);      // (ablation build: 0 = launch order)
-    p.xcd_group = (group_env && wgrad_xcd_group_enabled() && splits >= 8 && tiles > 1) ? 1 : 0;
+    p.xcd_group = (group_env && tune_xcd_group != 0 && splits >= 8 && tiles > 1) ? 1 : 0;
     const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
@@ -298,13 +298,13 @@ int run(const WgradBfArgs& a, hipStream_t stream) {
 }
 
 template <int NP>
-int dispatch(const WgradBfArgs& a, hipStream_t stream) {
+int dispatch(const WgradBfArgs& a, hipStream_t stream, int tune_xcd_group) {
     if (a.Cout % 128 == 0) {
-        if (a.Cin % 128 == 0) return run<128, 128, NP>(a, stream);
-        if (a.Cin % 64 == 0) return run<128, 64, NP>(a, stream);
+        if (a.Cin % 128 == 0) return run<128, 128, NP>(a, stream, tune_xcd_group);
+        if (a.Cin % 64 == 0) return run<128, 64, NP>(a, stream, tune_xcd_group);
     }
-    if (a.Cout % 64 == 0 && a.Cin % 64 == 0) return run<64, 64, NP>(a, stream);
-    if (a.Cout % 32 == 0 && a.Cin % 128 == 0) return run<32, 128, NP>(a, stream);
+    if (a.Cout % 64 == 0 && a.Cin % 64 == 0) return run<64, 64, NP>(a, stream, tune_xcd_group);
+    if (a.Cout % 32 == 0 && a.Cin % 128 == 0) return run<32, 128, NP>(a, stream, tune_xcd_group);
     set_error("conv_wgrad_bf16: unsupported Cout=%d Cin=%d", a.Cout, a.Cin);
     return -1;
 }
@@ -335,7 +335,7 @@ int launch_conv_wgrad_bf16(const uint16_t* const x[2], const uint16_t* const dy[
             if (took != 0) return took < 0 ? took : 0;
         }
     }
-    return nplanes == 2 ? dispatch<2>(a, stream) : dispatch<1>(a, stream);
+    return nplanes == 2 ? dispatch<2>(a, stream, g.tune.wgrad_xcd_group) : dispatch<1>(a, stream, g.tune.wgrad_xcd_group);
 }
 
 }  // namespace simq

@@ -752,7 +752,7 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     if (in.on()) hipLaunchKernelGGL(wino_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in);
     else hipLaunchKernelGGL(wino_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T, in);
     SIMQ_CHECK_LAUNCH();
-    if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream)) return rc;
+    if (int rc = launch_gemm_batched(V, U, Mt, T, g.Cout, g.Cin, 16, stream, g.tune)) return rc;
     int bout = (T + tpb_out - 1) / tpb_out;
     // statistics: few blocks, one fp64 atomic per channel and block (the step is insensitive to this cap from 256 to 2048)
     bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 512 : 4096);
@@ -793,7 +793,7 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     if (in.on()) hipLaunchKernelGGL(wino4f_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
     else hipLaunchKernelGGL(wino4f_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
     SIMQ_CHECK_LAUNCH();
-    if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream)) return rc;
+    if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream, g.tune)) return rc;
     int bout = (T4 + tpb_out - 1) / tpb_out;
     // F(4x4,3x3) has a quarter of the tiles: at 512 channels a block is two tiles and B = 32 gives 576 blocks -- capped at 512, sixty-four
     // blocks did two grid-stride trips while the rest did one (the launch took the time of two).  Up to 1024 blocks, equal trips each.
@@ -819,10 +819,6 @@ bool winograd_wgrad_pays(const ConvGeom& g, bool allow_f4) {
     return (long)g.Cin * g.Cout >= ((allow_f4 && winograd_wgrad_f4(g)) ? 128L * 256 : 256L * 256);
 }
 
-int g_wgrad_ksplit = 0;   // 0: by shape; 1 / 2 / 4: forced (simq_tune_wgrad_ksplit, A-B runs)
-
-void tune_wgrad_ksplit(int s) { g_wgrad_ksplit = (s == 1 || s == 2 || s == 4) ? s : 0; }
-
 int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const ConvGeom& g, float* scratch, hipStream_t stream, bool allow_f4,
                                const InBn& in) {
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv_wgrad_winograd: geometry not supported");
@@ -839,19 +835,20 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         // documented scratch the F(4x4,3x3) operands leave free.
         int S = 1;
         {
+            const int ksplit = (g.tune.wgrad_ksplit == 1 || g.tune.wgrad_ksplit == 2 || g.tune.wgrad_ksplit == 4) ? g.tune.wgrad_ksplit : 0;   // 0: by shape
             const long blocks = 36L * (g.Cout / 64) * (g.Cin / 64);
             const long room = (long)winograd_scratch_floats(g) - 36L * T4 * (g.Cin + g.Cout);      // floats behind the operands, beside dU4's own 36 planes
             for (int cand = 4; cand >= 2; cand >>= 1) {
-                if (g_wgrad_ksplit > 0 && cand != g_wgrad_ksplit) continue;
+                if (ksplit > 0 && cand != ksplit) continue;
                 const bool fits = T4 % (cand * 32) == 0 && 36L * (cand - 1) * g.Cout * g.Cin <= room;
                 // by shape (tools/wgrad_ksplit_check.py, whole launch sequence, S = 1 | 2 | 4): B = 32 256 -> 256 108 | 104 | 119 us,
                 // 128 -> 256 87 | 83 | 94; B = 128 256 -> 256 370 | 332 | 338, 128 -> 256 268 | 231 | 229, 256 -> 512 555 | 526 | 548;
                 // 512 -> 512 (2304 blocks) loses at every batch size -- shorter chains only pay while the CUs are short of blocks
                 const int kc = T4 / cand;
                 const bool pays = cand == 4 ? (blocks <= 288 && kc >= 1152) : ((blocks <= 576 && kc >= 512) || (blocks <= 1152 && kc >= 1152));
-                if (fits && (g_wgrad_ksplit > 0 || pays)) { S = cand; break; }
+                if (fits && (ksplit > 0 || pays)) { S = cand; break; }
             }
-            if (g_wgrad_ksplit == 1) S = 1;
+            if (ksplit == 1) S = 1;
         }
         const int Kc = T4 / S;
         float* Vt4 = scratch;                                   // [36][S][Cin][Kc]
@@ -862,7 +859,7 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         else hipLaunchKernelGGL((wino4_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt4, g.B, g.Hin, g.Win, g.Cin, T4, in, Kc, S);
         hipLaunchKernelGGL((wino4_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt4, g.B, g.Hin, g.Win, g.Cout, T4, InBn(), Kc, S);
         SIMQ_CHECK_LAUNCH();
-        if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, Kc, 36 * S, stream)) return rc;
+        if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, Kc, 36 * S, stream, g.tune)) return rc;
         int blocks4 = (g.Cout * g.Cin + 255) / 256;
         if (blocks4 > 2048) blocks4 = 2048;
         hipLaunchKernelGGL(wino4_dw_kernel, dim3(blocks4), dim3(256), 0, stream, dU4, dw, g.Cout, g.Cin, S);
@@ -880,7 +877,7 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         hipLaunchKernelGGL(wino_dy_kernel, dim3(bout), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T);
         SIMQ_CHECK_LAUNCH();
         SIMQ_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)g.Cout * g.Cin, stream));
-        if (int rc = launch_wgrad_batched(Vt, dMt, dU, T, g.Cout, g.Cin, 16, stream)) return rc;
+        if (int rc = launch_wgrad_batched(Vt, dMt, dU, T, g.Cout, g.Cin, 16, stream, g.tune)) return rc;
     } else {
         // tile index contiguous: dU[g] = dMt[g] (Cout x T) * Vt[g]^T (T x Cin) is a K-contiguous GEMM with K = T
         const int tb = (T + 31) / 32;
@@ -888,7 +885,7 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         else hipLaunchKernelGGL((wino_tr_kernel<false>), dim3((unsigned)(tb * (g.Cin / 32))), dim3(256), 0, stream, x, Vt, g.B, g.Hin, g.Win, g.Cin, T, in);
         hipLaunchKernelGGL((wino_tr_kernel<true>), dim3((unsigned)(tb * (g.Cout / 32))), dim3(256), 0, stream, dy, dMt, g.B, g.Hin, g.Win, g.Cout, T, InBn());
         SIMQ_CHECK_LAUNCH();
-        if (int rc = launch_gemm_batched(dMt, Vt, dU, g.Cout, g.Cin, T, 16, stream)) return rc;
+        if (int rc = launch_gemm_batched(dMt, Vt, dU, g.Cout, g.Cin, T, 16, stream, g.tune)) return rc;
     }
     int blocks = (g.Cout * g.Cin + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -28,7 +28,7 @@ int conv_fwd(const Ctx& c, const ConvL& cv, const Act& x, float* y, const ConvGe
 
 // conv (+bias); in train modes its epilogue accumulates the BatchNorm batch statistics of `bn`
 int conv_bn(const Ctx& c, const ConvL& cv, const BnL& bn, int mode, const Act& x, float* y, int hin, const InBn& in = InBn()) {
-    ConvGeom g = geom(cv, c.B, hin);
+    ConvGeom g = geom(c.p, cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     if (mode != SIMQ_MODE_EVAL) e.stats = c.red(bn);
@@ -54,7 +54,7 @@ BnRef bnref(const Ctx& c, const BnL& bn, int mode, int64_t rows) {
 // eval-mode convolution with the following BatchNorm (running statistics), residual and ReLU folded into its epilogue:
 // out = [relu]( (conv(x) + bias) * scale + shift [+ addend] )  -- the same fma / add / max sequence bn_apply performs
 int conv_bn_folded(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, float* out, int hin, const float* addend, int relu) {
-    ConvGeom g = geom(cv, c.B, hin);
+    ConvGeom g = geom(c.p, cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     e.scale = c.aux(bn, 0); e.shift = c.aux(bn, 1);
@@ -65,7 +65,7 @@ int conv_bn_folded(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, f
 // the same for plain-bf16 plans: input, residual and output are bf16 planes (the fp32 accumulator is scaled / shifted / added / rectified
 // in fp32 and rounded once); `out` and `addend` are plane pointers
 int conv_bn_folded_planes(const Ctx& c, const ConvL& cv, const BnL& bn, const Act& x, uint16_t* out, int hin, const uint16_t* addend, int relu) {
-    ConvGeom g = geom(cv, c.B, hin);
+    ConvGeom g = geom(c.p, cv, c.B, hin);
     ConvEpilogue e;
     if (cv.b_off >= 0) e.bias = c.params + cv.b_off;
     e.scale = c.aux(bn, 0); e.shift = c.aux(bn, 1);
@@ -196,7 +196,7 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
         if (!c.lazy1()) RC(launch_bn_apply(c.f(L.yh1), bnref(c, p->hb1, mode, rows), nullptr, nullptr, 1, a1.f, rows, 128, c.stream, a1pl, Planes(), c.ybf()));
     }
     {
-        ConvGeom g2 = geom(p->h2, c.B, 24);
+        ConvGeom g2 = geom(p, p->h2, c.B, 24);
         ConvEpilogue e2;
         if (p->h2.b_off >= 0) e2.bias = c.params + p->h2.b_off;
         if (folded) { e2.scale = c.aux(p->hb2, 0); e2.shift = c.aux(p->hb2, 1); }     // eval: the affine map commutes with the upsample too

@@ -14,7 +14,15 @@ struct IgemmBfArgs {
     int tilesN;
     int xcd_chunk;                 // XCD-aware tile order (see IgemmArgs in conv_igemm.hip): blocks b < 8 * xcd_chunk take tile (b % 8) * xcd_chunk + b / 8
     unsigned x_bytes, w_bytes;     // plane sizes for the bounds-checked buffer loads
+    int force_bm, force_bn;        // host side only: LaunchTune::force_bm / force_bn of the launch (0: the launchers' own rules)
 };
+
+// 1 when the launch carries a forced tile (per-kernel tests / tools; ablation build: also SIMQ_IGEMM_TILE)
+inline int bf16_forced_tile(const IgemmBfArgs& a, int* bm, int* bn) {
+    LaunchTune t;
+    t.force_bm = a.force_bm; t.force_bn = a.force_bn;
+    return tune_forced_tile(t, bm, bn);
+}
 
 
 // conv_igemm_bf16_dma.hip: large-tile LDS-DMA kernel for plain bf16 operands; returns 1 when it took the launch,

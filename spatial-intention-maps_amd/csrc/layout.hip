@@ -107,6 +107,14 @@ WeightPrepTable weight_table(const simq_plan* p) {
     return t;
 }
 
+int plan_streams(const simq_plan* plan, PlanStreams** out, int* device) {
+    int dev = 0;
+    SIMQ_CHECK_HIP(hipGetDevice(&dev));
+    if (device) *device = dev;
+    *out = (dev >= 0 && dev < kMaxDevices) ? &plan->streams[dev] : nullptr;
+    return 0;
+}
+
 }  // namespace simq
 
 using namespace simq;
@@ -186,6 +194,15 @@ void simq_plan_options_default(simq_plan_options* o) {
     o->stem_bf16 = 1; o->bf16_act_grads = 1; o->keep_fp32_activations = 0; o->fold_eval_bn_bf16 = 1;
     o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
     o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1; o->deterministic = 0;
+    o->wgrad_ksplit = 0; o->fwd_overlap = 2; o->wgrad_overlap = 4; o->plane_xcd = 1; o->wgrad_xcd_group = 1; o->tail_split = 0;
+}
+
+void simq_launch_opts_default(simq_launch_opts* o) {
+    if (!o) return;
+    const LaunchTune t;
+    o->struct_bytes = (int)sizeof(simq_launch_opts);
+    o->force_bm = t.force_bm; o->force_bn = t.force_bn; o->tail_split = t.tail_split; o->plane_xcd = t.plane_xcd;
+    o->wgrad_xcd_group = t.wgrad_xcd_group; o->wgrad_ksplit = t.wgrad_ksplit;
 }
 
 int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out) {
@@ -207,6 +224,10 @@ int simq_plan_create_opts(int cin, int cout, int precision, const simq_plan_opti
         SIMQ_REQUIRE(opt.winograd_f4_grad >= 0 && opt.winograd_f4_grad <= 2, "plan_create: winograd_f4_grad = %d (0, 1 or 2)", opt.winograd_f4_grad);
         SIMQ_REQUIRE(opt.winograd_min_cc >= 64 * 64, "plan_create: winograd_min_cc = %d below 64*64 (layer1 does not fit the transform table)", opt.winograd_min_cc);
         SIMQ_REQUIRE(opt.winograd_f4_min_tiles >= 1, "plan_create: winograd_f4_min_tiles = %d", opt.winograd_f4_min_tiles);
+        SIMQ_REQUIRE(opt.wgrad_ksplit == 0 || opt.wgrad_ksplit == 1 || opt.wgrad_ksplit == 2 || opt.wgrad_ksplit == 4, "plan_create: wgrad_ksplit = %d (0, 1, 2 or 4)", opt.wgrad_ksplit);
+        SIMQ_REQUIRE(opt.fwd_overlap >= 0 && opt.fwd_overlap <= 2, "plan_create: fwd_overlap = %d (0, 1 or 2)", opt.fwd_overlap);
+        SIMQ_REQUIRE(opt.wgrad_overlap >= 0 && opt.wgrad_overlap <= 4, "plan_create: wgrad_overlap = %d (0 .. 4)", opt.wgrad_overlap);
+        SIMQ_REQUIRE(opt.wgrad_xcd_group >= 0 && opt.wgrad_xcd_group <= 2, "plan_create: wgrad_xcd_group = %d (0, 1 or 2)", opt.wgrad_xcd_group);
     }
     SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
     SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);
@@ -256,7 +277,23 @@ int simq_plan_create_opts(int cin, int cout, int precision, const simq_plan_opti
 
 int simq_plan_create(int cin, int cout, simq_plan** out) { return simq_plan_create_ex(cin, cout, SIMQ_PREC_FP32, out); }
 
-void simq_plan_destroy(simq_plan* plan) { delete plan; }
+// ... and with the plan go the streams / events it created (PlanStreams); work still in flight on them completes first (HIP releases a
+// destroyed stream's resources once it has drained)
+void simq_plan_destroy(simq_plan* plan) {
+    if (!plan) return;
+    for (int d = 0; d < kMaxDevices; ++d) {
+        PlanStreams& s = plan->streams[d];
+        hipStream_t* streams[3] = {&s.bwd_side, &s.third, &s.copy};
+        for (hipStream_t* st : streams)
+            if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+        hipEvent_t* events[] = {&s.bwd_ev[0], &s.bwd_ev[1], &s.bwd_ev[2], &s.bwd_ev[3], &s.third_ev, &s.step_ev[0], &s.step_ev[1], &s.step_ev[2],
+                                &s.step_ev[3], &s.step_ev[4], &s.step_ev[5], &s.copy_ready, &s.copy_done};
+        for (hipEvent_t* ev : events)
+            if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+    }
+    (void)hipGetLastError();
+    delete plan;
+}
 
 int simq_plan_precision(const simq_plan* plan) { return plan ? plan->precision : -1; }
 

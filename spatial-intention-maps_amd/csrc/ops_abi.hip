@@ -4,6 +4,19 @@
 
 using namespace simq;
 
+namespace {
+// simq_launch_opts of a standalone operator call -> the hints its launch carries (NULL: the defaults, what a default plan launches)
+int tune_of(const simq_launch_opts* o, LaunchTune* t) {
+    *t = LaunchTune();
+    if (!o) return 0;
+    SIMQ_REQUIRE(o->struct_bytes == (int)sizeof(simq_launch_opts), "simq_launch_opts.struct_bytes = %d, this library's struct has %d (fill it with "
+                 "simq_launch_opts_default first)", o->struct_bytes, (int)sizeof(simq_launch_opts));
+    t->force_bm = o->force_bm > 0 ? o->force_bm : 0; t->force_bn = o->force_bm > 0 ? o->force_bn : 0;
+    t->tail_split = o->tail_split; t->plane_xcd = o->plane_xcd; t->wgrad_xcd_group = o->wgrad_xcd_group; t->wgrad_ksplit = o->wgrad_ksplit;
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream) {
@@ -62,8 +75,9 @@ int simq_nhwc_to_nchw(const float* d_in, float* d_out, int batch, int channels, 
 }
 
 int simq_conv2d_fwd(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
-                    int cin, int cout, int r, int s, int stride, int pad, double* d_stats, void* stream) {
+                    int cin, int cout, int r, int s, int stride, int pad, double* d_stats, void* stream, const simq_launch_opts* opts) {
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     ConvEpilogue e;
@@ -72,9 +86,10 @@ int simq_conv2d_fwd(const float* d_x, const float* d_w, const float* d_bias, flo
 }
 
 int simq_conv2d_fwd_winograd(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
-                             int cin, int cout, double* d_stats, float* d_scratch, void* stream) {
+                             int cin, int cout, double* d_stats, float* d_scratch, void* stream, const simq_launch_opts* opts) {
     SIMQ_REQUIRE(d_x && d_w && d_y && d_scratch && batch >= 1, "conv2d_fwd_winograd: bad argument");
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
     SIMQ_REQUIRE(winograd_eligible(g), "conv2d_fwd_winograd: geometry not supported (even map, cin %% 16, cout %% 64)");
     ConvEpilogue e;
@@ -125,10 +140,11 @@ int simq_bn_relu_backward(const void* d_g, const void* d_mask, int mask_kind, co
 
 int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_w, const float* d_bias,
                               float* d_y, int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
-                              float* d_scratch, void* stream) {
+                              float* d_scratch, void* stream, const simq_launch_opts* opts) {
     SIMQ_REQUIRE(d_y_pre && d_in_scale && d_in_shift && d_w && d_y && batch >= 1, "conv2d_fwd_bnrelu_in: bad argument");
     SIMQ_REQUIRE(form >= 0 && form <= 2 && (form == 0 || d_scratch), "conv2d_fwd_bnrelu_in: form %d (0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3) with scratch)", form);
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     ConvEpilogue e;
@@ -151,10 +167,11 @@ int simq_conv2d_fwd_bnrelu_in(const float* d_y_pre, const float* d_in_scale, con
 
 int simq_conv2d_wgrad_bnrelu_in(const float* d_y_pre, const float* d_in_scale, const float* d_in_shift, const float* d_dy, float* d_dw,
                                 int batch, int hin, int win, int cin, int cout, int r, int s, int stride, int pad, int form,
-                                float* d_scratch, void* stream) {
+                                float* d_scratch, void* stream, const simq_launch_opts* opts) {
     SIMQ_REQUIRE(d_y_pre && d_in_scale && d_in_shift && d_dy && d_dw && batch >= 1, "conv2d_wgrad_bnrelu_in: bad argument");
     SIMQ_REQUIRE(form == 0 || (form == 1 && d_scratch), "conv2d_wgrad_bnrelu_in: form %d (0 direct, 1 transform domain with scratch)", form);
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     InBn in; in.scale = d_in_scale; in.shift = d_in_shift;
@@ -190,9 +207,10 @@ int simq_conv2d_wgrad_stem_bf16(const float* d_x, const uint16_t* d_dy, float* d
 }
 
 int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
-                              int cin, int cout, double* d_stats, float* d_scratch, void* stream) {
+                              int cin, int cout, double* d_stats, float* d_scratch, void* stream, const simq_launch_opts* opts) {
     SIMQ_REQUIRE(d_x && d_w && d_y && d_scratch && batch >= 1, "conv2d_fwd_winograd4: bad argument");
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
     SIMQ_REQUIRE(winograd_eligible(g) && hin % 4 == 0 && win % 4 == 0, "conv2d_fwd_winograd4: geometry not supported (map %% 4, cin %% 16, cout %% 64)");
     ConvEpilogue e;
@@ -206,20 +224,22 @@ int simq_conv2d_fwd_winograd4(const float* d_x, const float* d_w, const float* d
 }
 
 int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
-                               float* d_scratch, void* stream) {
+                               float* d_scratch, void* stream, const simq_launch_opts* opts) {
     SIMQ_REQUIRE(d_x && d_dy && d_dw && d_scratch && batch >= 1, "conv2d_wgrad_winograd: bad argument");
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Hout = hin; g.Wout = win;
     SIMQ_REQUIRE(winograd_wgrad_eligible(g), "conv2d_wgrad_winograd: geometry not supported (even map, cin %% 128, cout %% 128)");
     return launch_conv_wgrad_winograd(d_x, d_dy, d_dw, g, d_scratch, static_cast<hipStream_t>(stream));
 }
 
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, float* d_dx, int batch, int hin, int win,
-                      int cin, int cout, int r, int s, int pad, void* stream) {
+                      int cin, int cout, int r, int s, int pad, void* stream, const simq_launch_opts* opts) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     SIMQ_REQUIRE(r == s, "conv2d_dgrad: square filters only");
     RC(launch_weight_transpose(d_w, d_wt_scratch, cout, r * s, cin, st));
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cout; g.Cout = cin; g.Hout = hin; g.Wout = win;
     g.R = r; g.S = s; g.stride = 1; g.pad = r - 1 - pad;
     ConvEpilogue e;
@@ -227,9 +247,10 @@ int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, 
 }
 
 int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
-                      int r, int s, int stride, int pad, void* stream) {
+                      int r, int s, int stride, int pad, void* stream, const simq_launch_opts* opts) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     SIMQ_CHECK_HIP(hipMemsetAsync(d_dw, 0, sizeof(float) * (size_t)cout * r * s * cin, st));
@@ -238,9 +259,10 @@ int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw, int batc
 
 int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w, const float* d_bias, float* d_y, int batch, int hin, int win,
                          int cin, int cout, int r, int s, int stride, int pad, int nplanes, void* d_scratch, double* d_stats,
-                         void* stream) {
+                         void* stream, const simq_launch_opts* opts) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     const int64_t nx = (int64_t)batch * hin * win * cin, nw = (int64_t)cout * r * s * cin;
@@ -257,14 +279,15 @@ int simq_conv2d_fwd_bf16(const float* d_x, const float* d_w, const float* d_bias
 int64_t simq_conv2d_wgrad_bf16_slab_bytes(void) { return conv_wgrad_bf16_slab_bytes(); }
 
 int simq_conv2d_wgrad_bf16(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
-                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream) {
-    return simq_conv2d_wgrad_bf16_slab(d_x, d_dy, d_dw, batch, hin, win, cin, cout, r, s, stride, pad, nplanes, d_scratch, nullptr, stream);
+                           int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* stream, const simq_launch_opts* opts) {
+    return simq_conv2d_wgrad_bf16_slab(d_x, d_dy, d_dw, batch, hin, win, cin, cout, r, s, stride, pad, nplanes, d_scratch, nullptr, stream, opts);
 }
 
 int simq_conv2d_wgrad_bf16_slab(const float* d_x, const float* d_dy, float* d_dw, int batch, int hin, int win, int cin, int cout,
-                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream) {
+                                int r, int s, int stride, int pad, int nplanes, void* d_scratch, void* d_slab, void* stream, const simq_launch_opts* opts) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvGeom g;
+    RC(tune_of(opts, &g.tune));
     g.B = batch; g.Hin = hin; g.Win = win; g.Cin = cin; g.Cout = cout; g.R = r; g.S = s; g.stride = stride; g.pad = pad;
     g.Hout = (hin + 2 * pad - r) / stride + 1; g.Wout = (win + 2 * pad - s) / stride + 1;
     const int64_t nx = (int64_t)batch * hin * win * cin, ny = (int64_t)batch * g.Hout * g.Wout * cout;

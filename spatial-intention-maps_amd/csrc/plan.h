@@ -6,6 +6,7 @@
 //   resnet.py:52-91    ResNet.__init__     (7x7 s2 stem, maxpool, 4 x 2 BasicBlocks, strides removed)
 // as a flat list of convolution / BatchNorm descriptors over ONE fp32 parameter buffer.
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,20 @@ struct BlockL {
 
 struct TensorInfo { std::string name; int64_t off; int64_t shape[4]; int kind; };
 
+// Streams and events the library itself owns: per plan and device, created on first use (under simq_plan::mu), destroyed by
+// simq_plan_destroy.  A plan is used by one host thread at a time (include/simq.h), so the sets need no further locking.
+struct PlanStreams {
+    hipStream_t bwd_side = nullptr;                 // weight gradients beside the dgrads of a backward pass called on its own (wgrad_overlap)
+    hipEvent_t bwd_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t third = nullptr;                    // simq_train_step: the policy's no-grad forward beside the other two (fwd_overlap = 2)
+    hipEvent_t third_ev = nullptr;
+    hipEvent_t step_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // simq_train_step: fork / join of the caller's side stream
+    hipStream_t copy = nullptr;                     // simq_train_step: out4 -> pinned host memory without a stream synchronisation
+    hipEvent_t copy_ready = nullptr, copy_done = nullptr;
+    bool copy_pending = false;
+};
+constexpr int kMaxDevices = 64;
+
 }  // namespace simq
 
 struct simq_plan {
@@ -68,6 +83,14 @@ struct simq_plan {
                                       // statistics arrive from an elementwise launch whose blocks all finish together (forward_impl)
     int64_t wino_scratch_per_sample = 0;   // floats of V | Mt scratch per transition (max over the Winograd layers)
     int64_t wino_du_floats = 0;            // transform-domain weight gradient of the largest Winograd layer
+    mutable std::mutex mu;
+    mutable simq::PlanStreams streams[simq::kMaxDevices];
+    // kernel-selection / scheduling hints every launch of this plan carries (ConvGeom::tune)
+    simq::LaunchTune tune() const {
+        simq::LaunchTune t;
+        t.tail_split = opt.tail_split; t.plane_xcd = opt.plane_xcd; t.wgrad_xcd_group = opt.wgrad_xcd_group; t.wgrad_ksplit = opt.wgrad_ksplit;
+        return t;
+    }
 };
 
 namespace simq {
@@ -172,8 +195,9 @@ struct Ctx {
     }
 };
 
-inline ConvGeom geom(const ConvL& c, int B, int hin) {
+inline ConvGeom geom(const simq_plan* p, const ConvL& c, int B, int hin) {
     ConvGeom g;
+    g.tune = p->tune();
     g.B = B; g.Hin = hin; g.Win = hin; g.Cin = c.cin; g.Cout = c.cout; g.R = c.k; g.S = c.k; g.stride = c.stride; g.pad = c.pad;
     g.Hout = (hin + 2 * c.pad - c.k) / c.stride + 1; g.Wout = g.Hout;
     return g;
@@ -213,7 +237,7 @@ int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, 
                        hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr);
 int check_sync(const simq_sync* sync, int batch);
 
-extern int g_fwd_overlap;     // simq_tune_fwd_overlap (A-B runs): where the no-grad forwards of simq_train_step are forked
-extern int g_wgrad_overlap;   // simq_tune_wgrad_overlap (A-B runs): weight gradients beside the dgrads on a side stream (4: up to one block behind)
+// the plan's stream set of the calling thread's current device (created on first use); *out = nullptr when the device index is out of range
+int plan_streams(const simq_plan* plan, PlanStreams** out, int* device = nullptr);   // layout.hip
 
 }  // namespace simq

@@ -66,29 +66,4 @@ int simq_profile_stop(double* out, int max_kinds) {
     return 0;
 }
 
-int simq_tune_force_tile(int bm, int bn) {
-    simq::tune_force_tile(bm, bn);
-    return 0;
-}
-
-int simq_tune_tail_split(int on) {
-    simq::tune_tail_split(on);
-    return 0;
-}
-
-int simq_tune_wgrad_ksplit(int splits) {
-    simq::tune_wgrad_ksplit(splits);
-    return 0;
-}
-
-int simq_tune_wgrad_xcd_group(int on) {
-    simq::tune_wgrad_xcd_group(on);
-    return 0;
-}
-
-int simq_tune_plane_xcd(int on) {
-    simq::tune_plane_xcd(on);
-    return 0;
-}
-
 }  // extern "C"

@@ -5,48 +5,46 @@
 using namespace simq;
 
 namespace {
-// out4 -> pinned host memory without a stream synchronisation: per device and host thread one copy stream + two events
-struct LossCopy { hipStream_t copy = nullptr; hipEvent_t ready = nullptr, done = nullptr; bool pending = false; };
-thread_local LossCopy g_loss_copy[64];
-
-int loss_copy(const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream) {
+// out4 -> pinned host memory without a stream synchronisation: the plan's copy stream + two events of the current device (PlanStreams)
+int loss_copy(const simq_plan* plan, const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream) {
+    PlanStreams* c = nullptr;
     int dev = 0;
-    SIMQ_CHECK_HIP(hipGetDevice(&dev));
-    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
+    RC(plan_streams(plan, &c, &dev));
+    SIMQ_REQUIRE(c, "train_step: device index %d out of range", dev);
     if (producer) {                         // the copy stream / events are created on the CURRENT device: it must be the producer stream's
         hipDevice_t sdev = 0;
         SIMQ_CHECK_HIP(hipStreamGetDevice(producer, &sdev));
         SIMQ_REQUIRE((int)sdev == dev, "train_step: the stream belongs to device %d, the calling thread's current device is %d", (int)sdev, dev);
     }
-    LossCopy& c = g_loss_copy[dev];
-    if (!c.copy) {
-        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c.copy, hipStreamNonBlocking));
-        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    if (!c->copy) {
+        std::lock_guard<std::mutex> lk(plan->mu);
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c->copy_ready, hipEventDisableTiming));
+        SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     }
     hipStream_t s = producer;
     if (own_stream) {                       // the copy must not queue behind the backward pass that follows on `producer`
-        SIMQ_CHECK_HIP(hipEventRecord(c.ready, producer));
-        SIMQ_CHECK_HIP(hipStreamWaitEvent(c.copy, c.ready, 0));
-        s = c.copy;
+        SIMQ_CHECK_HIP(hipEventRecord(c->copy_ready, producer));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(c->copy, c->copy_ready, 0));
+        s = c->copy;
     }
     SIMQ_CHECK_HIP(hipMemcpyAsync(h_out4, d_out4, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
-    SIMQ_CHECK_HIP(hipEventRecord(c.done, s));
-    c.pending = true;
+    SIMQ_CHECK_HIP(hipEventRecord(c->copy_done, s));
+    c->copy_pending = true;
     return 0;
 }
 }  // namespace
 
 extern "C" {
 
-int simq_train_loss_wait(void) {
+int simq_train_loss_wait(const simq_plan* plan) {
+    SIMQ_REQUIRE(plan, "train_loss_wait: NULL plan");
+    PlanStreams* c = nullptr;
     int dev = 0;
-    SIMQ_CHECK_HIP(hipGetDevice(&dev));
-    SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_loss_wait: device index %d out of range", dev);
-    LossCopy& c = g_loss_copy[dev];
-    SIMQ_REQUIRE(c.pending, "train_loss_wait: no simq_train_step with loss_host on this thread and device");
-    SIMQ_CHECK_HIP(hipEventSynchronize(c.done));
-    c.pending = false;
+    RC(plan_streams(plan, &c, &dev));
+    SIMQ_REQUIRE(c && c->copy_pending, "train_loss_wait: no simq_train_step with loss_host on this plan and device (%d)", dev);
+    SIMQ_CHECK_HIP(hipEventSynchronize(c->copy_done));
+    c->copy_pending = false;
     return 0;
 }
 
@@ -67,24 +65,21 @@ int simq_train_step(const simq_train_args* a) {
     const simq_plan* p = a->plan;
     hipStream_t main = static_cast<hipStream_t>(a->stream), side = static_cast<hipStream_t>(a->side_stream);
     const int n = p->cout * 96 * 96, B = a->batch, Nn = a->num_nonfinal;
-    // fork / join events, one pair per device and host thread (events belong to the device they were created on)
-    static thread_local hipEvent_t ev_pairs[64][6] = {};
+    // fork / join events of the caller's side stream: the plan's, per device (events belong to the device they were created on)
+    PlanStreams* ps = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr, ev_wdone0 = nullptr, ev_wdone1 = nullptr;
     if (side) {
         int dev = 0;
-        SIMQ_CHECK_HIP(hipGetDevice(&dev));
-        SIMQ_REQUIRE(dev >= 0 && dev < 64, "train_step: device index %d out of range", dev);
-        if (!ev_pairs[dev][0]) {
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][0], hipEventDisableTiming));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][1], hipEventDisableTiming));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][2], hipEventDisableTiming));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][3], hipEventDisableTiming));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][4], hipEventDisableTiming));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ev_pairs[dev][5], hipEventDisableTiming));
+        RC(plan_streams(p, &ps, &dev));
+        SIMQ_REQUIRE(ps, "train_step: device index %d out of range", dev);
+        if (!ps->step_ev[0]) {
+            std::lock_guard<std::mutex> lk(p->mu);
+            for (int i = 0; i < 6; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->step_ev[i], hipEventDisableTiming));
         }
-        ev_fork = ev_pairs[dev][0]; ev_join = ev_pairs[dev][1]; ev_wfork = ev_pairs[dev][2]; ev_wjoin = ev_pairs[dev][3];
-        ev_wdone0 = ev_pairs[dev][4]; ev_wdone1 = ev_pairs[dev][5];
+        ev_fork = ps->step_ev[0]; ev_join = ps->step_ev[1]; ev_wfork = ps->step_ev[2]; ev_wjoin = ps->step_ev[3];
+        ev_wdone0 = ps->step_ev[4]; ev_wdone1 = ps->step_ev[5];
     }
+    const int fwd_overlap = p->opt.fwd_overlap;      // simq_plan_options.fwd_overlap (2: three forwards side by side)
     // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
     simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
     const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
@@ -96,17 +91,14 @@ int simq_train_step(const simq_train_args* a) {
     // forwards alternate HBM-bound transforms and matrix-bound GEMMs; side by side the three fill each other's phases
     // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN (its collectives order the streams); the plain
     // data-parallel step has no collective before its backward pass and takes it.
-    const bool three = g_fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync;
-    static thread_local hipStream_t third_streams[64] = {};
-    static thread_local hipEvent_t third_events[64] = {};
+    const bool three = fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync;
     if (three) {
-        int dev = 0;
-        SIMQ_CHECK_HIP(hipGetDevice(&dev));
-        if (!third_streams[dev]) {
-            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&third_streams[dev], hipStreamNonBlocking));
-            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&third_events[dev], hipEventDisableTiming));
+        if (!ps->third) {
+            std::lock_guard<std::mutex> lk(p->mu);
+            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->third, hipStreamNonBlocking));
+            SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->third_ev, hipEventDisableTiming));
         }
-        hipStream_t third = third_streams[dev];
+        hipStream_t third = ps->third;
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
@@ -117,14 +109,14 @@ int simq_train_step(const simq_train_args* a) {
         cn.defer_running = true;
         RC(forward_impl(cn, SIMQ_MODE_TRAIN_NOGRAD, a->next_state, a->q_next));
         RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, third));
-        SIMQ_CHECK_HIP(hipEventRecord(third_events[dev], third));
+        SIMQ_CHECK_HIP(hipEventRecord(ps->third_ev, third));
         RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
-        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, third_events[dev], 0));
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ps->third_ev, 0));
         RC(launch_bn_running_deferred(a->bnbuf, reinterpret_cast<const double*>(cn.ws + cn.L.defer), p->nbnbuf, main));     // update #2
         SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
         RC(launch_q_gather(a->q_tgt, Nn, n, a->best, a->vals, main));
     } else {
-    if (g_fwd_overlap == 1 && side) {                      // (A-B: the target-net forward forked at the start of the step)
+    if (fwd_overlap == 1 && side) {                      // (A-B: the target-net forward forked at the start of the step)
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     }
@@ -133,7 +125,7 @@ int simq_train_step(const simq_train_args* a) {
     // forked BEHIND the policy's train-mode forward so that it overlaps the policy's next-state forward: both run on the
     // ~29 non-final samples, whose tiles do not fill whole rounds of the CUs, and fill each other's tails (+1.7 % on the step
     // over starting it beside the perfectly tiled 32-sample forward)
-    if (side && g_fwd_overlap != 1) {
+    if (side && fwd_overlap != 1) {
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     }
@@ -163,7 +155,7 @@ int simq_train_step(const simq_train_args* a) {
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
-    if (a->loss_host && !a->comm) RC(loss_copy(a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
+    if (a->loss_host && !a->comm) RC(loss_copy(p, a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;
@@ -182,16 +174,11 @@ int simq_train_step(const simq_train_args* a) {
         RC(comm_allreduce(a->comm, a->grads, split, SIMQ_COMM_F32, main));
         RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
         RC(comm_wait(a->comm, main));
-        if (a->loss_host) RC(loss_copy(a->out4, a->loss_host, main, false));            // (summed over the ranks)
+        if (a->loss_host) RC(loss_copy(p, a->out4, a->loss_host, main, false));            // (summed over the ranks)
     }
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);
-}
-
-int simq_tune_fwd_overlap(int on) {
-    g_fwd_overlap = (on >= 0 && on <= 2) ? on : 2;
-    return 0;
 }
 
 int64_t simq_grad_bucket_split(const simq_plan* plan) { return plan ? plan->blocks[kPhaseSplitBlock].c1.w_off : -1; }

@@ -47,7 +47,13 @@ class PlanOptions(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
         'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
-        'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'deterministic', 'bn1_mask_from_preact')]
+        'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'deterministic', 'bn1_mask_from_preact',
+        'wgrad_ksplit', 'fwd_overlap', 'wgrad_overlap', 'plane_xcd', 'wgrad_xcd_group', 'tail_split')]
+
+
+class LaunchOpts(ctypes.Structure):
+    """simq_launch_opts of include/simq.h: kernel selection / block scheduling of ONE standalone operator call (per-kernel tests, tools/)."""
+    _fields_ = [(n, c_int) for n in ('struct_bytes', 'force_bm', 'force_bn', 'tail_split', 'plane_xcd', 'wgrad_xcd_group', 'wgrad_ksplit')]
 
 
 class TrainArgs(ctypes.Structure):
@@ -71,6 +77,7 @@ _SIGS = {
     'simq_plan_create': (c_int, [c_int, c_int, POINTER(c_void_p)]),
     'simq_plan_create_ex': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     'simq_plan_options_default': (None, [c_void_p]),
+    'simq_launch_opts_default': (None, [c_void_p]),
     'simq_plan_create_opts': (c_int, [c_int, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     'simq_plan_get_options': (c_int, [c_void_p, c_void_p]),
     'simq_plan_precision': (c_int, [c_void_p]),
@@ -92,7 +99,7 @@ _SIGS = {
     'simq_backward_phase': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_grad_bucket_split': (c_int64, [c_void_p]),
     'simq_train_step': (c_int, [c_void_p]),
-    'simq_train_loss_wait': (c_int, []),
+    'simq_train_loss_wait': (c_int, [c_void_p]),
     'simq_backward_onehot': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -107,31 +114,24 @@ _SIGS = {
     'simq_replay_gather': (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     'simq_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'simq_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    'simq_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
-    'simq_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
-    'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
-    'simq_conv2d_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p]),
-    'simq_conv2d_wgrad_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p]),
+    'simq_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p] + [c_void_p]),
+    'simq_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] + [c_void_p]),
+    'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p] + [c_void_p]),
+    'simq_conv2d_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
+    'simq_conv2d_wgrad_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p] + [c_void_p]),
     'simq_conv2d_wgrad_bf16_slab_bytes': (c_int64, []),
-    'simq_conv2d_wgrad_bf16_slab': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_wgrad_bf16_slab': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
     'simq_upsample2x_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_profile_start': (c_int, []),
     'simq_profile_stop': (c_int, [c_void_p, c_int]),
-    'simq_tune_force_tile': (c_int, [c_int, c_int]),
-    'simq_tune_tail_split': (c_int, [c_int]),
-    'simq_tune_plane_xcd': (c_int, [c_int]),
-    'simq_tune_wgrad_overlap': (c_int, [c_int]),
-    'simq_tune_fwd_overlap': (c_int, [c_int]),
-    'simq_tune_wgrad_xcd_group': (c_int, [c_int]),
-    'simq_tune_wgrad_ksplit': (c_int, [c_int]),
-    'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
-    'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
-    'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p] + [c_void_p]),
+    'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
+    'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
     'simq_bn_relu_apply': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_bn_relu_backward': (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_void_p]),
-    'simq_conv2d_fwd_bnrelu_in': (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p]),
-    'simq_conv2d_wgrad_bnrelu_in': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p]),
+    'simq_conv2d_fwd_bnrelu_in': (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p] + [c_void_p]),
+    'simq_conv2d_wgrad_bnrelu_in': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p] + [c_void_p]),
     'simq_conv2d_fwd_stem_f32': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     'simq_conv2d_fwd_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     'simq_conv2d_wgrad_stem_bf16': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
@@ -152,6 +152,23 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
+# operators whose last argument is `const simq_launch_opts*`
+OPTS_FUNCS = frozenset(('simq_conv2d_fwd', 'simq_conv2d_dgrad', 'simq_conv2d_wgrad', 'simq_conv2d_fwd_bf16', 'simq_conv2d_wgrad_bf16',
+                        'simq_conv2d_wgrad_bf16_slab', 'simq_conv2d_wgrad_winograd', 'simq_conv2d_fwd_winograd', 'simq_conv2d_fwd_winograd4',
+                        'simq_conv2d_fwd_bnrelu_in', 'simq_conv2d_wgrad_bnrelu_in'))
+
+
+def launch_opts(tile=None, **fields):
+    """A simq_launch_opts with the library's defaults; tile=(bm, bn) forces a block tile, other fields by name (plane_xcd=0, ...)."""
+    o = LaunchOpts()
+    _c.simq_launch_opts_default(ctypes.byref(o))
+    if tile is not None and tile[0] > 0:
+        o.force_bm, o.force_bn = int(tile[0]), int(tile[1])
+    for k, v in fields.items():
+        if k == 'struct_bytes' or not hasattr(o, k):
+            raise SimqError('unknown launch option %r (fields of simq_launch_opts: %s)' % (k, ', '.join(n for n, _ in LaunchOpts._fields_[1:])))
+        setattr(o, k, int(v))
+    return o
 
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(_c, _name)      # AttributeError here == header / library mismatch
@@ -187,7 +204,13 @@ class Lib:
 
 
     @staticmethod
-    def call(name, *args):
+    def call(name, *args, opts=None):
+        """Checked call.  The convolution operators of include/simq.h end in `const simq_launch_opts* opts`: pass opts=launch_opts(...) to
+        force a tile / a scheduling variant for THAT call; omitted = NULL = what a default plan launches."""
+        if name in OPTS_FUNCS:
+            args = args + (ctypes.byref(opts) if opts is not None else None,)
+        elif opts is not None:
+            raise SimqError('%s takes no simq_launch_opts' % name)
         check(getattr(_c, name)(*args), name)
 
 

@@ -608,7 +608,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q.view(B, policy_net.num_output_channels, W, W)}
     if not sync:
         return out4
-    lib.call('simq_train_loss_wait')
+    lib.call('simq_train_loss_wait', policy_net.plan.handle)
     o = loss_host.tolist()                                                  # train.py:138-139 (.item())
     return {'td_error': o[1] / gB, 'loss': o[0] / gB}
 

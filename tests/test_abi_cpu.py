@@ -31,7 +31,35 @@ def test_every_declared_symbol_is_exported(L):
     for s in syms:
         assert hasattr(raw, s), 'libsimq.so does not export %s' % s
     assert sorted(L.EXPORTS) == syms, 'ctypes binding and header disagree'
-    assert L.lib.version == 301
+    assert L.lib.version == 400
+
+
+def test_no_process_global_behaviour_switch_is_exported(L):
+    """Round 5: what a plan computes and how it schedules its launches is a property of the plan (simq_plan_options); a standalone
+    operator call carries its own simq_launch_opts.  The product library exports no simq_tune_* (or any other setter of process state)."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', L.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in 'TDBR']
+    assert not [s for s in exported if 'tune' in s], [s for s in exported if 'tune' in s]
+    assert sorted(exported) == sorted(L.EXPORTS)                          # (csrc/libsimq.map: the C-ABI of include/simq.h and nothing else)
+    # the scheduling options live in the plan, validated at creation, reported back
+    plan = L.Plan(4, 2, options={'fwd_overlap': 0, 'wgrad_overlap': 1, 'plane_xcd': 0, 'wgrad_ksplit': 2, 'wgrad_xcd_group': 2, 'tail_split': 1})
+    for k, v in (('fwd_overlap', 0), ('wgrad_overlap', 1), ('plane_xcd', 0), ('wgrad_ksplit', 2), ('wgrad_xcd_group', 2), ('tail_split', 1)):
+        assert plan.options[k] == v
+    d = L.Plan(4, 2).options
+    assert (d['fwd_overlap'], d['wgrad_overlap'], d['plane_xcd'], d['wgrad_ksplit'], d['wgrad_xcd_group'], d['tail_split']) == (2, 4, 1, 0, 1, 0)
+    for bad in ({'wgrad_ksplit': 3}, {'fwd_overlap': 3}, {'wgrad_overlap': 5}, {'wgrad_xcd_group': -1}):
+        with pytest.raises(L.SimqError):
+            L.Plan(4, 2, options=bad)
+    o = L.launch_opts(tile=(96, 64), plane_xcd=0)
+    assert (o.struct_bytes, o.force_bm, o.force_bn, o.plane_xcd, o.wgrad_xcd_group) == (ctypes.sizeof(L.LaunchOpts), 96, 64, 0, 1)
+    with pytest.raises(L.SimqError):
+        L.launch_opts(nonsense=1)
+    # a launch-opts struct of another version is refused before anything is launched
+    o.struct_bytes = 4
+    assert L.lib.c.simq_conv2d_fwd(None, None, None, None, 1, 24, 24, 64, 64, 3, 3, 1, 1, None, None, ctypes.byref(o)) != 0
+    assert 'struct_bytes' in L.last_error()
+    assert L.lib.c.simq_train_loss_wait(None) != 0 and 'NULL' in L.last_error()
 
 
 def test_plan_layout_matches_reference_state_dict(L):
@@ -252,7 +280,8 @@ def test_plan_options_are_a_property_of_the_plan_and_not_of_the_environment(L, m
     d = L.Plan(4, 2).options
     assert d == {'winograd': 1, 'winograd_min_cc': 128 * 128, 'winograd_f4_forward': 1, 'winograd_f4_min_tiles': 256, 'winograd_f4_grad': 2,
                  'winograd_f4_fwd_grad_min_cc': 512 * 512, 'winograd_wgrad': 1, 'winograd_wgrad_f4': 1, 'stem_bf16': 1, 'bf16_act_grads': 1, 'keep_fp32_activations': 0,
-                 'fold_eval_bn_bf16': 1, 'fuse_bn_backward_sums': 1, 'fuse_stem_backward_sums': 1, 'fuse_bn1_apply': 1, 'deterministic': 0, 'bn1_mask_from_preact': 1}
+                 'fold_eval_bn_bf16': 1, 'fuse_bn_backward_sums': 1, 'fuse_stem_backward_sums': 1, 'fuse_bn1_apply': 1, 'deterministic': 0, 'bn1_mask_from_preact': 1,
+                 'wgrad_ksplit': 0, 'fwd_overlap': 2, 'wgrad_overlap': 4, 'plane_xcd': 1, 'wgrad_xcd_group': 1, 'tail_split': 0}
     p = L.Plan(5, 1, 'bf16', options={'stem_bf16': 0, 'keep_fp32_activations': 1})
     assert p.options['stem_bf16'] == 0 and p.options['keep_fp32_activations'] == 1 and p.options['winograd'] == 1
     # the Winograd weight cache exists only when the option is on: the option changes the plan, not a global

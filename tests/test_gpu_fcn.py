@@ -311,7 +311,7 @@ def test_train_returns_the_loss_without_a_stream_synchronisation(simq_mod):
             huber = float(np.where(np.abs(d) < 1.0, 0.5 * d * d, np.abs(d) - 0.5).mean())
             assert abs(info['loss'] - huber) <= 1e-5 * huber and abs(info['td_error'] - np.abs(d).mean()) <= 1e-5 * np.abs(d).mean()
     torch.cuda.synchronize()
-    assert lib.c.simq_train_loss_wait() != 0 and 'no simq_train_step' in simq_mod._lib.last_error()
+    assert lib.c.simq_train_loss_wait(nets[0][0].plan.handle) != 0 and 'no simq_train_step' in simq_mod._lib.last_error()
 
 
 def test_policy_step_golden(simq_mod, golden_dir):

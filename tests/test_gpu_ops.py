@@ -337,16 +337,12 @@ def test_conv_bf16_pingpong_kernels_match_register_staged(L, B, Cin, Cout, tile)
     scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
     st = L.stream_ptr()
     outs = []
-    try:
-        for t in (tile, (96, 128) if Cout % 128 == 0 else (96, 64)):       # (the second: a register-staged tile)
-            L.lib.call('simq_tune_force_tile', *t)
-            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
-            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
-            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1,
-                       L.ptr(scratch), L.ptr(stats), st)
-            outs.append((y, stats))
-    finally:
-        L.lib.call('simq_tune_force_tile', 0, 0)
+    for t in (tile, (96, 128) if Cout % 128 == 0 else (96, 64)):       # (the second: a register-staged tile)
+        y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1,
+                   L.ptr(scratch), L.ptr(stats), st, opts=L.launch_opts(tile=t))
+        outs.append((y, stats))
     (y1, s1), (y0, s0) = outs
     assert torch.isfinite(y1).all()
     assert rel(y1, y0) < 5e-6 and rel(s1, s0) < 1e-6
@@ -406,16 +402,12 @@ def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k)
     scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
     st = L.stream_ptr()
     outs = []
-    try:
-        for tile in ((288, 128), (96, 128)):
-            L.lib.call('simq_tune_force_tile', *tile)
-            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
-            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
-            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1,
-                       L.ptr(scratch), L.ptr(stats), st)
-            outs.append((y, stats))
-    finally:
-        L.lib.call('simq_tune_force_tile', 0, 0)
+    for tile in ((288, 128), (96, 128)):
+        y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1,
+                   L.ptr(scratch), L.ptr(stats), st, opts=L.launch_opts(tile=tile))
+        outs.append((y, stats))
     (y_dma, s_dma), (y_reg, s_reg) = outs
     assert torch.isfinite(y_dma).all()
     assert rel(y_dma, y_reg) < 2e-6
@@ -430,7 +422,7 @@ def test_conv_bf16_lds_dma_kernel_matches_register_staged(L, B, H, Cin, Cout, k)
 
 @pytest.mark.parametrize('B,H', [(29, 24), (39, 20)], ids=['112_tail_tiles', 'ragged_tail'])
 def test_conv_fp32_balanced_last_round(L, B, H):
-    """conv_igemm.hip's opt-in balanced last round (simq_tune_tail_split): the tiles of a partial last round are contracted
+    """conv_igemm.hip's opt-in balanced last round (simq_launch_opts.tail_split / simq_plan_options.tail_split): the tiles of a partial last round are contracted
     in K-slices by several blocks and finished by igemm_tail_fixup_kernel.  Same output (up to the fp32 summation order of
     the slices) and the same fused bias + batch statistics as the plain launch.  (29, 24): 1392 tiles of 96x64 on 1280
     slots; (39, 20): M = 15600 is not a multiple of 96 -- the 24 tail tiles include the ragged last row tile."""
@@ -441,17 +433,12 @@ def test_conv_fp32_balanced_last_round(L, B, H):
     b = torch.randn(Cout, generator=g).cuda()
     st = L.stream_ptr()
     outs = []
-    try:
-        L.lib.call('simq_tune_force_tile', 96, 64)
-        for on in (0, 1):
-            L.lib.call('simq_tune_tail_split', on)
-            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
-            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
-            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st)
-            outs.append((y, stats))
-    finally:
-        L.lib.call('simq_tune_tail_split', 0)
-        L.lib.call('simq_tune_force_tile', 0, 0)
+    for on in (0, 1):
+        y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+        L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st,
+                   opts=L.launch_opts(tile=(96, 64), tail_split=on))
+        outs.append((y, stats))
     (y0, s0), (y1, s1) = outs
     assert torch.isfinite(y1).all()
     assert rel(y1, y0) < 5e-6 and rel(s1, s0) < 1e-6
@@ -475,15 +462,12 @@ def test_conv_fp32_image_tile_kernel_matches_implicit_gemm(L, B, Cout, bias):
     b = torch.randn(Cout, generator=g).cuda() if bias else None
     st = L.stream_ptr()
     outs = []
-    try:
-        for tile in ((0, 0), (32, 32)):
-            L.lib.call('simq_tune_force_tile', *tile)
-            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
-            stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
-            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st)
-            outs.append((y, stats))
-    finally:
-        L.lib.call('simq_tune_force_tile', 0, 0)
+    for tile in ((0, 0), (32, 32)):
+        y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+        stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
+        L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st,
+                   opts=L.launch_opts(tile=tile))
+        outs.append((y, stats))
     (y0, s0), (y1, s1) = outs
     assert torch.isfinite(y0).all()
     assert rel(y0, y1) < 5e-6 and rel(s0, s1) < 1e-6
@@ -525,7 +509,7 @@ def test_conv_winograd_forward_matches_direct(L, B, H, Cin, Cout):
 def test_winograd_gemm_plane_per_xcd_walk_is_bit_identical(L, f4, B, H, Cin, Cout):
     """conv_igemm.hip's batched transform-domain GEMM hands whole planes to one XCD (16 planes: two per XCD; 36: four per XCD and the
     last four shared by two XCDs each, a contiguous half of the row blocks per XCD).  It is a permutation of (plane, tile) over the
-    launch's blocks: every block must be covered exactly once -- the output equals the launch-order walk (simq_tune_plane_xcd 0) BIT FOR
+    launch's blocks: every block must be covered exactly once -- the output equals the launch-order walk (simq_launch_opts.plane_xcd = 0) BIT FOR
     BIT, with a NaN-filled destination to catch an uncovered tile.  Shapes whose tile count does not divide (odd row-block counts)
     fall back to the launch-order walk inside the launcher and are covered by the same equality."""
     g = torch.Generator().manual_seed(23 + Cin + Cout + B)
@@ -536,16 +520,13 @@ def test_winograd_gemm_plane_per_xcd_walk_is_bit_identical(L, f4, B, H, Cin, Cou
     scratch = torch.empty(nb * Cout * Cin + nb * T * (Cin + Cout) + 64, device='cuda')
     name = 'simq_conv2d_fwd_winograd4' if f4 else 'simq_conv2d_fwd_winograd'
     ys = []
-    try:
-        for on in (0, 1):
-            L.lib.call('simq_tune_plane_xcd', on)
-            y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
-            scratch.fill_(float('nan'))
-            L.lib.call(name, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, None, L.ptr(scratch), L.stream_ptr())
-            torch.cuda.synchronize()
-            ys.append(y)
-    finally:
-        L.lib.call('simq_tune_plane_xcd', 1)
+    for on in (0, 1):
+        y = torch.full((B, H, H, Cout), float('nan'), device='cuda')
+        scratch.fill_(float('nan'))
+        L.lib.call(name, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, H, H, Cin, Cout, None, L.ptr(scratch), L.stream_ptr(),
+                   opts=L.launch_opts(plane_xcd=on))
+        torch.cuda.synchronize()
+        ys.append(y)
     assert torch.isfinite(ys[1]).all()
     assert torch.equal(ys[0], ys[1])
 
@@ -620,18 +601,15 @@ def test_conv_winograd_wgrad_ksplit(L, B, Cin, Cout, splits):
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
                                       padding=1).permute(0, 2, 3, 1)
     out = {}
-    try:
-        for s in (1, splits, splits):
-            L.lib.call('simq_tune_wgrad_ksplit', s)
-            d = torch.full((Cout, 3, 3, Cin), float('nan'), device='cuda')
-            scratch.fill_(float('nan'))
-            L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d), B, H, H, Cin, Cout, L.ptr(scratch), st)
-            torch.cuda.synchronize()
-            assert torch.isfinite(d).all()
-            assert rel(d, ref) < 1e-4
-            out.setdefault(s, []).append(d)
-    finally:
-        L.lib.call('simq_tune_wgrad_ksplit', 0)
+    for s in (1, splits, splits):
+        d = torch.full((Cout, 3, 3, Cin), float('nan'), device='cuda')
+        scratch.fill_(float('nan'))
+        L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(d), B, H, H, Cin, Cout, L.ptr(scratch), st,
+                   opts=L.launch_opts(wgrad_ksplit=s))
+        torch.cuda.synchronize()
+        assert torch.isfinite(d).all()
+        assert rel(d, ref) < 1e-4
+        out.setdefault(s, []).append(d)
     assert torch.equal(out[splits][0], out[splits][1])
     assert rel(out[splits][0], out[1][0]) < 6e-5               # (two summation orders of a gradient whose own error is 0.6-3e-5)
 

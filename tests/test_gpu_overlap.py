@@ -5,8 +5,9 @@ BatchNorm running-statistics update deferred and applied behind the grad-mode fo
 gradients of the residual blocks on a side stream up to one block behind the dgrads (a second set of gradient temporaries).  On a
 DETERMINISTIC plan (fixed-order reductions everywhere) every result of two consecutive steps -- losses, gradient, parameters and the
 BatchNorm buffers, whose update order is exactly what the deferral has to preserve -- must equal the fully serial order BIT FOR BIT,
-for every setting of the two A-B switches; the standalone backward entry points (FCN.backward, simq_backward*) take the same side
-stream from the library and are held to the same bar.  Against the reference itself the overlapped step is what every golden test
+for every setting of the two scheduling options of the plan (simq_plan_options.wgrad_overlap / fwd_overlap: round 5 -- they were
+process-global switches before); the standalone backward entry points (FCN.backward, simq_backward*) take a side stream the PLAN owns
+(created on first use, destroyed with the plan) and are held to the same bar.  Against the reference itself the overlapped step is what every golden test
 of tests/test_gpu_fcn.py / test_gpu_sized.py runs (the defaults)."""
 import os
 import sys
@@ -28,9 +29,7 @@ def env():
     from oracle import cases, fcn as ofcn
     from simq import synth
     from simq._lib import lib
-    yield dict(simq=simq, sl=sl, cases=cases, ofcn=ofcn, synth=synth, lib=lib)
-    lib.call('simq_tune_wgrad_overlap', 4)
-    lib.call('simq_tune_fwd_overlap', 2)
+    return dict(simq=simq, sl=sl, cases=cases, ofcn=ofcn, synth=synth, lib=lib)
 
 
 def _nets(e, precision, options, cin=5, cout=2):
@@ -44,9 +43,9 @@ def _nets(e, precision, options, cin=5, cout=2):
 
 def _two_steps(e, wgrad, fwd, B, precision='fp32', options=None, cin=5, cout=2):
     c = e['cases']
-    e['lib'].call('simq_tune_wgrad_overlap', wgrad)
-    e['lib'].call('simq_tune_fwd_overlap', fwd)
-    policy, target = _nets(e, precision, options if options is not None else {'deterministic': 1}, cin, cout)
+    opts = dict(options if options is not None else {'deterministic': 1}, wgrad_overlap=wgrad, fwd_overlap=fwd)
+    policy, target = _nets(e, precision, opts, cin, cout)
+    assert policy.plan.options['wgrad_overlap'] == wgrad and policy.plan.options['fwd_overlap'] == fwd
     losses = []
     for s in range(2):     # (the second step re-records every event and reuses both sets of temporaries)
         info = e['sl'].train_step(policy, target, c.make_batch(cin, cout, B, 7 + s), c.GAMMA, B, c.LR, c.MOMENTUM, c.WEIGHT_DECAY, c.CLIP,
@@ -77,15 +76,14 @@ def test_overlapped_bf16_step_keeps_the_buffers_of_the_serial_step(env):
         assert torch.equal(r[k], ref[k]), k
 
 
-def test_standalone_backward_on_the_library_side_stream(env):
-    # FCN.backward / simq_backward_phase: dense upstream gradient, weight gradients on the library-owned side stream
+def test_standalone_backward_on_the_plan_side_stream(env):
+    # FCN.backward / simq_backward_phase: dense upstream gradient, weight gradients on the plan-owned side stream (wgrad_overlap = 0: none)
     from simq._lib import MODE_TRAIN
     e = env
     B, cin, cout = 8, 4, 2
     out = {}
     for wgrad in (0, 4, 1):
-        e['lib'].call('simq_tune_wgrad_overlap', wgrad)
-        policy, _ = _nets(e, 'fp32', {'deterministic': 1}, cin, cout)
+        policy, _ = _nets(e, 'fp32', {'deterministic': 1, 'wgrad_overlap': wgrad}, cin, cout)
         g = torch.Generator().manual_seed(5)
         x = torch.randn(B, 96, 96, cin, generator=g).cuda()
         for _ in range(2):
@@ -99,3 +97,39 @@ def test_standalone_backward_on_the_library_side_stream(env):
         assert torch.equal(out[wgrad][0], out[0][0])
         assert torch.equal(out[wgrad][1], out[0][1]), 'standalone backward: gradient differs with wgrad_overlap %d' % wgrad
 
+
+
+def test_plan_owned_streams_are_created_lazily_and_die_with_the_plan(env):
+    """Round 5: the third stream of fwd_overlap = 2, the side stream of a standalone backward and the loss-copy stream belong to the PLAN
+    (one set per device), not to the calling host thread: creating and dropping many nets must not grow the process's stream count, and a
+    backward called from ANOTHER host thread (torch's autograd engine does that) uses the same plan-owned stream."""
+    import gc
+    import threading
+    from simq._lib import MODE_TRAIN
+    e = env
+    B, cin, cout = 4, 4, 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 96, 96, cin, generator=g).cuda()
+    ref = None
+    for rep in range(12):                           # (12 plans, each creating its side stream and 4 events; a leak shows in rocm-smi, a crash here)
+        policy, _ = _nets(e, 'fp32', {'deterministic': 1}, cin, cout)
+        q = policy._forward_raw(x, MODE_TRAIN)
+        dq = torch.full_like(q, 1e-3)
+        err = []
+
+        def run():
+            try:
+                torch.cuda.set_device(0)
+                policy._backward_raw(dq, B)
+                torch.cuda.synchronize()
+            except Exception as ex:               # noqa: BLE001
+                err.append(ex)
+        t = threading.Thread(target=run)
+        t.start(); t.join()
+        assert not err, err
+        grads = policy.flat_grads.clone()
+        if ref is None:
+            ref = grads
+        assert torch.equal(grads, ref)
+        del policy, _
+        gc.collect()

@@ -24,16 +24,15 @@ for name in sys.argv[2:] or ['l4']:
     for bm, bn in TILES:
         if Cout % bn:
             continue
-        L.lib.call('simq_tune_force_tile', bm, bn)
         for _ in range(4):
-            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st)
+            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st,
+                       opts=L.launch_opts(tile=(bm, bn)))
         torch.cuda.synchronize()
     for dbg in os.environ.get('BF16_DBGS', '').split():
         os.environ['SIMQ_BF16_DBG'] = dbg
-        L.lib.call('simq_tune_force_tile', 288, 128)
         for _ in range(4):
-            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st)
+            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st,
+                       opts=L.launch_opts(tile=(288, 128)))
         torch.cuda.synchronize()
     os.environ.pop('SIMQ_BF16_DBG', None)
-    L.lib.call('simq_tune_force_tile', 0, 0)
     print(name, 'GFLOP', flops / 1e9)

@@ -19,18 +19,18 @@ def run(B, Cout, tile, reps=20):
     y = torch.empty(B, H, H, Cout, device='cuda')
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
     scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
-    L.lib.call('simq_tune_force_tile', *tile)
+    opts = L.launch_opts(tile=tile)
     try:
-        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), L.ptr(stats), st)
+        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), L.ptr(stats), st, opts=opts)
         torch.cuda.synchronize()
         out, s = y.clone(), stats.clone()
         L.lib.call('simq_profile_start')
         for _ in range(reps):
-            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), None, st)
+            L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, 1, L.ptr(scratch), None, st, opts=opts)
         o = (ctypes.c_double * 12)()
         L.lib.call('simq_profile_stop', o, 3)
     finally:
-        L.lib.call('simq_tune_force_tile', 0, 0)
+        pass
     return out, s, (o[1] + o[9]) / max(o[0] + o[8], 1)
 
 

@@ -18,10 +18,10 @@ def bench(B, Cout, tile, stats_on, reps=50):
     y = torch.empty(B, H, H, Cout, device='cuda')
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda') if stats_on else None
     st = L.stream_ptr()
-    L.lib.call('simq_tune_force_tile', *tile)
+    opts = L.launch_opts(tile=tile)
     try:
         def go():
-            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st)
+            L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, 1, L.ptr(stats), st, opts=opts)
         for _ in range(5):
             go()
         torch.cuda.synchronize()
@@ -32,7 +32,7 @@ def bench(B, Cout, tile, stats_on, reps=50):
         e1.record()
         torch.cuda.synchronize()
     finally:
-        L.lib.call('simq_tune_force_tile', 0, 0)
+        pass
     return e0.elapsed_time(e1) / reps * 1e3
 
 

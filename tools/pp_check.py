@@ -23,18 +23,17 @@ def run(B, name, tile, reps=5):
     y = torch.empty(B, H, H, Cout, device='cuda')
     stats = torch.zeros(2 * Cout, dtype=torch.float64, device='cuda')
     scratch = torch.empty(2 * (x.numel() + w.numel()) + 64, dtype=torch.int16, device='cuda')
-    L.lib.call('simq_tune_force_tile', *tile)
-    L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), L.ptr(stats), st)
+    opts = L.launch_opts(tile=tile)
+    L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), L.ptr(stats), st, opts=opts)
     torch.cuda.synchronize()
     out, s = y.clone(), stats.clone()
     L.lib.call('simq_profile_start')
     for _ in range(reps):
-        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st)
+        L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, H, Cin, Cout, k, k, 1, k // 2, 1, L.ptr(scratch), None, st, opts=opts)
     import ctypes
     o = (ctypes.c_double * 12)()
     L.lib.call('simq_profile_stop', o, 3)
     ms = (o[1] + o[9]) / max(o[0] + o[8], 1)
-    L.lib.call('simq_tune_force_tile', 0, 0)
     return out, s, ms, 2.0 * B * H * H * Cout * k * k * Cin
 
 

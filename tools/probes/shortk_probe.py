@@ -20,8 +20,7 @@ for K in (128, 256, 512, 1024, 2048, 4096):
     y = torch.empty(B, H, H, Cout, device='cuda')
     out = []
     for tile in ((64, 64), (96, 64), (128, 64), (96, 128)):
-        L.lib.call('simq_tune_force_tile', *tile)
-        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, K, Cout, 1, 1, 1, 0, None, st))
+        o = L.launch_opts(tile=tile)
+        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, K, Cout, 1, 1, 1, 0, None, st, opts=o))
         out.append('%dx%d %.1f TF' % (tile[0], tile[1], 2.0 * B * H * H * K * Cout / ms / 1e9))
-    L.lib.call('simq_tune_force_tile', 0, 0)
     print('K=%4d  ' % K + '  '.join(out))

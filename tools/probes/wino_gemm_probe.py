@@ -16,8 +16,7 @@ for B, Cin, Cout in [(128, 512, 512), (128, 256, 512), (128, 256, 256), (128, 51
     y = torch.empty(B, H, H, Cout, device='cuda')
     res = []
     for tile in [(0, 0), (96, 64), (128, 64), (96, 128), (64, 64), (64, 128)]:
-        L.lib.call('simq_tune_force_tile', *tile)
-        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, 1, 1, 1, 0, None, st))
+        o = L.launch_opts(tile=tile)
+        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, 1, 1, 1, 0, None, st, opts=o))
         res.append('%dx%d: %.1f TF (%.3f ms)' % (tile[0], tile[1], 2.0 * B * H * H * Cin * Cout / ms / 1e9, ms))
-    L.lib.call('simq_tune_force_tile', 0, 0)
     print(B, Cin, Cout, ' | '.join(res))

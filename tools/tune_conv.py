@@ -36,10 +36,9 @@ for name, H, Cin, Cout, k, stride, pad in SHAPES:
     for bm, bn in TILES:
         if Cout % bn or (Cin % 16 and not (bn == 64 and bm in (128, 64, 32))):
             continue
-        L.lib.call('simq_tune_force_tile', bm, bn)
-        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, stride, pad, None, st))
+        o = L.launch_opts(tile=(bm, bn))
+        ms = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, stride, pad, None, st, opts=o))
         res.append((flops / ms / 1e9, bm, bn, ms))
-    L.lib.call('simq_tune_force_tile', 0, 0)
     ms_auto = timeit(lambda: L.lib.call('simq_conv2d_fwd', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, stride, pad, None, st))
     ms_wg = timeit(lambda: L.lib.call('simq_conv2d_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), B, H, H, Cin, Cout, k, k, stride, pad, st))
     res.sort(reverse=True)
@@ -57,7 +56,6 @@ for name, H, Cin, Cout, k, stride, pad in SHAPES:
     # the entry points re-split the fp32 inputs on every call: time the splitters alone and subtract
     out = []
     for npl in (2, 1):
-        L.lib.call('simq_tune_force_tile', 0, 0)
         ms_f = timeit(lambda: L.lib.call('simq_conv2d_fwd_bf16', L.ptr(x), L.ptr(w), None, L.ptr(y), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), None, st))
         if Cin % 64 and not (Cout % 32 == 0 and Cin % 128 == 0): continue
         ms_w = timeit(lambda: L.lib.call('simq_conv2d_wgrad_bf16', L.ptr(x), L.ptr(dy), L.ptr(dw), B, H, H, Cin, Cout, k, k, 1, pad, npl, L.ptr(scratch), st))

@@ -32,7 +32,6 @@ for B in (32, 64, 128):
         st = L.stream_ptr()
         row = []
         for s in (1, 2, 4, 0):
-            L.lib.call('simq_tune_wgrad_ksplit', s)
-            row.append(timed(lambda: L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(dw), B, 24, 24, Cin, Cout, L.ptr(scratch), st)))
-        L.lib.call('simq_tune_wgrad_ksplit', 0)
+            o = L.launch_opts(wgrad_ksplit=s)
+            row.append(timed(lambda: L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(dy), L.ptr(dw), B, 24, 24, Cin, Cout, L.ptr(scratch), st, opts=o)))
         print('B=%3d %3d->%3d  whole launch sequence, us:  S=1 %7.1f   S=2 %7.1f   S=4 %7.1f   auto %7.1f' % ((B, Cin, Cout) + tuple(row)), flush=True)
