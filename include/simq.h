@@ -177,7 +177,8 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
  * recomputation from the STORED tensors it was computed from).  name: "layer<1-4>.<0-1>.<y1|a1|y2|yd|out>" (pre-BatchNorm outputs of
  * conv1 / conv2 / the downsample convolution, the activation between the two convolutions, the block output; NHWC [batch][24][24][C]),
  * "layer<l>.<b>.<bn1|bn2|bnd>" (4*C floats: scale | shift | mean | invstd as the consuming kernel formed them), "stem.pool.plane"
- * (matrix-core precisions).  storage: 0 fp32, 1 bf16.  Fails for tensors the plan does not store (e.g. a1 under fuse_bn1_apply). */
+ * (matrix-core precisions), "layer<l>.<b>.<red1|red2|redd>" (2*C doubles: the BatchNorm's reduction slot -- after a backward pass
+ * [sum dz | sum dz*xhat]).  storage: 0 fp32, 1 bf16, 2 fp64.  Fails for tensors the plan does not store (e.g. a1 under fuse_bn1_apply). */
 int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels,
                              int* storage);
 
@@ -195,6 +196,18 @@ int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_para
  * d_grads  flat gradient buffer (param layout); OVERWRITTEN.                                  */
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream);
+
+/* Inspection aid of the backward walk (teacher-forced parity tests, tests/test_gpu_bf16_points.py): simq_backward with every gradient
+ * tensor that travels between the kernels of a residual block (resnet.py:31-47 reversed) copied into d_trace as it becomes final --
+ * the walk itself reuses four temporaries.  name: "layer<1-4>.<0-1>.<g_out|dy2|dz|dyd|da1|dy1|g_ds|g_in>" = gradient w.r.t. the block output
+ * (as received), conv2's pre-BN output, the masked gradient dz = g_out * [out > 0] (identity blocks: the shortcut's addend), the
+ * downsample convolution's pre-BN output (downsample blocks), the activation between the convolutions, conv1's pre-BN output, the
+ * downsample convolution's data gradient (downsample blocks: the addend of conv1's data gradient), the block input; NHWC [batch][24][24][C].  storage as simq_workspace_tensor_ex.  d_trace: simq_backward_trace_bytes() bytes. */
+int64_t simq_backward_trace_bytes(const simq_plan* plan, int batch);
+int simq_backward_trace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels,
+                               int* storage);
+int simq_backward_traced(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                         float* d_grads, void* d_workspace, void* d_trace, void* stream);
 
 /* Two-phase form for data-parallel callers: phase 1 (zero-fill + head + layer4) leaves d_grads[simq_grad_bucket_split() ..]
  * final, so its all-reduce can overlap phase 2 (layers 3..1 + stem, which completes d_grads[0 .. split)).  phase 0 = both. */
@@ -449,6 +462,15 @@ int simq_upsample2x_bwd(const float* d_dout, float* d_din, int batch, int h, int
  * {launches, total ms, total algorithmic flops (2*M*N*K), total algorithmic bytes}.  Not thread-safe. */
 int simq_profile_start(void);
 int simq_profile_stop(double* out, int max_kinds);
+/* ... and a launch log (always on): every launcher names the kernel FAMILY that took a launch -- "igemm_bf16_img_whole" / "_half" (image
+ * tile), "igemm_bf16_c64", "igemm_bf16_pp", "igemm_bf16_dma", "igemm_bf16_reg", "wgrad_bf16_img", "wgrad_bf16_pp", "wgrad_bf16_reg",
+ * "stem_conv_bf16", "stem_wgrad_bf16", "bn_apply16", "bn_bwd_apply16[_mask_from_y]", "gemm_f32_batched", "igemm_f32", "conv_img_f32",
+ * "stem_conv_f32", "winograd_f2" / "winograd_f4" [_wgrad], "wgrad_f32" [_batched] ... (csrc: note_launch).  simq_launch_count: launches
+ * of one family since the last reset (0 for a name that never ran); simq_launch_counts: "name=count;..." of every family that ran.
+ * The parity tests use it to assert that the kernels a batch size is meant to select DID run. */
+int simq_launch_counts_reset(void);
+int64_t simq_launch_count(const char* family);
+int simq_launch_counts(char* buf, int cap);
 
 #ifdef __cplusplus
 }

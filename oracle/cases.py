@@ -25,6 +25,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(_HERE), 'tests', 'golden')
 # (name, cin, cout, batch, weight seed, data seed)
 FORWARD_CASES = [('fwd_c4o2', 4, 2, 2, 11, 21), ('fwd_c5o2', 5, 2, 2, 12, 22), ('fwd_c5o1', 5, 1, 2, 13, 23)]
 TRAIN_CASES = [('train_c4o2_b4', 4, 2, 4, 31, 41), ('train_c5o1_b4', 5, 1, 4, 32, 42), ('train_c4o2_b8', 4, 2, 8, 33, 43)]
+# the reference's OTHER input-channel counts (tools_generate_experiments.py:200-204: num_input_channels in {3, 4, 5, 6, 7, 10}; 4 / 5 above):
+# the stem's forward and weight gradient are the kernels whose addressing depends on Cin (K = 49 * Cin, unaligned rows; Cin = 10 leaves the
+# dedicated fp32 stem kernel for the generic implicit GEMM).  Summaries only (no Q-map): < 100 KB per fixture.
+TRAIN_CASES_CIN = [('train_c3o2_b4', 3, 2, 4, 91, 101), ('train_c6o2_b4', 6, 2, 4, 92, 102), ('train_c7o2_b4', 7, 2, 4, 93, 103),
+                   ('train_c10o1_b4', 10, 1, 4, 94, 104)]
 # the bench workload's own size (BASELINE configs[1]); summaries only, checked on the GPU without re-running the oracle
 TRAIN_CASES_FULL = [('train_c4o2_b32', 4, 2, 32, 36, 46)]
 # BASELINE configs[2] / configs[4]'s per-GPU shape (Cin 5, Cout 2, 128 transitions) and configs[3]'s two per-GPU shapes (Cin 5; lifting

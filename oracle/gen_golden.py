@@ -150,7 +150,7 @@ def gen_forward():
         print('forward case', name, 'oracle == reference (bit-exact); saved')
 
 
-def gen_train(case_list=None):
+def gen_train(case_list=None, keep_output=True):
     for name, cin, cout, B, wseed, dseed in (case_list or cases.TRAIN_CASES):
         cfg = cases.make_cfg(B)
         batch = cases.make_batch(cin, cout, B, dseed)
@@ -184,7 +184,7 @@ def gen_train(case_list=None):
             'loss': np.array([i['loss'] for i in info_ref]), 'td_error': np.array([i['td_error'] for i in info_ref]),
             'total_norm': np.array([e['total_norm'] for e in extras]),
             'q_sa': extras[0]['q'].numpy(), 'y': extras[0]['y'].numpy(),
-            'output_step1': extras[0]['output'].numpy() if B <= 4 else np.zeros(0, np.float32),
+            'output_step1': extras[0]['output'].numpy() if (B <= 4 and keep_output) else np.zeros(0, np.float32),
             'param_summary_after2': cases.param_summary(st, spec),
             'bn_buffers_after2': cases.bn_buffer_vector(st).astype(np.float32),
             'num_batches_tracked': np.array([int(st[k]) for k in st if k.endswith('num_batches_tracked')]),
@@ -668,7 +668,7 @@ def gen_grad_study(case_list=None, fname='grad_study.npz'):
     np.savez_compressed(os.path.join(cases.GOLDEN_DIR, fname), **out)
 
 
-def gen_bf16_calibration():
+def gen_bf16_calibration(train_cases=None, fname='bf16_calibration.npz'):
     """Fixture G8: how far the REFERENCE moves when its own modules run in bf16 -- torch.autocast('cpu', bfloat16) over
     the imported networks.FCN / train.train arithmetic (bf16 convolution operands and outputs, fp32 BatchNorm statistics and
     parameters: the mixed-precision recipe the opt-in `precision='bf16'` plans follow) -- measured against the fp64 oracle on the
@@ -680,7 +680,7 @@ def gen_bf16_calibration():
     def rel(a, b):
         a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
         return float(np.abs(a - b).max() / np.abs(b).max())
-    for name, cin, cout, B, wseed, dseed in cases.FORWARD_CASES:
+    for name, cin, cout, B, wseed, dseed in (cases.FORWARD_CASES if train_cases is None else []):
         x = torch.cat([learner.apply_transform(s) for s in synth.make_states(B, cin, dseed)])
         for training in (False, True):
             st64 = cases.oracle_state(cin, cout, wseed, torch.float64)
@@ -691,7 +691,7 @@ def gen_bf16_calibration():
             with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
                 q16 = net(x)
             out['%s.%s' % (name, 'train' if training else 'eval')] = rel(q16.float().numpy(), q64.numpy())
-    for name, cin, cout, B, wseed, dseed in cases.TRAIN_CASES:
+    for name, cin, cout, B, wseed, dseed in (train_cases or cases.TRAIN_CASES):
         cfg, batch, spec = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed), fcn.state_spec(cin, cout)
         st64, tg64 = cases.oracle_state(cin, cout, wseed, torch.float64), cases.oracle_state(cin, cout, wseed + 1000, torch.float64)
         ex64 = {}
@@ -722,7 +722,7 @@ def gen_bf16_calibration():
         out[name + '.loss'] = abs(float(loss) - i64['loss']) / abs(i64['loss'])
         out[name + '.td_error'] = abs(float(torch.abs(q - y).mean()) - i64['td_error']) / abs(i64['td_error'])
         out[name + '.grad'] = (num / den) ** 0.5
-    np.savez(os.path.join(cases.GOLDEN_DIR, 'bf16_calibration.npz'), **{k: np.array(v) for k, v in out.items()})
+    np.savez(os.path.join(cases.GOLDEN_DIR, fname), **{k: np.array(v) for k, v in out.items()})
     for k, v in out.items():
         print('bf16 calibration (reference under torch.autocast bf16 vs fp64)  %-28s %.4g' % (k, v))
 
@@ -869,7 +869,8 @@ if __name__ == '__main__':
     os.makedirs(cases.GOLDEN_DIR, exist_ok=True)
     gens = {'sampler': gen_sampler, 'forward': gen_forward, 'step': gen_step, 'train': gen_train,
             'intention': gen_intention, 'intention_step': gen_intention_step,
-            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
+            'train_full': lambda: gen_train(cases.TRAIN_CASES_FULL),
+            'train_cin': lambda: (gen_train(cases.TRAIN_CASES_CIN, keep_output=False), gen_bf16_calibration(cases.TRAIN_CASES_CIN, 'bf16_calibration_cin.npz')), 'train_sized': gen_train_sized, 'dense_grad': gen_dense_grad, 'tracker': gen_tracker, 'checkpoint': gen_checkpoint,
             'dp': gen_dp, 'dp_literal': gen_dp_literal, 'bf16_calibration': gen_bf16_calibration, 'bf16_points': gen_bf16_points,
             'grad_study': gen_grad_study,
             'grad_study_b64': lambda: gen_grad_study(cases.GRAD_STUDY_B64_CASES, 'grad_study_b64.npz'),

@@ -96,6 +96,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     const bool piped = wide && wov == 4 && L.S2[0] >= 0 && c.ev_wdone[0] && c.ev_wdone[1];
     Ctx cw = c;
     if (ov) { cw.stream = c.wstream; if (L.wino2 >= 0) cw.L.wino = L.wino2; }
+    const TraceLayout TL = c.trace ? make_trace_layout(p, B) : TraceLayout();
+    auto trace = [&](int64_t off, const void* src, int64_t bytes) -> int {      // (simq_backward_traced: a copy of a tensor that has just become final)
+        if (c.trace && src) SIMQ_CHECK_HIP(hipMemcpyAsync(c.trace + off, src, (size_t)bytes, hipMemcpyDeviceToDevice, c.stream));
+        return 0;
+    };
     auto fork = [&]() -> int {
         if (ov) { SIMQ_CHECK_HIP(hipEventRecord(c.ev_wfork, c.stream)); SIMQ_CHECK_HIP(hipStreamWaitEvent(c.wstream, c.ev_wfork, 0)); }
         return 0;
@@ -202,9 +207,16 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         const float* m_a1 = (po || mfy) ? nullptr : c.f(o.a1);
         const uint16_t* m16_out = po ? c.planes(o.p_out, rows * b.planes).hi : nullptr;
         const uint16_t* m16_a1 = (po && !mfy) ? c.planes(o.p_a1, rows * b.planes).hi : nullptr;
+        // (trace: element sizes of the gradient values / of the BatchNorm input gradients in this plan)
+        const int64_t nel = rows * b.planes, gsz = gb ? 2 : 4, dsz = po ? 2 : 4;
+        auto dptr = [&](const Act& a) -> const void* { return po ? (const void*)a.pl.hi : (const void*)a.f; };
+        RC(trace(TL.blk[i].g_out, G, nel * gsz));
         // out = relu(bn2(y2) + identity): dz = G * (out > 0) feeds bn2 and the identity branch
         RC(bn_bwd(c, b.b2, G, m_out, c.f(o.y2), T0, b.has_ds ? nullptr : T1.f, rows, !no_fuse, m16_out, -1, gb));
         if (b.has_ds) RC(bn_bwd(c, b.bds, G, m_out, c.f(o.yd), T1, nullptr, rows, !no_fuse, m16_out, -1, gb));
+        RC(trace(TL.blk[i].dy2, dptr(T0), nel * dsz));
+        if (b.has_ds) RC(trace(TL.blk[i].t1, dptr(T1), nel * dsz));
+        else RC(trace(TL.blk[i].t1, T1.f, nel * gsz));
         RC(fork());
         if (c.lazy1()) {                                     // (a1 was never stored: the weight gradient re-applies bn1 + ReLU to y1)
             Act y1; y1.f = c.f(o.y1);
@@ -219,20 +231,24 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         f1.bnr_mask = m_a1; f1.bnr_mask16 = m16_a1; f1.bnr_y1 = c.f(o.y1); f1.bnr_mean1 = c.aux(b.b1, 2); f1.bnr_invstd1 = c.aux(b.b1, 3); f1.bnr_red1 = c.red(b.b1);
         }
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1, gb));
+        RC(trace(TL.blk[i].da1, T2, nel * gsz));
         Act D1 = T0;                                         // dy1: over dy2, or (wide) in place over the gradient bn1 receives
         if (wide) { D1 = Act(); D1.f = T2; }
         else RC(join());                                     // (bn1's backward writes dy1 over dy2)
         RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), D1, nullptr, rows, !no_fuse, m16_a1, -1, gb, mfy));
+        RC(trace(TL.blk[i].dy1, dptr(D1), nel * dsz));
         RC(fork());
         RC(conv_wgrad(cw, b.c1, xin, D1, 24));
         const ConvEpilogue fin = i > 0 ? fuse_block_out(i - 1) : ConvEpilogue();
         if (b.has_ds) {
             RC(conv_wgrad(cw, b.ds, xin, T1, 24));
             RC(conv_dgrad(c, b.ds, T1, G, nullptr, 24, ConvEpilogue(), gb));
+            RC(trace(TL.blk[i].g_ds, G, rows * b.cin * gsz));
             RC(conv_dgrad(c, b.c1, D1, G, G, 24, fin, gb));
         } else {
             RC(conv_dgrad(c, b.c1, D1, G, T1.f, 24, fin, gb));
         }
+        RC(trace(TL.blk[i].g_in, G, rows * b.cin * gsz));
         if (piped) SIMQ_CHECK_HIP(hipEventRecord(c.ev_wdone[set], c.wstream));
         else RC(join());                                     // (the next block's BatchNorm backwards and dgrad reuse T0 / T1 / T2)
         // G (same buffer) now holds the gradient w.r.t. the block input
@@ -286,6 +302,25 @@ static int attach_backward_side(Ctx& c) {
 }
 
 namespace simq {
+TraceLayout make_trace_layout(const simq_plan* p, int B) {
+    TraceLayout T;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+    const bool mc = p->precision != SIMQ_PREC_FP32;
+    const bool po = mc && !p->opt.keep_fp32_activations && p->opt.fuse_bn_backward_sums;      // Ctx::planes_only
+    const int64_t gsz = (p->precision == SIMQ_PREC_BF16 && p->opt.bf16_act_grads) ? 2 : 4, dsz = po ? 2 : 4;
+    for (int i = 7; i >= 0; --i) {
+        const int64_t n = (int64_t)B * 576 * p->blocks[i].planes;
+        T.blk[i].g_out = take(n * gsz); T.blk[i].dy2 = take(n * dsz);
+        T.blk[i].t1 = take(n * (p->blocks[i].has_ds ? dsz : gsz));
+        T.blk[i].da1 = take(n * gsz); T.blk[i].dy1 = take(n * dsz);
+        T.blk[i].g_ds = p->blocks[i].has_ds ? take((int64_t)B * 576 * p->blocks[i].cin * gsz) : -1;
+        T.blk[i].g_in = take((int64_t)B * 576 * p->blocks[i].cin * gsz);
+    }
+    T.total = off;
+    return T;
+}
+
 // simq_backward_sync with the stream / events of the weight-gradient overlap (simq_train_step only: its side stream is idle by then)
 int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                               const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
@@ -337,6 +372,54 @@ int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params
     const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
     RC(attach_backward_side(c));
     return backward_impl(c, nullptr, phase, &oh);
+}
+
+int64_t simq_backward_trace_bytes(const simq_plan* plan, int batch) {
+    if (!plan || batch < 1) return -1;
+    return make_trace_layout(plan, batch).total;
+}
+
+int simq_backward_trace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels, int* storage) {
+    SIMQ_REQUIRE(plan && name && batch >= 1, "backward_trace_tensor: bad argument");
+    const TraceLayout T = make_trace_layout(plan, batch);
+    const bool mc = plan->precision != SIMQ_PREC_FP32;
+    const bool po = mc && !plan->opt.keep_fp32_activations && plan->opt.fuse_bn_backward_sums;
+    const int gst = (plan->precision == SIMQ_PREC_BF16 && plan->opt.bf16_act_grads) ? 1 : 0, dst = po ? 1 : 0;
+    int li = 0, bi = 0;
+    char what[32] = "";
+    int64_t off = -1;
+    int ch = 0, st = 0;
+    if (sscanf(name, "layer%d.%d.%31s", &li, &bi, what) == 3 && li >= 1 && li <= 4 && bi >= 0 && bi <= 1) {
+        const int i = (li - 1) * 2 + bi;
+        const BlockL& b = plan->blocks[i];
+        const std::string w(what);
+        ch = b.planes;
+        if (w == "g_out") { off = T.blk[i].g_out; st = gst; }
+        else if (w == "dy2") { off = T.blk[i].dy2; st = dst; }
+        else if (w == "dz" && !b.has_ds) { off = T.blk[i].t1; st = gst; }
+        else if (w == "dyd" && b.has_ds) { off = T.blk[i].t1; st = dst; }
+        else if (w == "da1") { off = T.blk[i].da1; st = gst; }
+        else if (w == "dy1") { off = T.blk[i].dy1; st = dst; }
+        else if (w == "g_in") { off = T.blk[i].g_in; st = gst; ch = b.cin; }
+        else if (w == "g_ds" && b.has_ds) { off = T.blk[i].g_ds; st = gst; ch = b.cin; }
+    }
+    SIMQ_REQUIRE(off >= 0, "backward_trace_tensor: '%s' is not a tensor of the traced walk (layer<1-4>.<0-1>.<g_out|dy2|dz|dyd|da1|dy1|g_ds|g_in>)", name);
+    if (byte_offset) *byte_offset = off;
+    if (elems) *elems = (int64_t)batch * 576 * ch;
+    if (channels) *channels = ch;
+    if (storage) *storage = st;
+    return 0;
+}
+
+int simq_backward_traced(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
+                         float* d_grads, void* d_workspace, void* d_trace, void* stream) {
+    SIMQ_REQUIRE(plan && d_params && d_wcache && d_dq && d_grads && d_workspace && d_trace, "backward_traced: NULL argument");
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096, "backward: batch=%d out of range", batch);
+    Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    c.trace = static_cast<char*>(d_trace);
+    RC(attach_backward_side(c));
+    return backward_impl(c, d_dq, 0);
 }
 
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,

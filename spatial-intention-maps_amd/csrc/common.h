@@ -125,6 +125,10 @@ struct InBn {
 // profile.hip: optional HIP-event timing of GEMM-class launches (kind 0 = implicit GEMM fwd/dgrad, 1 = wgrad)
 void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream);
 void prof_launch_end(hipStream_t stream);
+// ... and a launch log: every launcher names the kernel FAMILY that took the launch (a string literal); simq_launch_count reports how
+// often each ran since simq_launch_counts_reset.  Always on (one relaxed atomic increment per launch).  The tests that claim "the
+// whole-map image tile / the LDS-resident 64-channel kernel / ... ran at this batch size" assert it through this log.
+void note_launch(const char* family);
 
 int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& g, const ConvEpilogue& e,
                       hipStream_t stream, const InBn& in = InBn());

@@ -560,6 +560,7 @@ int run(const IgemmArgs& a, hipStream_t stream, const LaunchTune& tune, int batc
     // algorithmic work: 2*M*N*K flops; bytes = read x once + read w once + write y once
     // profiling kinds: 0 = the dominant kernel of the headline workload (the batched transform-domain GEMM of the Winograd
     // layers), 2 = every other implicit-GEMM launch, 1 = wgrad
+    note_launch(BATCHED ? "gemm_f32_batched" : (VEC ? "igemm_f32" : "igemm_f32_gather"));
     prof_launch_begin(BATCHED ? 0 : 2, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);

@@ -140,6 +140,7 @@ int try_conv_igemm_bf16_c64(const IgemmBfArgs& a, hipStream_t stream) {
     IgemmBfArgs p = a;
     p.tilesN = p.Cout / BN;
     p.xcd_chunk = 0;
+    note_launch("igemm_bf16_c64");
     prof_launch_begin(2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout), stream);
     hipLaunchKernelGGL(igemm_bf16_c64_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, stream, p);

@@ -252,6 +252,7 @@ int run(const IgemmBfArgs& a, hipStream_t stream) {
     p.tilesN = p.Cout / BN;
     p.xcd_chunk = bf16_xcd_chunk(((p.M + BM - 1) / BM) * p.tilesN, p.tilesN);
     const int tilesM = (p.M + BM - 1) / BM;
+    note_launch("igemm_bf16_dma");
     prof_launch_begin(2, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);

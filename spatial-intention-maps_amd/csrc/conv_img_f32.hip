@@ -233,6 +233,7 @@ int try_conv_img_f32(const float* x, const float* w, float* y, const ConvGeom& g
     p.in = in;
     const unsigned blocks = (unsigned)(g.B * (HW / ROWS) * p.tilesN);
     if (blocks > 512) return 0;                                  // more rounds: the implicit-GEMM tiles win (see the header)
+    note_launch("conv_img_f32");
     prof_launch_begin(2, 2.0 * p.M * p.Cout * TAPS * CIN, 4.0 * ((double)p.M * CIN + (double)p.Cout * TAPS * CIN + (double)p.M * p.Cout), stream);
     if (in.on()) hipLaunchKernelGGL(conv_img_f32_kernel<true>, dim3(blocks), dim3(NW * 64), 0, stream, p);
     else hipLaunchKernelGGL(conv_img_f32_kernel<false>, dim3(blocks), dim3(NW * 64), 0, stream, p);

@@ -303,6 +303,7 @@ int run(const WgradArgs& a, hipStream_t stream, const LaunchTune& tune, int batc
     // B = 32) and are not bound by their L2 misses, unlike the bf16 kernel's at B = 128 (conv_wgrad_bf16.hip: 237 -> 63 MB, + 0.5-1 %)
     p.xcd_group = (tune.wgrad_xcd_group == 2 && batch == 1 && splits >= 8 && tiles > 1) ? 1 : 0;
     const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
+    note_launch(batch > 1 ? "wgrad_f32_batched" : "wgrad_f32");
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K * batch,
                       4.0 * batch * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);

@@ -287,6 +287,7 @@ int run(const WgradBfArgs& a, hipStream_t stream, int tune_xcd_group) {
     static const int group_env = SIMQ_TUNE_INT("SIMQ_WGRAD_BF16_XCD_GROUP", 1);      // (ablation build: 0 = launch order)
     p.xcd_group = (group_env && tune_xcd_group != 0 && splits >= 8 && tiles > 1) ? 1 : 0;
     const int launch_splits = p.xcd_group ? ((splits + 7) / 8) * 8 : splits;
+    note_launch(NP == 2 ? "wgrad_bf16x3_reg" : "wgrad_bf16_reg");
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K,
                       4.0 * ((double)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.Cin + (double)p.Cout * p.K + (double)p.M * p.Cout),
                       stream);

@@ -375,6 +375,7 @@ int try_conv_wgrad_bf16_img(const uint16_t* x, const uint16_t* dy, float* dw, co
     p.imgs_per_split = (g.B + splits - 1) / splits;
     splits = (g.B + p.imgs_per_split - 1) / p.imgs_per_split;        // only splits that own an image: every launched block writes its slab
     p.splits = splits;
+    note_launch("wgrad_bf16_img");
     prof_launch_begin(1, 2.0 * g.M() * p.Cout * p.K, 2.0 * ((double)g.M() * (g.Cin + g.Cout)) + 4.0 * (double)p.Cout * p.K, stream);
     const dim3 grid((unsigned)(tiles * splits)), block(NW * 64);
     p.dbg = 0;

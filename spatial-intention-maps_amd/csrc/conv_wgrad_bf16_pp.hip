@@ -242,6 +242,7 @@ int try_conv_wgrad_bf16_pp(const uint16_t* x, const uint16_t* dy, float* dw, con
     rps = ((rps + BRB - 1) / BRB) * BRB;
     const int splits = (p.M + rps - 1) / rps;
     p.rows_per_split = rps;
+    note_launch("wgrad_bf16_pp");
     prof_launch_begin(1, 2.0 * p.M * p.Cout * p.K, 2.0 * ((double)p.M * (g.Cin + g.Cout)) + 4.0 * (double)p.Cout * p.K, stream);
     hipLaunchKernelGGL(wgrad_bf16_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(NW * 64), 0, stream, p);
     prof_launch_end(stream);

@@ -757,6 +757,7 @@ int launch_conv_winograd(const float* x, const float* U, float* y, const ConvGeo
     // statistics: few blocks, one fp64 atomic per channel and block (the step is insensitive to this cap from 256 to 2048)
     bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 512 : 4096);
     const EpiArgs ea = make_epi(y, e);
+    note_launch("winograd_f2");
     hipLaunchKernelGGL(wino_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -799,6 +800,7 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     // blocks did two grid-stride trips while the rest did one (the launch took the time of two).  Up to 1024 blocks, equal trips each.
     bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 1024 : 4096);
     const EpiArgs ea = make_epi(y, e);
+    note_launch("winograd_f4");
     hipLaunchKernelGGL(wino4f_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T4);
     SIMQ_CHECK_LAUNCH();
     return 0;
@@ -862,6 +864,7 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
         if (int rc = launch_gemm_batched(dMt4, Vt4, dU4, g.Cout, g.Cin, Kc, 36 * S, stream, g.tune)) return rc;
         int blocks4 = (g.Cout * g.Cin + 255) / 256;
         if (blocks4 > 2048) blocks4 = 2048;
+        note_launch("winograd_f4_wgrad");
         hipLaunchKernelGGL(wino4_dw_kernel, dim3(blocks4), dim3(256), 0, stream, dU4, dw, g.Cout, g.Cin, S);
         SIMQ_CHECK_LAUNCH();
         return 0;
@@ -889,6 +892,7 @@ int launch_conv_wgrad_winograd(const float* x, const float* dy, float* dw, const
     }
     int blocks = (g.Cout * g.Cin + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    note_launch("winograd_f2_wgrad");
     hipLaunchKernelGGL(wino_dw_kernel, dim3(blocks), dim3(256), 0, stream, dU, dw, g.Cout, g.Cin);
     SIMQ_CHECK_LAUNCH();
     return 0;

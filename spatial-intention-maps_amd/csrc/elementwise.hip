@@ -664,6 +664,7 @@ int launch_bn_apply(const float* y, const BnRef& bn, const float* res, const BnR
     SIMQ_REQUIRE(out || pl.hi, "bn_apply: no output requested");
     if (y_bf16 && !out && pl.hi && !pl.lo && !res && !res_pl.lo && C % 8 == 0 && 256 % (C / 8) == 0 && C <= 512) {   // all-bf16 form
         size_t total8 = (size_t)rows * (C / 8);
+        note_launch("bn_apply16");
         hipLaunchKernelGGL(bn_apply16_kernel, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(y), bn, res_pl.hi,
                            rbn ? *rbn : bn, rbn ? 1 : 0, relu, pl.hi, total8, C / 8);
         SIMQ_CHECK_LAUNCH();
@@ -738,6 +739,7 @@ int launch_bn_bwd_apply(const float* g, const float* mask, const float* y, const
     if (g_bf16 && y_bf16 && (mask16 || mscale) && !mask && !dy && pl.hi && !pl.lo && C % 8 == 0 && 256 % (C / 8) == 0) {   // all-bf16 form
         size_t total8 = (size_t)rows * (C / 8);
         const float inv_rows = (float)(1.0 / (global_rows > 0.0 ? global_rows : (double)rows));
+        note_launch(mscale ? "bn_bwd_apply16_mask_from_y" : "bn_bwd_apply16");
         if (mscale) hipLaunchKernelGGL(bn_bwd_apply16_kernel<true>, dim3(grid_for(total8)), dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(g), mask16,
                                        reinterpret_cast<const uint16_t*>(y), mean, invstd, gamma, red, pl.hi, reinterpret_cast<uint16_t*>(dz_out), dgamma, dbeta,
                                        total8, C / 8, inv_rows, dparam_scale, mscale, mshift);

@@ -221,6 +221,7 @@ int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, 
     p.xcd_chunk = (remap && p.tilesN > 1 && tiles >= 64 && tiles % 8 == 0) ? tiles / 8 : 0;
     p.tiles = tiles; p.batch = batch;
     p.full = remap ? (batch / 8) * 8 : 0;
+    note_launch("gemm_f32_pp");
     prof_launch_begin(0, 2.0 * M * N * K * batch, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N), stream);
     const dim3 grid((unsigned)tiles * (unsigned)batch);
 #ifdef SIMQ_ABLATIONS      // timing ablations (tools/f32pp_check.py): compiled into libsimq_ablate.so only

@@ -385,6 +385,12 @@ int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name,
         else if (w == "bn1") bnaux(b.b1);
         else if (w == "bn2") bnaux(b.b2);
         else if (w == "bnd" && b.has_ds) bnaux(b.bds);
+        // the BatchNorm's fp64 reduction slot [2*C]: after a forward pass [sum | sum of squares] of the pre-BN output, after a backward
+        // pass [sum dz | sum dz*xhat] as the fused dgrad epilogue (or the reduction launch) left them
+        auto bnred = [&](const BnL& bn) { off = L.red + bn.red_off * (int64_t)sizeof(double); cnt = 2 * (int64_t)bn.C; ch = bn.C; st = 2; };
+        if (w == "red1") bnred(b.b1);
+        else if (w == "red2") bnred(b.b2);
+        else if (w == "redd" && b.has_ds) bnred(b.bds);
         if ((w == "a1") && plan->precision == SIMQ_PREC_FP32 && plan->opt.fuse_bn1_apply && plan->opt.fuse_bn_backward_sums) off = -1;   // never stored
     } else if (std::string(name) == "stem.pool.plane" && mc) {
         off = L.p_pooled; ch = 64; cnt = (int64_t)batch * 576 * 64; st = 1;

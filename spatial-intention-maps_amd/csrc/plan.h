@@ -150,6 +150,8 @@ struct Ctx {
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
     hipEvent_t ev_wdone[2] = {nullptr, nullptr};   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
     // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
+    // inspection aid: simq_backward_traced copies the gradient tensors of the walk here as they become final (TraceLayout), nullptr otherwise
+    char* trace = nullptr;
     double bn_rows(int64_t rows) const { return sync ? (double)rows / (double)B * (double)sync->global_batch : (double)rows; }
     int sync_reduce(double* buf, int64_t count) const { return sync ? sync->reduce(sync->user, buf, count, stream) : 0; }
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
@@ -227,6 +229,18 @@ constexpr int kPhaseSplitBlock = 6;   // first block (walking backwards) that be
 
 // one-hot form of the upstream gradient (the TD loss): dQ[b][action[b]] = clamp(q_sa[b] - y[b], -1, 1) * grad_scale
 struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; float grad_scale; };
+
+// simq_backward_traced: where the walk's gradient tensors are copied to (byte offsets into the caller's trace buffer, 256-B aligned).
+// Per residual block, in the order the walk produces them: g_out (gradient w.r.t. the block output, as the block receives it), dy2
+// (w.r.t. conv2's pre-BN output), t1 (identity blocks: dz = g_out * [out > 0], the shortcut's addend; downsample blocks: dyd, w.r.t. the
+// downsample convolution's pre-BN output), da1 (w.r.t. the activation between the convolutions), dy1 (w.r.t. conv1's pre-BN output),
+// g_ds (downsample blocks: the downsample convolution's data gradient, the addend of conv1's), g_in (w.r.t. the block input).  Storage follows the plan: plain-bf16 plans keep dy* as bf16 planes and the others as bf16 values
+// (Ctx::gbf), every other plan fp32.
+struct TraceLayout {
+    struct Blk { int64_t g_out, dy2, t1, da1, dy1, g_ds, g_in; } blk[8];      // g_ds: downsample blocks only (-1 otherwise)
+    int64_t total;
+};
+TraceLayout make_trace_layout(const simq_plan* p, int B);   // backward.hip
 
 // backward.hip: the autograd graph torch builds for FCN.forward (loss.backward(), train.py:132)
 int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* oh = nullptr);

@@ -1,5 +1,9 @@
 // Optional per-launch timing of the two GEMM-class kernels with HIP events recorded on the launch
 // stream (bench.py's live roofline measurement).  Off by default: zero overhead in normal runs.
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/simq.h"
@@ -12,6 +16,29 @@ struct Rec { int kind; double flops, bytes; hipEvent_t e0, e1; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
+
+// launch log: a small fixed table keyed by the family's name
+constexpr int kMaxFamilies = 64;
+struct Family { const char* name; std::atomic<int64_t> count; };
+Family g_fam[kMaxFamilies];
+std::atomic<int> g_nfam{0};
+std::mutex g_fam_mu;
+
+Family* family_slot(const char* name, bool create) {
+    const int n = g_nfam.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (g_fam[i].name == name || strcmp(g_fam[i].name, name) == 0) return &g_fam[i];
+    if (!create) return nullptr;
+    std::lock_guard<std::mutex> lk(g_fam_mu);
+    const int m = g_nfam.load(std::memory_order_acquire);
+    for (int i = n; i < m; ++i)
+        if (strcmp(g_fam[i].name, name) == 0) return &g_fam[i];
+    if (m >= kMaxFamilies) return nullptr;
+    g_fam[m].name = name;
+    g_fam[m].count.store(0, std::memory_order_relaxed);
+    g_nfam.store(m + 1, std::memory_order_release);
+    return &g_fam[m];
+}
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -27,6 +54,10 @@ void prof_launch_begin(int kind, double flops, double bytes, hipStream_t stream)
     if (!r.e0 || !r.e1) return;
     (void)hipEventRecord(r.e0, stream);
     g_recs.push_back(r);
+}
+
+void note_launch(const char* family) {
+    if (Family* f = family_slot(family, true)) f->count.fetch_add(1, std::memory_order_relaxed);
 }
 
 void prof_launch_end(hipStream_t stream) {
@@ -63,6 +94,34 @@ int simq_profile_stop(double* out, int max_kinds) {
         g_pool.push_back(r.e1);
     }
     g_recs.clear();
+    return 0;
+}
+
+int simq_launch_counts_reset(void) {
+    const int n = simq::g_nfam.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i) simq::g_fam[i].count.store(0, std::memory_order_relaxed);
+    return 0;
+}
+
+int64_t simq_launch_count(const char* family) {
+    if (!family) return -1;
+    simq::Family* f = simq::family_slot(family, false);
+    return f ? f->count.load(std::memory_order_relaxed) : 0;
+}
+
+// "name=count;name=count;..." of every family that ran since the reset
+int simq_launch_counts(char* buf, int cap) {
+    SIMQ_REQUIRE(buf && cap > 0, "launch_counts: bad buffer");
+    int used = 0;
+    buf[0] = 0;
+    const int n = simq::g_nfam.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i) {
+        const long long c = (long long)simq::g_fam[i].count.load(std::memory_order_relaxed);
+        if (c == 0) continue;
+        const int w = snprintf(buf + used, (size_t)(cap - used), "%s=%lld;", simq::g_fam[i].name, c);
+        if (w < 0 || w >= cap - used) { buf[used] = 0; break; }
+        used += w;
+    }
     return 0;
 }
 

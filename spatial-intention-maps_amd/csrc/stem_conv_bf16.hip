@@ -321,6 +321,7 @@ int launch_stem_wgrad_bf16(const float* x, const uint16_t* dy, float* dw, float*
     p.x = x; p.dy = dy; p.partial = partial;
     p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = H / 2; p.Wo = W / 2;
     const int slabs = stem_wgrad_bf16_slabs(B, H, W);
+    note_launch("stem_wgrad_bf16");
     hipLaunchKernelGGL(stem_wgrad_bf16_kernel, dim3(slabs), dim3(WG_WAVES * 64), 0, stream, p);
     SIMQ_CHECK_LAUNCH();
     const int n = COUT * R * R * C;
@@ -359,6 +360,7 @@ int launch_stem_conv_bf16(const float* x, const uint16_t* w16, uint16_t* y, doub
         SIMQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
+    note_launch("stem_conv_bf16");
     hipLaunchKernelGGL(stem_conv_bf16_kernel, dim3(blocks), dim3(NWAVE * 64), smem, stream, p);
     SIMQ_CHECK_LAUNCH();
     return 0;

@@ -207,6 +207,7 @@ int launch_stem_conv_f32(const float* x, const float* w_ohwi, float* y, double* 
         SIMQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_smem[dev][nss].store(smem, std::memory_order_relaxed);
     }
+    note_launch("stem_conv_f32");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVE * 64), smem, stream, p);
     SIMQ_CHECK_LAUNCH();
     return 0;

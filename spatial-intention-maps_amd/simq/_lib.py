@@ -98,6 +98,9 @@ _SIGS = {
     'simq_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_backward_phase': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_grad_bucket_split': (c_int64, [c_void_p]),
+    'simq_backward_trace_bytes': (c_int64, [c_void_p, c_int]),
+    'simq_backward_trace_tensor': (c_int, [c_void_p, c_int, c_char_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]),
+    'simq_backward_traced': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_train_step': (c_int, [c_void_p]),
     'simq_train_loss_wait': (c_int, [c_void_p]),
     'simq_backward_onehot': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
@@ -125,6 +128,9 @@ _SIGS = {
     'simq_upsample2x_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'simq_profile_start': (c_int, []),
     'simq_profile_stop': (c_int, [c_void_p, c_int]),
+    'simq_launch_counts_reset': (c_int, []),
+    'simq_launch_count': (c_int64, [c_char_p]),
+    'simq_launch_counts': (c_int, [c_char_p, c_int]),
     'simq_conv2d_wgrad_winograd': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p] + [c_void_p]),
     'simq_conv2d_fwd_winograd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
     'simq_conv2d_fwd_winograd4': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
@@ -156,6 +162,13 @@ EXPORTS = tuple(_SIGS)
 OPTS_FUNCS = frozenset(('simq_conv2d_fwd', 'simq_conv2d_dgrad', 'simq_conv2d_wgrad', 'simq_conv2d_fwd_bf16', 'simq_conv2d_wgrad_bf16',
                         'simq_conv2d_wgrad_bf16_slab', 'simq_conv2d_wgrad_winograd', 'simq_conv2d_fwd_winograd', 'simq_conv2d_fwd_winograd4',
                         'simq_conv2d_fwd_bnrelu_in', 'simq_conv2d_wgrad_bnrelu_in'))
+
+
+def launch_counts():
+    """{kernel family: launches since the last simq_launch_counts_reset} (include/simq.h: the launch log)."""
+    buf = ctypes.create_string_buffer(4096)
+    check(_c.simq_launch_counts(buf, 4096), 'simq_launch_counts')
+    return {kv.split('=')[0]: int(kv.split('=')[1]) for kv in buf.value.decode().split(';') if kv}
 
 
 def launch_opts(tile=None, **fields):

@@ -333,11 +333,14 @@ class FCN(torch.nn.Module):
 
     def stored_tensor(self, name, batch, slot='train'):
         """A block-internal tensor of the last forward in workspace `slot` (simq_workspace_tensor_ex: 'layer<l>.<b>.<y1|a1|y2|yd|out>' as
-        [B,24,24,C] fp32 or bf16, 'layer<l>.<b>.<bn1|bn2|bnd>' as [4,C] = scale | shift | mean | invstd, 'stem.pool.plane') -- teacher-forced tests."""
+        [B,24,24,C] fp32 or bf16, 'layer<l>.<b>.<bn1|bn2|bnd>' as [4,C] = scale | shift | mean | invstd, 'layer<l>.<b>.<red1|red2|redd>' as [2,C] fp64,
+        'stem.pool.plane') -- teacher-forced tests."""
         import ctypes
         off, n, ch, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
         lib.call('simq_workspace_tensor_ex', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch), ctypes.byref(st))
         ws = self._ws[slot]
+        if st.value == 2:
+            return ws[off.value:off.value + 8 * n.value].view(torch.float64).view(2, ch.value)
         if st.value:
             t = ws[off.value:off.value + 2 * n.value].view(torch.bfloat16)
         else:
@@ -345,6 +348,28 @@ class FCN(torch.nn.Module):
         if n.value == 4 * ch.value:
             return t.view(4, ch.value)
         return t.view(batch, 24, 24, ch.value)
+
+    def backward_traced(self, dq, batch):
+        """simq_backward_traced: the backward pass of the last grad-mode forward with every gradient tensor of the residual blocks' walk
+        kept (teacher-forced tests).  Returns (flat gradient buffer, lookup) with lookup('layer<l>.<b>.<g_out|dy2|dz|dyd|da1|dy1|g_in>') ->
+        [B,24,24,C] tensor in the plan's storage type."""
+        import ctypes
+        ws = self._ws.get('train')
+        if ws is None:
+            raise SimqError('simq.FCN: backward without a grad-mode forward')
+        trace = torch.empty(int(lib.c.simq_backward_trace_bytes(self.plan.handle, batch)), dtype=torch.uint8, device=self.device_)
+        lib.call('simq_backward_traced', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq.contiguous()), ptr(self.flat_grads),
+                 ptr(ws), ptr(trace), stream_ptr(self.device_))
+
+        def lookup(name):
+            off, n, ch, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+            lib.call('simq_backward_trace_tensor', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch), ctypes.byref(st))
+            if st.value:
+                t = trace[off.value:off.value + 2 * n.value].view(torch.bfloat16)
+            else:
+                t = trace[off.value:off.value + 4 * n.value].view(torch.float32)
+            return t.view(batch, 24, 24, ch.value)
+        return self.flat_grads, lookup
 
     def infer_argmax_batch(self, states, need_q=False):
         """Eval-mode forward of several HWC states (numpy [96,96,C] or device tensors [1,96,96,C]) in ONE batch + one

@@ -159,7 +159,28 @@ def _fma32(y, sc, sh):
     return (y.double() * sc.double() + sh.double()).float()
 
 
-@pytest.mark.parametrize('B', [6, 29], ids=['b6', 'b29'])
+def _host_threads():
+    """fp64 reference convolutions on the host: capped (MKL's dgemm beyond ~32 threads gets SLOWER on the 256-CPU boxes)."""
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def _check_conv(name, got16, ref64, log):
+    """stored bf16 value == bf16(fp64 convolution of the stored bf16 operands) except where fp32 accumulation crosses a rounding boundary:
+    < 1 % of the elements, each one bf16 ulp."""
+    want = ref64.to(torch.bfloat16)
+    frac = float((got16 != want).double().mean())
+    worst = float(((got16.double() - ref64).abs() / ref64.abs().clamp_min(1e-2 * float(ref64.abs().max()))).max())
+    log.append('  %-22s %.4f %% of the stored elements differ from bf16(fp64), worst %.3g of the value' % (name, 100 * frac, worst))
+    assert frac < 1e-2 and worst < 2 ** -7, (name, frac, worst)
+
+
+# kernel families (include/simq.h: the launch log) the bench's batch size is meant to select, and must have selected, in these tests
+_FWD_FAMILIES_B128 = ('igemm_bf16_img_whole', 'igemm_bf16_img_half', 'igemm_bf16_c64', 'stem_conv_bf16', 'bn_apply16')
+_BWD_FAMILIES_B128 = ('igemm_bf16_img_whole', 'igemm_bf16_img_half', 'igemm_bf16_c64', 'wgrad_bf16_img', 'wgrad_bf16_reg', 'stem_wgrad_bf16',
+                      'bn_bwd_apply16', 'bn_bwd_apply16_mask_from_y')
+
+
+@pytest.mark.parametrize('B', [6, 29, 128], ids=['b6', 'b29', 'b128'])
 def test_bf16_forward_teacher_forced_block_by_block(simq_mod, B):
     """Network-level and flip-free: after ONE train-mode forward of the bf16 plan every tensor the residual blocks STORE (pre-BatchNorm outputs,
     the activation between the two convolutions, the block output, the BatchNorm coefficients) is recomputed in fp64 from the stored tensors it
@@ -170,73 +191,208 @@ def test_bf16_forward_teacher_forced_block_by_block(simq_mod, B):
       BatchNorm      mean / invstd against the statistics of the fp64 convolution output at 2e-5; scale / shift = their gamma / beta form;
       elementwise    a1 = bf16(relu(fma(y1, scale, shift))) and out = bf16(relu(fma(y2, scale2, shift2) + identity)) -- identity = the stored
                      plane, the fp32 pooled map (block 1) or fma(yd, scale_d, shift_d) -- BIT-EXACT up to a 1e-4 fraction of half-way cases.
-    This is what would catch a wrong residual plane, mask / activation plane, or bn_apply16 at network level (resnet.py:31-47)."""
+    This is what would catch a wrong residual plane, mask / activation plane, or bn_apply16 at network level (resnet.py:31-47).
+    B = 128 is the batch the bench's bf16 leg runs (configs[2], configs[4] per GPU): only there are the whole-map image tile, the half-map
+    tile of the 128-channel layers, the LDS-resident kernel of the 64-input-channel layers and the large-tile 1x1 kernels selected -- asserted
+    through the launch log (B = 6 / 29 run the register-staged and 288-row LDS-DMA tiles instead)."""
     import torch.nn.functional as F
+    from simq import _lib
     from simq._lib import MODE_TRAIN
     cin, cout = 5, 2
     net = simq_mod.FCN(cin, cout, precision='bf16')
     net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 77)))
     net.train()
     x = torch.cat([olearner.apply_transform(s) for s in synth.make_states(B, cin, 78)]).permute(0, 2, 3, 1).contiguous().cuda()
+    net._ensure_weights()
+    _lib.lib.call('simq_launch_counts_reset')
     net._forward_raw(x, MODE_TRAIN)
     torch.cuda.synchronize()
-    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    nchw = lambda t: t.permute(0, 3, 1, 2)
-    stored = lambda name: net.stored_tensor(name, B, 'train').cpu()
-    rnd = lambda t: t.to(torch.bfloat16)
+    ran = _lib.launch_counts()
+    print('\n  B = %d forward launch log: %s' % (B, ', '.join('%s x %d' % kv for kv in sorted(ran.items()))))
+    if B == 128:
+        missing = [f for f in _FWD_FAMILIES_B128 if ran.get(f, 0) == 0]
+        assert not missing, 'B = 128 forward did not select %s (ran: %s)' % (missing, ran)
+        assert ran.get('igemm_bf16_pp', 0) + ran.get('igemm_bf16_dma', 0) > 0          # the 1x1 downsample / head convolutions: large LDS-DMA tiles
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    try:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        stored = lambda name: net.stored_tensor(name, B, 'train').cpu()
+        rnd = lambda t: t.to(torch.bfloat16)
+        log = []
 
-    def check_conv(name, got16, ref64):
-        want = ref64.to(torch.bfloat16)
-        off = (got16 != want)
-        frac = float(off.double().mean())
-        worst = float(((got16.double() - ref64).abs() / ref64.abs().clamp_min(1e-2 * float(ref64.abs().max()))).max())
-        print('  %-18s %.4f %% of the stored elements differ from bf16(fp64 conv), worst %.3g of the value' % (name, 100 * frac, worst))
-        assert frac < 1e-2 and worst < 2 ** -7, name
+        def check_bn(name, aux, ref64, gamma, beta):
+            mean = ref64.mean(dim=(0, 2, 3))
+            var = ref64.var(dim=(0, 2, 3), unbiased=False)
+            invstd = 1.0 / torch.sqrt(var + 1e-5)
+            rng = float(ref64.abs().max())
+            assert float((aux[2].double() - mean).abs().max()) < 2e-5 * rng and relmax(aux[3], invstd) < 2e-5, name
+            sc = gamma.double() * aux[3].double()
+            assert relmax(aux[0], sc) < 1e-6 and float((aux[1].double() - (beta.double() - aux[2].double() * sc)).abs().max()) < 1e-5 * max(1.0, float(sc.abs().max()) * rng), name
 
-    def check_bn(name, aux, ref64, gamma, beta):
-        mean = ref64.mean(dim=(0, 2, 3))
-        var = ref64.var(dim=(0, 2, 3), unbiased=False)
-        invstd = 1.0 / torch.sqrt(var + 1e-5)
-        rng = float(ref64.abs().max())
-        assert float((aux[2].double() - mean).abs().max()) < 2e-5 * rng and relmax(aux[3], invstd) < 2e-5, name
-        sc = gamma.double() * aux[3].double()
-        assert relmax(aux[0], sc) < 1e-6 and float((aux[1].double() - (beta.double() - aux[2].double() * sc)).abs().max()) < 1e-5 * max(1.0, float(sc.abs().max()) * rng), name
+        def check_exact(name, got16, want32):
+            want = want32.to(torch.bfloat16)
+            frac = float((got16 != want).double().mean())
+            log.append('  %-22s %.5f %% of the elements differ from the bit-exact emulation' % (name, 100 * frac))
+            assert frac < 1e-4, name
+        cur16 = stored('stem.pool.plane')
+        cur_id = net.saved_activation('stem.pool', B, 'train').cpu()          # fp32: block 1's identity shortcut
+        assert torch.equal(cur16, cur_id.to(torch.bfloat16))
+        r = 'module.resnet18.'
+        for li in range(1, 5):
+            for bi in range(2):
+                b, key = 'layer%d.%d' % (li, bi), '%slayer%d.%d.' % (r, li, bi)
+                xin = nchw(cur16.double())
+                y1 = stored(b + '.y1')
+                y1ref = F.conv2d(xin, rnd(sd[key + 'conv1.weight']).double(), padding=1)
+                _check_conv(b + '.conv1', nchw(y1), y1ref, log)
+                a1x = stored(b + '.bn1')
+                check_bn(b + '.bn1', a1x, y1ref, sd[key + 'bn1.weight'], sd[key + 'bn1.bias'])
+                a1 = stored(b + '.a1')
+                check_exact(b + '.a1', a1, torch.relu(_fma32(y1.float(), a1x[0], a1x[1])))
+                y2 = stored(b + '.y2')
+                y2ref = F.conv2d(nchw(a1.double()), rnd(sd[key + 'conv2.weight']).double(), padding=1)
+                _check_conv(b + '.conv2', nchw(y2), y2ref, log)
+                a2x = stored(b + '.bn2')
+                check_bn(b + '.bn2', a2x, y2ref, sd[key + 'bn2.weight'], sd[key + 'bn2.bias'])
+                if (key + 'downsample.0.weight') in sd:
+                    yd = stored(b + '.yd')
+                    ydref = F.conv2d(xin, rnd(sd[key + 'downsample.0.weight']).double())
+                    _check_conv(b + '.downsample', nchw(yd), ydref, log)
+                    adx = stored(b + '.bnd')
+                    check_bn(b + '.bnd', adx, ydref, sd[key + 'downsample.1.weight'], sd[key + 'downsample.1.bias'])
+                    identity = _fma32(yd.float(), adx[0], adx[1])
+                else:
+                    identity = cur_id.float()
+                out = stored(b + '.out')
+                v = (_fma32(y2.float(), a2x[0], a2x[1]).double() + identity.double()).float()
+                check_exact(b + '.out', out, torch.relu(v))
+                cur16, cur_id = out, out.float()
+        print('\n'.join(log))
+    finally:
+        torch.set_num_threads(keep_threads)
 
-    def check_exact(name, got16, want32):
-        want = want32.to(torch.bfloat16)
-        frac = float((got16 != want).double().mean())
-        print('  %-18s %.5f %% of the elements differ from the bit-exact emulation' % (name, 100 * frac))
-        assert frac < 1e-4, name
-    cur16 = stored('stem.pool.plane')
-    cur_id = net.saved_activation('stem.pool', B, 'train').cpu()          # fp32: block 1's identity shortcut
-    assert torch.equal(cur16, cur_id.to(torch.bfloat16))
-    r = 'module.resnet18.'
-    for li in range(1, 5):
-        for bi in range(2):
-            b, key = 'layer%d.%d' % (li, bi), '%slayer%d.%d.' % (r, li, bi)
-            xin = nchw(cur16.double())
-            y1 = stored(b + '.y1')
-            y1ref = F.conv2d(xin, rnd(sd[key + 'conv1.weight']).double(), padding=1)
-            check_conv(b + '.conv1', nchw(y1), y1ref)
-            a1x = stored(b + '.bn1')
-            check_bn(b + '.bn1', a1x, y1ref, sd[key + 'bn1.weight'], sd[key + 'bn1.bias'])
-            a1 = stored(b + '.a1')
-            check_exact(b + '.a1', a1, torch.relu(_fma32(y1.float(), a1x[0], a1x[1])))
-            y2 = stored(b + '.y2')
-            y2ref = F.conv2d(nchw(a1.double()), rnd(sd[key + 'conv2.weight']).double(), padding=1)
-            check_conv(b + '.conv2', nchw(y2), y2ref)
-            a2x = stored(b + '.bn2')
-            check_bn(b + '.bn2', a2x, y2ref, sd[key + 'bn2.weight'], sd[key + 'bn2.bias'])
-            if (key + 'downsample.0.weight') in sd:
-                yd = stored(b + '.yd')
-                ydref = F.conv2d(xin, rnd(sd[key + 'downsample.0.weight']).double())
-                check_conv(b + '.downsample', nchw(yd), ydref)
-                adx = stored(b + '.bnd')
-                check_bn(b + '.bnd', adx, ydref, sd[key + 'downsample.1.weight'], sd[key + 'downsample.1.bias'])
-                identity = _fma32(yd.float(), adx[0], adx[1])
-            else:
-                identity = cur_id.float()
-            out = stored(b + '.out')
-            v = (_fma32(y2.float(), a2x[0], a2x[1]).double() + identity.double()).float()
-            check_exact(b + '.out', out, torch.relu(v))
-            cur16, cur_id = out, out.float()
+
+@pytest.mark.parametrize('B', [6, 29, 128], ids=['b6', 'b29', 'b128'])
+def test_bf16_backward_teacher_forced_block_by_block(simq_mod, B):
+    """The backward walk of the bf16 plan (loss.backward(), train.py:132, through resnet.py:31-47 reversed), network-level and flip-free: after
+    ONE train-mode forward and ONE backward with a dense seeded upstream gradient every gradient tensor the walk produces inside a residual
+    block (simq_backward_traced keeps them; the walk itself reuses four temporaries) and every parameter gradient of the block is recomputed
+    in fp64 from the STORED tensors it was made from -- the forward's stored bf16 tensors (simq_workspace_tensor_ex) and the traced bf16
+    gradients -- so that a rounding which differs from the recomputation's cannot propagate and every comparison has a single kernel's bar:
+      g_out -> [out > 0] -> BatchNorm-2 backward (dy2; dz for the identity shortcut; dyd through the downsample BatchNorm) -> conv2's data
+      gradient (da1) -> ReLU mask from the stored PRE-BatchNorm output y1 (bn1_mask_from_preact: fma(y1, scale, shift) > 0) -> BatchNorm-1
+      backward (dy1) -> conv1's data gradient + shortcut (g_in), and each layer's weight gradient = conv2d_weight(stored bf16 x, stored bf16 dy).
+    Bars:
+      stored bf16 gradient planes == bf16(fp64 recomputation) on all but < 1 % of the elements, each within one bf16 ulp;
+      convolution weight gradients 2e-5 (max-abs over max-abs) against fp64 on the stored operands;
+      the BatchNorm backward sums [sum dz | sum dz*xhat] the fused dgrad epilogues leave (formed from the fp32 values BEFORE they are rounded
+      to the stored bf16): within the rounding noise of that storage, 3 * 2^-9 * ||dz||_2 per channel (a wrong mask source / y plane / mean
+      moves them by ~sqrt(rows) times that), and d gamma / d beta == (float)those sums.
+    g_in of block k must equal g_out of block k - 1 bit for bit (same buffer).  B = 128 is the bench's batch: the image-tile dgrad / weight-
+    gradient kernels, the LDS-resident 64-channel dgrad and bn_bwd_apply16<mask from y> are selected only there (asserted, launch log)."""
+    import torch.nn.functional as F
+    from simq import _lib
+    from simq._lib import MODE_TRAIN
+    cin, cout = 5, 2
+    net = simq_mod.FCN(cin, cout, precision='bf16')
+    assert net.plan.options['bn1_mask_from_preact'] == 1 and net.plan.options['bf16_act_grads'] == 1
+    net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 81)))
+    net.train()
+    x = torch.cat([olearner.apply_transform(s) for s in synth.make_states(B, cin, 82)]).permute(0, 2, 3, 1).contiguous().cuda()
+    q = net._forward_raw(x, MODE_TRAIN)
+    dq = torch.from_numpy(cases.dense_upstream(cout, B, 83)).cuda().contiguous()
+    assert dq.shape == q.shape
+    _lib.lib.call('simq_launch_counts_reset')
+    grads_flat, traced = net.backward_traced(dq, B)
+    torch.cuda.synchronize()
+    ran = _lib.launch_counts()
+    print('\n  B = %d backward launch log: %s' % (B, ', '.join('%s x %d' % kv for kv in sorted(ran.items()))))
+    if B == 128:
+        missing = [f for f in _BWD_FAMILIES_B128 if ran.get(f, 0) == 0]
+        assert not missing, 'B = 128 backward did not select %s (ran: %s)' % (missing, ran)
+        assert ran['bn_bwd_apply16_mask_from_y'] == 8                                     # bn1 of every block: the mask recomputed from y1
+    gview = {k: v.detach().cpu().double() for (k, _, _), v in zip(net._param_names, net.reference_views(grads_flat))}
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    try:
+        sd = {k[len('module.'):]: v.detach().cpu() for k, v in net.state_dict().items()}
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        stored = lambda name: net.stored_tensor(name, B, 'train').cpu()
+        tr = lambda name: traced(name).cpu()
+        w64 = lambda k: sd[k].to(torch.bfloat16).double()
+        log = []
+        M = B * 576
+
+        def check_wgrad(key, x16, dy16, pad):
+            want = torch.nn.grad.conv2d_weight(nchw(x16.double()), tuple(sd[key].shape), nchw(dy16.double()), padding=pad)
+            err = float((gview[key] - want).abs().max() / want.abs().max())
+            log.append('  %-38s weight gradient vs fp64 on the stored operands %.2e' % (key, err))
+            assert err < 2e-5, (key, err)
+
+        def check_sums(name, red, dz64, y16, aux, gkey, bkey):
+            """red [2, C] fp64 as the dgrad epilogue left them; dz64 [B,24,24,C] = stored bf16 gradient x mask; xhat from the stored pre-BN output"""
+            xhat = (y16.double() - aux[2].double()) * aux[3].double()
+            s0, s1 = dz64.sum(dim=(0, 1, 2)), (dz64 * xhat).sum(dim=(0, 1, 2))
+            n0 = 2.0 ** -9 * torch.sqrt((dz64 ** 2).sum(dim=(0, 1, 2))).clamp_min(1e-30)
+            n1 = 2.0 ** -9 * torch.sqrt(((dz64 * xhat) ** 2).sum(dim=(0, 1, 2))).clamp_min(1e-30)
+            e0, e1 = float(((red[0] - s0).abs() / n0).max()), float(((red[1] - s1).abs() / n1).max())
+            l1 = float(((red[0] - s0).abs() / dz64.abs().sum(dim=(0, 1, 2)).clamp_min(1e-30)).max())
+            log.append('  %-22s sums vs the stored tensors: %.2f / %.2f of the bf16-storage noise 2^-9 ||dz||_2 (%.1e of sum |dz|)' % (name, e0, e1, l1))
+            assert e0 < 3.0 and e1 < 3.0, (name, e0, e1)
+            assert float((gview[bkey] - red[0].float().double()).abs().max()) <= 1e-6 * float(red[0].abs().max()), bkey      # d beta = sum dz
+            assert float((gview[gkey] - red[1].float().double()).abs().max()) <= 1e-6 * float(red[1].abs().max()), gkey      # d gamma = sum dz*xhat
+            return xhat
+
+        def bn_backward(dz64, xhat, red, gamma, aux):
+            """dy = gamma * invstd * (dz - sum(dz) / M - xhat * sum(dz*xhat) / M) with the STORED sums (elementwise.hip bn_bwd_apply)"""
+            return gamma.double() * aux[3].double() * (dz64 - red[0] / M - xhat * red[1] / M)
+        prev_g_in = None
+        for li in range(4, 0, -1):
+            for bi in (1, 0):
+                b, key = 'layer%d.%d' % (li, bi), 'resnet18.layer%d.%d.' % (li, bi)
+                has_ds = (key + 'downsample.0.weight') in sd
+                xin16 = stored('layer%d.%d.out' % ((li, 0) if bi == 1 else (li - 1, 1))) if (li, bi) != (1, 0) else stored('stem.pool.plane')
+                y1, a1, y2, out = stored(b + '.y1'), stored(b + '.a1'), stored(b + '.y2'), stored(b + '.out')
+                bn1, bn2 = stored(b + '.bn1'), stored(b + '.bn2')
+                red1, red2 = stored(b + '.red1').cpu(), stored(b + '.red2').cpu()
+                g_out = tr(b + '.g_out')
+                if prev_g_in is not None:
+                    assert torch.equal(g_out, prev_g_in), b + ': the gradient the block receives is not the one the block above produced'
+                # out = relu(bn2(y2) + identity): dz = g_out * [out > 0]
+                dz64 = g_out.double() * (out.float() > 0).double()
+                xhat2 = check_sums(b + '.bn2', red2, dz64, y2, bn2, key + 'bn2.weight', key + 'bn2.bias')
+                _check_conv(b + '.dy2', tr(b + '.dy2'), bn_backward(dz64, xhat2, red2, sd[key + 'bn2.weight'], bn2), log)
+                if has_ds:
+                    yd, bnd, redd = stored(b + '.yd'), stored(b + '.bnd'), stored(b + '.redd').cpu()
+                    xhatd = check_sums(b + '.bnd', redd, dz64, yd, bnd, key + 'downsample.1.weight', key + 'downsample.1.bias')
+                    _check_conv(b + '.dyd', tr(b + '.dyd'), bn_backward(dz64, xhatd, redd, sd[key + 'downsample.1.weight'], bnd), log)
+                else:
+                    assert torch.equal(tr(b + '.dz'), dz64.to(torch.bfloat16)), b + '.dz: the masked gradient of the identity shortcut is not exact'
+                dy2 = tr(b + '.dy2')
+                check_wgrad(key + 'conv2.weight', a1, dy2, 1)
+                da1 = tr(b + '.da1')
+                _check_conv(b + '.da1', nchw(da1), F.conv_transpose2d(nchw(dy2.double()), w64(key + 'conv2.weight'), padding=1), log)
+                # a1 = relu(bn1(y1)): the mask is recomputed from the stored pre-BN output with the forward's own scale / shift
+                mask1 = (_fma32(y1.float(), bn1[0], bn1[1]) > 0)
+                assert float((mask1 != (a1.float() > 0)).double().mean()) < 1e-6, b + ': the recomputed ReLU mask is not the mask of the stored activation'
+                dz1 = da1.double() * mask1.double()
+                xhat1 = check_sums(b + '.bn1', red1, dz1, y1, bn1, key + 'bn1.weight', key + 'bn1.bias')
+                _check_conv(b + '.dy1', tr(b + '.dy1'), bn_backward(dz1, xhat1, red1, sd[key + 'bn1.weight'], bn1), log)
+                dy1 = tr(b + '.dy1')
+                check_wgrad(key + 'conv1.weight', xin16, dy1, 1)
+                gin = F.conv_transpose2d(nchw(dy1.double()), w64(key + 'conv1.weight'), padding=1)
+                if has_ds:
+                    dyd = tr(b + '.dyd')
+                    check_wgrad(key + 'downsample.0.weight', xin16, dyd, 0)
+                    g_ds = tr(b + '.g_ds')
+                    _check_conv(b + '.g_ds', nchw(g_ds), F.conv_transpose2d(nchw(dyd.double()), w64(key + 'downsample.0.weight')), log)
+                    gin = gin + nchw(g_ds.double())
+                else:
+                    gin = gin + nchw(tr(b + '.dz').double())
+                prev_g_in = tr(b + '.g_in')
+                _check_conv(b + '.g_in', nchw(prev_g_in), gin, log)
+        print('\n'.join(log))
+    finally:
+        torch.set_num_threads(keep_threads)

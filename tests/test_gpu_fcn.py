@@ -157,7 +157,7 @@ def test_state_dict_roundtrip(simq_mod):
     assert torch.equal(other.flat_params, net.flat_params) and torch.equal(other.bn_buffers, net.bn_buffers)
 
 
-@pytest.mark.parametrize('case', cases.TRAIN_CASES[:2], ids=[c[0] for c in cases.TRAIN_CASES[:2]])
+@pytest.mark.parametrize('case', cases.TRAIN_CASES[:2] + cases.TRAIN_CASES_CIN, ids=[c[0] for c in cases.TRAIN_CASES[:2] + cases.TRAIN_CASES_CIN])
 def test_autograd_path_reference_style_train(simq_mod, case, golden_dir):
     """The reference's own train() recipe (torch gather / smooth_l1 / backward / clip / optim.SGD,
     train.py:108-141) driving simq.FCN through autograd -- only the network is HIP."""
@@ -200,9 +200,11 @@ def test_autograd_path_reference_style_train(simq_mod, case, golden_dir):
     assert abs(norms[0] - float(g['total_norm64'])) <= 5e-2 * float(g['total_norm64'])
 
 
-@pytest.mark.parametrize('case', cases.TRAIN_CASES, ids=[c[0] for c in cases.TRAIN_CASES])
+@pytest.mark.parametrize('case', cases.TRAIN_CASES + cases.TRAIN_CASES_CIN, ids=[c[0] for c in cases.TRAIN_CASES + cases.TRAIN_CASES_CIN])
 def test_fused_train_vs_golden_and_oracle(simq_mod, case, golden_dir):
-    """simq.train (drop-in signature of train.py:108) -- two consecutive calls."""
+    """simq.train (drop-in signature of train.py:108) -- two consecutive calls.  train_c{3,6,7,10}*: the reference's other input-channel
+    counts (tools_generate_experiments.py:200-204) -- the stem's forward and weight gradient address K = 49 * Cin; Cin = 10 leaves the
+    dedicated fp32 stem kernel (7 * Cin <= 64) for the generic implicit GEMM."""
     name, cin, cout, B, wseed, dseed = case
     g = np.load('%s/%s.npz' % (golden_dir, name))
     cfg = cases.make_cfg(B)
@@ -417,7 +419,7 @@ def test_precision_forward(simq_mod, case, precision, tol, golden_dir):
 
 
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
-@pytest.mark.parametrize('case', cases.TRAIN_CASES, ids=[c[0] for c in cases.TRAIN_CASES])
+@pytest.mark.parametrize('case', cases.TRAIN_CASES + cases.TRAIN_CASES_CIN, ids=[c[0] for c in cases.TRAIN_CASES + cases.TRAIN_CASES_CIN])
 def test_precision_fused_train(simq_mod, case, precision, golden_dir):
     name, cin, cout, B, wseed, dseed = case
     g = np.load('%s/%s.npz' % (golden_dir, name))
@@ -444,7 +446,7 @@ def test_precision_fused_train(simq_mod, case, precision, golden_dir):
         assert rel(policy._last['q_sa'], g['q_sa']) < 3e-4 and rel(policy._last['y'], g['y']) < 3e-4
         assert err <= max(100 * ref_err, 5e-2)
     else:
-        cal = np.load('%s/bf16_calibration.npz' % golden_dir)
+        cal = np.load('%s/%s.npz' % (golden_dir, 'bf16_calibration_cin' if case in cases.TRAIN_CASES_CIN else 'bf16_calibration'))
         print('   bf16 calibration (reference under torch.autocast): loss %.3g td %.3g grad %.3g' % (
             float(cal[name + '.loss']), float(cal[name + '.td_error']), float(cal[name + '.grad'])))
         assert rel(info['loss'], g['loss'][0]) < max(0.15, 2 * float(cal[name + '.loss']))

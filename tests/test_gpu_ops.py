@@ -49,6 +49,12 @@ CONV_CASES = [
     (2, 48, 128, 32, 1, 1, 0, True),        # head conv2 (+bias), N = 32 tile
     (2, 96, 4, 64, 7, 2, 3, False),         # stem, generic gather
     (3, 96, 5, 64, 7, 2, 3, False),         # stem, Cin = 5 (K = 245, unaligned rows)
+    # the reference's other input-channel counts (tools_generate_experiments.py:200-204): generic-gather forward (what Cin = 10 plans run:
+    # the dedicated stem kernel needs 7 * Cin <= 64) and the fp32 stem weight gradient (wgrad_kernel on K = 49 * Cin, unaligned rows)
+    (2, 96, 3, 64, 7, 2, 3, False),
+    (2, 96, 6, 64, 7, 2, 3, False),
+    (3, 96, 7, 64, 7, 2, 3, False),
+    (2, 96, 10, 64, 7, 2, 3, False),
     (16, 24, 64, 128, 3, 1, 1, False),      # enough rows for the 128x128 tile path
 ]
 
@@ -624,7 +630,7 @@ def test_conv_winograd_rejects_unsupported_geometry(L):
         L.lib.call('simq_conv2d_wgrad_winograd', L.ptr(x), L.ptr(y), L.ptr(w), 1, 24, 24, 64, 64, L.ptr(scratch), L.stream_ptr())
 
 
-@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1), (32, 4), (2, 7)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1', 'cin4_b32', 'cin7'])
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1), (32, 4), (2, 7), (3, 6)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1', 'cin4_b32', 'cin7', 'cin6'])
 def test_stem_conv_f32_matches_an_fp64_convolution(L, B, C):
     """stem_conv_f32.hip (reference resnet.py:94: conv 7x7 s2 p3 -> 64, the form fp32 / split-bf16 plans run): 16-byte runs of the NHWC
     input straight into v_mfma_f32_16x16x4_f32 (the K index of the MFMA permuted consistently on both operands), left / right / top / bottom
@@ -652,7 +658,28 @@ def test_stem_conv_f32_matches_an_fp64_convolution(L, B, C):
     assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1'])
+def test_stem_kernels_refuse_ten_input_channels(L):
+    """Cin = 10 (the reference's widest intention-channel variant): 7 * Cin = 70 exceeds the 64-float filter row both dedicated stem
+    kernels are built around -- they refuse it with a message, and plans of that width run the generic implicit GEMM / fp32 weight
+    gradient instead (forward_impl: stem_conv_f32_eligible / stem_conv_bf16_eligible; CONV_CASES above cover that path at Cin = 10)."""
+    x = torch.zeros(1, 96, 96, 10, device='cuda'); w = torch.zeros(64, 7, 7, 10, device='cuda'); y = torch.zeros(1, 48, 48, 64, device='cuda')
+    with pytest.raises(Exception, match='geometry not supported'):
+        L.lib.call('simq_conv2d_fwd_stem_f32', L.ptr(x), L.ptr(w), L.ptr(y), 1, 96, 96, 10, None, L.stream_ptr())
+    y16 = torch.zeros(1, 48, 48, 64, dtype=torch.bfloat16, device='cuda'); scratch = torch.empty(58368, dtype=torch.uint8, device='cuda')
+    with pytest.raises(Exception, match='geometry not supported'):
+        L.lib.call('simq_conv2d_fwd_stem_bf16', L.ptr(x), L.ptr(w), L.ptr(y16), 1, 96, 96, 10, None, L.ptr(scratch), L.stream_ptr())
+    from simq import _lib
+    net10 = __import__('simq').FCN(10, 1, precision='bf16')
+    xx = torch.randn(2, 96, 96, 10, device='cuda')
+    net10.train()
+    _lib.lib.call('simq_launch_counts_reset')
+    net10._forward_raw(xx, _lib.MODE_TRAIN)
+    torch.cuda.synchronize()
+    ran = _lib.launch_counts()
+    assert ran.get('stem_conv_bf16', 0) == 0 and ran.get('stem_conv_f32', 0) == 0 and ran.get('igemm_f32_gather', 0) == 1, ran
+
+
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (2, 3), (1, 9), (5, 1), (3, 6), (2, 7)], ids=['cin4', 'cin5', 'cin3', 'cin9', 'cin1', 'cin6', 'cin7'])
 def test_stem_conv_bf16_matches_a_bf16_operand_convolution(L, B, C):
     """stem_conv_bf16.hip (reference resnet.py:94: conv 7x7 s2 p3 -> 64, the form plain-bf16 plans run): fragments gathered straight from
     the fp32 NHWC input (7*C contiguous floats per filter row, left / right / top / bottom padding by masks), bf16 operands, fp32
@@ -680,7 +707,7 @@ def test_stem_conv_bf16_matches_a_bf16_operand_convolution(L, B, C):
     assert rel(stats.cpu(), sref) < 1e-5                                     # statistics: from the fp32 accumulators
 
 
-@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (1, 9), (5, 1), (19, 5)], ids=['cin4', 'cin5', 'cin9', 'cin1', 'cin5_b19'])
+@pytest.mark.parametrize('B,C', [(3, 4), (2, 5), (1, 9), (5, 1), (19, 5), (2, 3), (3, 6), (2, 7)], ids=['cin4', 'cin5', 'cin9', 'cin1', 'cin5_b19', 'cin3', 'cin6', 'cin7'])
 def test_stem_wgrad_bf16_matches_a_bf16_operand_weight_gradient(L, B, C):
     """Weight gradient of the first convolution on the bf16 matrix cores (stem_conv_bf16.hip: dy plane and the gathered row fragments
     of x staged TRANSPOSED in LDS, contraction over pixels, per-block slabs added in a fixed order): against the fp64 weight gradient

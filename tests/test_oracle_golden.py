@@ -50,7 +50,7 @@ def test_forward_golden(case, golden_dir):
     assert all(int(st[k]) == 1 for k in st if k.endswith('num_batches_tracked'))
 
 
-@pytest.mark.parametrize('case', cases.TRAIN_CASES[:2], ids=[c[0] for c in cases.TRAIN_CASES[:2]])
+@pytest.mark.parametrize('case', cases.TRAIN_CASES[:2] + cases.TRAIN_CASES_CIN, ids=[c[0] for c in cases.TRAIN_CASES[:2] + cases.TRAIN_CASES_CIN])
 def test_train_step_golden(case, golden_dir):
     name, cin, cout, B, wseed, dseed = case
     g = np.load('%s/%s.npz' % (golden_dir, name))
