@@ -101,11 +101,14 @@ typedef struct simq_plan_options {
     int fuse_bn1_apply;           /* 1 (fp32 plans): the consuming convolution applies scale*y+shift -> ReLU while it stages its operand (Winograd input
                                    * transforms, image-tile / implicit-GEMM loaders), its weight gradient and the BatchNorm backward recompute the
                                    * activation / its mask from the saved pre-BN output.  Needs fuse_bn_backward_sums. */
-    int deterministic;            /* 0.  1: run-to-run bit-identical results (debugging aid, e.g. rank divergence in data-parallel runs): the weight
-                                   * gradients whose pixel reduction is split over blocks leave per-split partial tiles in a slab (64 MB more
-                                   * workspace) that a second launch adds in split order, instead of fp32 atomics; the one-hot head backward walks the
-                                   * transitions in order.  Forward, TD targets, loss and BatchNorm statistics are bit-reproducible in either setting
-                                   * (tests/diag/diag_determinism.py): their fp64 accumulators round to the same fp32 value whatever the order. */
+    int deterministic;            /* 0.  1: run-to-run bit-identical results UP TO the rounding of the fp64 reductions (debugging aid, e.g. rank
+                                   * divergence in data-parallel runs): every fp32 reduction of the step has a fixed order -- the weight gradients
+                                   * whose pixel reduction is split over blocks leave per-split partial tiles in a slab (64 MB more workspace) that
+                                   * a second launch adds in split order, instead of fp32 atomics; the one-hot head backward walks the transitions
+                                   * in order.  The BatchNorm sums (forward statistics, the backward's [sum dz | sum dz*xhat]) stay fp64 atomics in
+                                   * arbitrary order in either setting: a result changes only if two orders of an fp64 sum round to different fp32
+                                   * values (~1e-9 per consumer; never observed: tests/diag/diag_determinism.py, tests/test_gpu_overlap.py compare
+                                   * whole steps bit for bit), so "bit-identical" is an observation about those sums, not a guarantee. */
     int bn1_mask_from_preact;     /* 1 (plain-bf16 plans): the backward pass takes that ReLU mask from the saved pre-BN output (scale*y+shift > 0)
                                    * instead of reading the activation's plane -- one bf16 plane less in bn_bwd_apply and in the dgrad epilogue */
     /* Round 5: what used to be process-global simq_tune_* switches.  A plan's result and its launch schedule depend on the plan alone. */
@@ -168,8 +171,12 @@ int simq_weights_prepare(const simq_plan* plan, const float* d_params, void* d_w
 
 /* Inspection aid (parity bisecting): where a saved NHWC fp32 activation lives inside the workspace after simq_forward.
  * name: "stem.conv" | "stem.pool" | "layer<1-4>.<0-1>" (BasicBlock outputs) | "head.a1" | "head.a2".
- * In the matrix-core precisions the block outputs live as bf16 planes only; their fp32 copies are written when the
- * environment has SIMQ_KEEP_FP32_ACT=1 (diagnostics).                                                              */
+ * In the matrix-core precisions the block outputs live as bf16 planes only; their fp32 copies are written by plans created with
+ * simq_plan_options.keep_fp32_activations = 1 (diagnostics).
+ * Which forward wrote what: "head.a2" (the 48x48x32 activation) is written by GRAD-MODE forwards only (SIMQ_MODE_TRAIN: the backward pass
+ * reads it) -- the no-grad forward and the folded eval head (one pass: upsample -> ReLU -> conv3) never store it, the offset then holds
+ * whatever an earlier forward left.  "head.a1": eval-mode forwards of every plan and train-mode forwards of plans WITHOUT
+ * fuse_bn1_apply; fp32 plans with the fusion (the default) never store it in the train modes and the call refuses the name.          */
 int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems,
                           int* channels);
 

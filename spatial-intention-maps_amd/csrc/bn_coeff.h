@@ -47,8 +47,11 @@ __device__ __forceinline__ void bn_coeff_block(const BnRef& b, float* cs) {
 }
 // once per launch (block 0): save mean / invstd for backward and update the running statistics (momentum 0.1,
 // unbiased variance, in fp64 like ATen's CPU kernel)
+// Block (0, 0, 0) only: in a 2-D grid (the batched GEMM's blockIdx.y = transform element) every row would otherwise commit -- and the
+// committing block must run the whole kernel body: in the implicit GEMM's tail-split form block 0 is always a full tile (the K-sliced
+// tail blocks are the LAST blocks of the grid and return before this point).
 __device__ __forceinline__ void bn_commit(const BnRef& b) {
-    if (!b.stats || blockIdx.x != 0) return;
+    if (!b.stats || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0) return;
     for (int c = threadIdx.x; c < b.C; c += blockDim.x) {
         float sc, sh, m, i; double md, vd;
         bn_coeff(b, c, sc, sh, m, i, md, vd);

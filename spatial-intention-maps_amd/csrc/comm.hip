@@ -13,6 +13,8 @@
 #include <cstring>
 
 #include "../../include/simq.h"
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -83,9 +85,11 @@ struct simq_comm {
     int next = 0;
     // progress accounting for hang diagnosis (simq_comm_progress): every collective records `fin` behind itself on the comm stream
     hipEvent_t fin[kEvents] = {};
-    int64_t enqueued = 0, completed = 0;
-    int last_kind = -1;                    // 0 all-reduce fp32, 1 all-reduce fp64, 2 broadcast
-    int64_t last_count = 0;
+    // (atomics: simq_comm_progress runs on a watchdog thread while the training thread enqueues; `recorded` = how many `fin` events of the
+    // current generation exist -- progress never queries a slot whose event still belongs to the collective kEvents earlier)
+    std::atomic<int64_t> enqueued{0}, recorded{0}, completed{0};
+    std::atomic<int> last_kind{-1};        // 0 all-reduce fp32, 1 all-reduce fp64, 2 broadcast
+    std::atomic<int64_t> last_count{0};
 };
 
 namespace simq {
@@ -100,12 +104,13 @@ int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_
     c->next = (c->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, producer));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
-    const int slot = (int)(c->enqueued % kEvents);
-    c->last_kind = dtype == SIMQ_COMM_F32 ? 0 : 1; c->last_count = count;
-    ++c->enqueued;
+    const int slot = (int)(c->enqueued.load(std::memory_order_relaxed) % kEvents);
+    c->last_kind.store(dtype == SIMQ_COMM_F32 ? 0 : 1, std::memory_order_relaxed); c->last_count.store(count, std::memory_order_relaxed);
+    c->enqueued.fetch_add(1, std::memory_order_release);
     SIMQ_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == SIMQ_COMM_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->comm,
                                      c->stream));
     SIMQ_CHECK_HIP(hipEventRecord(c->fin[slot], c->stream));
+    c->recorded.fetch_add(1, std::memory_order_release);
     return 0;
 }
 
@@ -172,11 +177,12 @@ int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, v
     comm->next = (comm->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, static_cast<hipStream_t>(producer_stream)));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(comm->stream, ev, 0));
-    const int slot = (int)(comm->enqueued % kEvents);
-    comm->last_kind = 2; comm->last_count = bytes;
-    ++comm->enqueued;
+    const int slot = (int)(comm->enqueued.load(std::memory_order_relaxed) % kEvents);
+    comm->last_kind.store(2, std::memory_order_relaxed); comm->last_count.store(bytes, std::memory_order_relaxed);
+    comm->enqueued.fetch_add(1, std::memory_order_release);
     SIMQ_CHECK_RCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclInt8, root, comm->comm, comm->stream));
     SIMQ_CHECK_HIP(hipEventRecord(comm->fin[slot], comm->stream));
+    comm->recorded.fetch_add(1, std::memory_order_release);
     return 0;
 }
 
@@ -185,10 +191,13 @@ int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, v
 // is blocked in a synchronisation.  out = {enqueued, completed, last kind (0 all-reduce fp32, 1 all-reduce fp64, 2 broadcast), last count}
 int simq_comm_progress(simq_comm* comm, int64_t out[4]) {
     SIMQ_REQUIRE(comm && out, "comm_progress: NULL argument");
-    if (comm->enqueued - comm->completed > kEvents) comm->completed = comm->enqueued - kEvents;   // (older events were re-recorded)
-    while (comm->completed < comm->enqueued && hipEventQuery(comm->fin[comm->completed % kEvents]) == hipSuccess) ++comm->completed;
+    const int64_t enq = comm->enqueued.load(std::memory_order_acquire), rec = comm->recorded.load(std::memory_order_acquire);
+    int64_t done = comm->completed.load(std::memory_order_relaxed);
+    if (rec - done > kEvents) done = rec - kEvents;                                                // (older events were re-recorded)
+    while (done < rec && hipEventQuery(comm->fin[done % kEvents]) == hipSuccess) ++done;
     (void)hipGetLastError();                                                                       // (hipErrorNotReady is not an error here)
-    out[0] = comm->enqueued; out[1] = comm->completed; out[2] = comm->last_kind; out[3] = comm->last_count;
+    comm->completed.store(done, std::memory_order_relaxed);
+    out[0] = enq; out[1] = done; out[2] = comm->last_kind.load(std::memory_order_relaxed); out[3] = comm->last_count.load(std::memory_order_relaxed);
     return 0;
 }
 

@@ -325,6 +325,9 @@ class FCN(torch.nn.Module):
         """NHWC view [B,H,W,C] of an activation the last forward left in its workspace
         ('stem.pool', 'layer<1-4>.<0-1>', 'head.a1', 'head.a2') -- parity bisecting aid."""
         import ctypes
+        if name == 'head.a2' and slot != 'train':
+            raise SimqError("saved_activation: 'head.a2' is written by grad-mode forwards only (slot 'train'); the no-grad and the folded "
+                            "eval forward never store it (include/simq.h simq_workspace_tensor)")
         off, n, ch = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
         lib.call('simq_workspace_tensor', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch))
         ws = self._ws[slot]

@@ -25,7 +25,9 @@ with torch.no_grad():
 def err(a, b): return float((a.double() - b).abs().max() / b.abs().max())
 def l2(a, b): return float((a.double() - b).norm() / b.norm())
 print('precision', PREC, 'train' if TRAIN else 'eval')
-for name in ['stem.pool'] + ['layer%d.%d' % (l, b) for l in range(1, 5) for b in range(2)] + ['head.a1', 'head.a2']:
+# (head.a1 / head.a2: a no-grad forward does not store them -- the eval head is folded into one pass, fp32 plans apply the head's
+#  BatchNorm 1 inside conv2's operand staging: include/simq.h simq_workspace_tensor)
+for name in ['stem.pool'] + ['layer%d.%d' % (l, b) for l in range(1, 5) for b in range(2)]:
     h = net.saved_activation(name, B).cpu().permute(0, 3, 1, 2)
     r64, r32 = taps[torch.float64][name], taps[torch.float32][name]
     print('%-10s max-norm err: hip %.2e  o32 %.2e | rel-L2: hip %.2e  o32 %.2e' % (name, err(h, r64), err(r32, r64), l2(h, r64), l2(r32, r64)))

@@ -288,8 +288,10 @@ def test_bf16_backward_teacher_forced_block_by_block(simq_mod, B):
       stored bf16 gradient planes == bf16(fp64 recomputation) on all but < 1 % of the elements, each within one bf16 ulp;
       convolution weight gradients 2e-5 (max-abs over max-abs) against fp64 on the stored operands;
       the BatchNorm backward sums [sum dz | sum dz*xhat] the fused dgrad epilogues leave (formed from the fp32 values BEFORE they are rounded
-      to the stored bf16): within the rounding noise of that storage, 3 * 2^-9 * ||dz||_2 per channel (a wrong mask source / y plane / mean
-      moves them by ~sqrt(rows) times that), and d gamma / d beta == (float)those sums.
+      to the stored bf16): within the rounding noise of that storage -- a bf16 rounding error is uniform within half an ulp, 0.6-1.2 x
+      2^-9 |v| in standard deviation, so the sum over a channel's rows has sigma ~ 0.8 x 2^-9 ||dz||_2; measured 2.8-3.0 of that unit as the
+      maximum over the 6 000 channel sums of the walk (3.7 sigma), bar 6 -- a wrong mask source / y plane / mean moves them by ~sqrt(rows) x
+      512 of that unit --, and d gamma / d beta == (float)those sums.
     g_in of block k must equal g_out of block k - 1 bit for bit (same buffer).  B = 128 is the bench's batch: the image-tile dgrad / weight-
     gradient kernels, the LDS-resident 64-channel dgrad and bn_bwd_apply16<mask from y> are selected only there (asserted, launch log)."""
     import torch.nn.functional as F
@@ -340,7 +342,7 @@ def test_bf16_backward_teacher_forced_block_by_block(simq_mod, B):
             e0, e1 = float(((red[0] - s0).abs() / n0).max()), float(((red[1] - s1).abs() / n1).max())
             l1 = float(((red[0] - s0).abs() / dz64.abs().sum(dim=(0, 1, 2)).clamp_min(1e-30)).max())
             log.append('  %-22s sums vs the stored tensors: %.2f / %.2f of the bf16-storage noise 2^-9 ||dz||_2 (%.1e of sum |dz|)' % (name, e0, e1, l1))
-            assert e0 < 3.0 and e1 < 3.0, (name, e0, e1)
+            assert e0 < 6.0 and e1 < 6.0, (name, e0, e1)
             assert float((gview[bkey] - red[0].float().double()).abs().max()) <= 1e-6 * float(red[0].abs().max()), bkey      # d beta = sum dz
             assert float((gview[gkey] - red[1].float().double()).abs().max()) <= 1e-6 * float(red[1].abs().max()), gkey      # d gamma = sum dz*xhat
             return xhat

@@ -7,4 +7,5 @@ timeout=${1:-1500}; shift
 here=$(cd "$(dirname "$0")" && pwd)
 [ -f "$here/recipes/$recipe.sh" ] || { echo "no such recipe: $recipe (have: $(ls $here/recipes | sed 's/\.sh$//' | tr '\n' ' '))"; exit 2; }
 if [ -n "$GRAFT_REPO_ROOT" ]; then exec bash "$here/recipes/$recipe.sh" "$@"; fi
-exec /usr/local/graft/bin/gpurun --timeout "$timeout" -- "bash tools/recipes/$recipe.sh $*"
+args=$(printf '%q ' "$@")
+exec /usr/local/graft/bin/gpurun --timeout "$timeout" -- "bash tools/recipes/$recipe.sh $args"
