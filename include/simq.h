@@ -440,6 +440,12 @@ int simq_conv2d_wgrad_stem_bf16(const float* d_x, const uint16_t* d_dy, float* d
  * d_scratch: 16*T*(cin+cout) + 36*cout*cin floats. */
 int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw_ohwi,
                                int batch, int hin, int win, int cin, int cout, float* d_scratch, void* stream, const simq_launch_opts* opts);
+/* `batch` independent row-major GEMMs y_g[m][n] = x_g[m][k] * w_g[n][k]^T in exact fp32 (v_mfma_f32_16x16x4_f32), g-th operands at
+ * base + g * rows * cols: the transform-domain contraction of a Winograd layer (16 or 36 transform elements; what cuDNN's Winograd
+ * kernels do inside nn.Conv2d, reference resnet.py:14-16 under train.py:23) -- the dominant kernel of the fp32 step, on its own for the
+ * per-kernel tests and probes.  k % 16 == 0, n % 64 == 0. */
+int simq_gemm_f32_batched(const float* d_x, const float* d_w, float* d_y, int m, int n, int k, int batch, void* stream,
+                          const simq_launch_opts* opts);
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w_ohwi, float* d_wt_scratch, float* d_dx,
                       int batch, int hin, int win, int cin, int cout, int r, int s, int pad, void* stream, const simq_launch_opts* opts);
 int simq_conv2d_wgrad(const float* d_x, const float* d_dy, float* d_dw_ohwi /* zeroed by callee */,

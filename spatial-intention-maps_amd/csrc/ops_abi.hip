@@ -233,6 +233,13 @@ int simq_conv2d_wgrad_winograd(const float* d_x, const float* d_dy, float* d_dw,
     return launch_conv_wgrad_winograd(d_x, d_dy, d_dw, g, d_scratch, static_cast<hipStream_t>(stream));
 }
 
+int simq_gemm_f32_batched(const float* d_x, const float* d_w, float* d_y, int m, int n, int k, int batch, void* stream, const simq_launch_opts* opts) {
+    SIMQ_REQUIRE(d_x && d_w && d_y, "gemm_f32_batched: NULL argument");
+    LaunchTune t;
+    RC(tune_of(opts, &t));
+    return launch_gemm_batched(d_x, d_w, d_y, m, n, k, batch, static_cast<hipStream_t>(stream), t);
+}
+
 int simq_conv2d_dgrad(const float* d_dy, const float* d_w, float* d_wt_scratch, float* d_dx, int batch, int hin, int win,
                       int cin, int cout, int r, int s, int pad, void* stream, const simq_launch_opts* opts) {
     hipStream_t st = static_cast<hipStream_t>(stream);

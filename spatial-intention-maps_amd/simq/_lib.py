@@ -118,6 +118,7 @@ _SIGS = {
     'simq_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'simq_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'simq_conv2d_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p] + [c_void_p]),
+    'simq_gemm_f32_batched': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'simq_conv2d_dgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] + [c_void_p]),
     'simq_conv2d_wgrad': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p] + [c_void_p]),
     'simq_conv2d_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_void_p] + [c_void_p]),
@@ -159,7 +160,7 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 # operators whose last argument is `const simq_launch_opts*`
-OPTS_FUNCS = frozenset(('simq_conv2d_fwd', 'simq_conv2d_dgrad', 'simq_conv2d_wgrad', 'simq_conv2d_fwd_bf16', 'simq_conv2d_wgrad_bf16',
+OPTS_FUNCS = frozenset(('simq_gemm_f32_batched', 'simq_conv2d_fwd', 'simq_conv2d_dgrad', 'simq_conv2d_wgrad', 'simq_conv2d_fwd_bf16', 'simq_conv2d_wgrad_bf16',
                         'simq_conv2d_wgrad_bf16_slab', 'simq_conv2d_wgrad_winograd', 'simq_conv2d_fwd_winograd', 'simq_conv2d_fwd_winograd4',
                         'simq_conv2d_fwd_bnrelu_in', 'simq_conv2d_wgrad_bnrelu_in'))
 
