@@ -405,7 +405,9 @@ def main():
             idx = g['ring'].sample_indices(gB)
             return g['ring'].gather(sdist.shard_indices(idx, world, rank), allow_all_final=world > 1)
 
-        def step():
+        exposed_log = []      # (multi-rank runs, measurement pass only: ms the main stream stood in the step's last simq_comm_wait)
+
+        def step(log_exposed=False):
             # train.py:252-258: per robot group one minibatch draw (host-side picks + index upload + HBM gather) and one train().
             # train_step returns the loss as train.py:137-139 does (loss.item()), but waits only for the copy of the four sums the
             # library issues right behind the TD / Huber launch -- not for backward + SGD -- so the draw and the launches of the next
@@ -417,6 +419,8 @@ def main():
                 batch = g['drawn'] if g['drawn'] is not None else draw(g)
                 info = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
                                   opt_state=g['opt'], process_group=pg, global_batch=gB, sync=True, comm=comm)
+                if log_exposed:
+                    exposed_log.append(comm.last_wait_ms())
                 g['drawn'] = draw(g)
                 if not np.isfinite(info['loss']):
                     sys.exit('bench: non-finite loss %r' % (info,))
@@ -461,6 +465,25 @@ def main():
                          'window_steps': per, 'windows': len(rates), 'window_min': round(min(rates), 1), 'window_max': round(max(rates), 1),
                          'vs_timed_window': round(gB * len(groups) * n_done / total / value, 4), 'last_loss': info_s['loss']}
 
+        # Exposed communication (extra key, outside every timed window): per rank, how long the main stream stood waiting in the step's last
+        # simq_comm_wait -- the un-overlapped part of gradient bucket 2 + the loss scalars (bucket 1 travels beside backward phase 2; DESIGN 6
+        # prices the exposed part at ~0.12 ms).  Timing events around the wait inside libsimq (simq_comm_time_waits); each query synchronises,
+        # hence its own pass.
+        exposed = None
+        if comm is not None:
+            comm.time_waits(True)
+            for i in range(8):
+                dog.arm('%s exposed-communication pass, step %d' % (precision, i + 1))
+                step(log_exposed=True)
+            barrier('barrier behind the exposed-communication pass')
+            comm.time_waits(False)
+            mine = torch.tensor([float(np.mean(exposed_log)), float(np.max(exposed_log))], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine, group=pg)
+            exposed = {'what': 'ms per train() call the main stream waited in simq_comm_wait (bucket 2 + loss scalars not hidden behind backward phase 2)',
+                       'calls_timed': len(exposed_log), 'per_rank_mean_ms': [round(float(t[0]), 4) for t in allr],
+                       'per_rank_max_ms': [round(float(t[1]), 4) for t in allr]}
+
         # M1 of SURVEY 8d, the literal reading of the metric ("fwd+bwd"): policy forward (train-mode BN) + gather + Huber +
         # backward only -- no next-state forwards, all-reduce, clip or SGD.  Reported beside the full-step `value`, never instead of it.
         m1 = []
@@ -492,7 +515,7 @@ def main():
                 dt_m1 = sdist.max_over_ranks(dt_m1, dev, pg)
         dog.disarm()
         return {'value': value, 'dt': dt, 'dt_m1': dt_m1, 'info': info, 'step': step, 'B': B, 'gB': gB, 'n_nets': len(groups), 'sustained': sustained,
-                'm1': None if args.no_m1 else gB * len(groups) * steps / dt_m1, 'groups': groups}
+                'm1': None if args.no_m1 else gB * len(groups) * steps / dt_m1, 'groups': groups, 'exposed_comm': exposed}
 
     def roofline_pass(step_fn, groups_of_step, steps, precision, ms_per_step, per_gpu_rate):
         """Live per-launch timing of the GEMM-class kernels (hipEventRecord pairs on the launch stream, simq_profile_*) over
@@ -583,7 +606,7 @@ def main():
         ranks_roof = per_rank(roof)
         if ranks_roof is not None:
             roof['per_rank'] = ranks_roof
-    m1, dt_m1, n_nets, sustained = w['m1'], w['dt_m1'], w['n_nets'], w['sustained']
+    m1, dt_m1, n_nets, sustained, exposed_comm = w['m1'], w['dt_m1'], w['n_nets'], w['sustained'], w['exposed_comm']
     release(w)
 
     cpu = None
@@ -608,7 +631,7 @@ def main():
                       'steps': args.steps, 'warmup': args.warmup, 'scaling': xl['scaling'],
                       'fwd_bwd_only_transitions_per_s': None if e['m1'] is None else round(e['m1'], 1),
                       'fwd_bwd_only_ms_per_step': None if e['m1'] is None else round(e['dt_m1'] / args.steps * 1e3, 3), 'last_loss': e['info']['loss'],
-                      'sustained': e['sustained']}
+                      'sustained': e['sustained'], 'exposed_comm': e['exposed_comm']}
             if not args.no_roofline:
                 roof_x = roofline_pass(e['step'], e['groups'], args.steps, xl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
             release(e)
@@ -636,7 +659,7 @@ def main():
                        'gradient_transport': transport, 'simq_comm_world_size': comm_world, 'backend': args.backend if world > 1 else None,
                        'flop_per_transition': flop_m2, 'flop_per_transition_fwd_bwd_only': flop_m1,
                        'last_loss': info['loss'], 'last_td_error': info['td_error']},
-            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained,
+            'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'exposed_comm': exposed_comm,
         }
         # BASELINE.md publishes no number for this metric (BASELINE.json "published": {}), so `vs_baseline` stays null by the bench
         # contract; what exists is north_star's TARGET -- ">= 10k Q-map forward+backward transitions/sec ... at 1 GPU" -- and `vs_target`

@@ -345,6 +345,12 @@ int simq_comm_wait(simq_comm* comm, void* consumer_stream);
  * collectives the device has completed (event queries, no synchronisation), kind of the last one (0 all-reduce fp32, 1 all-reduce fp64,
  * 2 broadcast), its element / byte count}.  Safe to call from a watchdog thread while another thread waits on the device. */
 int simq_comm_progress(simq_comm* comm, int64_t out[4]);
+/* Exposed communication time (no reference counterpart: measurement aid of the data-parallel step).  With timing on, every simq_comm_wait
+ * brackets the consumer stream's wait with a pair of timing events; simq_comm_last_wait_ms blocks until the LAST wait has been passed and
+ * returns how long the consumer stream stood waiting for collectives still in flight -- inside simq_train_step that is the un-overlapped
+ * part of the second gradient bucket + the loss scalars (bucket 1 travels beside backward phase 2).  ~0 when everything was hidden. */
+int simq_comm_time_waits(simq_comm* comm, int on);
+int simq_comm_last_wait_ms(simq_comm* comm, float* ms);
 int simq_comm_destroy(simq_comm* comm);
 
 /* ---- intention-prediction head (train_intention, train.py:143-158; step_intention, policies.py:97-117) ----------

@@ -82,6 +82,10 @@ struct simq_comm {
     hipStream_t stream = nullptr;          // library-owned: every collective runs here
     hipEvent_t ready[kEvents] = {};        // producer stream -> comm stream (ring: one per collective in flight)
     hipEvent_t done = nullptr;             // comm stream -> consumer stream
+    // exposed-wait timing (simq_comm_time_waits): a timing-enabled pair around the consumer stream's wait -- what the consumer stream
+    // LOST waiting for collectives still in flight (0 when they finished behind the kernels that ran beside them)
+    hipEvent_t wait_t0 = nullptr, wait_t1 = nullptr;
+    int time_waits = 0, wait_timed = 0;
     int next = 0;
     // progress accounting for hang diagnosis (simq_comm_progress): every collective records `fin` behind itself on the comm stream
     hipEvent_t fin[kEvents] = {};
@@ -124,7 +128,9 @@ int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream) {
 int comm_wait(simq_comm* c, hipStream_t consumer) {
     SIMQ_REQUIRE(c, "comm_wait: NULL communicator");
     SIMQ_CHECK_HIP(hipEventRecord(c->done, c->stream));
+    if (c->time_waits) SIMQ_CHECK_HIP(hipEventRecord(c->wait_t0, consumer));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(consumer, c->done, 0));
+    if (c->time_waits) { SIMQ_CHECK_HIP(hipEventRecord(c->wait_t1, consumer)); c->wait_timed = 1; }
     return 0;
 }
 
@@ -207,6 +213,25 @@ int simq_comm_wait(simq_comm* comm, void* consumer_stream) {
     return simq::comm_wait(comm, static_cast<hipStream_t>(consumer_stream));
 }
 
+int simq_comm_time_waits(simq_comm* comm, int on) {
+    SIMQ_REQUIRE(comm, "comm_time_waits: NULL communicator");
+    if (on && !comm->wait_t0) {
+        SIMQ_CHECK_HIP(hipEventCreate(&comm->wait_t0));
+        SIMQ_CHECK_HIP(hipEventCreate(&comm->wait_t1));
+    }
+    comm->time_waits = on ? 1 : 0;
+    comm->wait_timed = 0;
+    return 0;
+}
+
+int simq_comm_last_wait_ms(simq_comm* comm, float* ms) {
+    SIMQ_REQUIRE(comm && ms, "comm_last_wait_ms: NULL argument");
+    SIMQ_REQUIRE(comm->wait_timed, "comm_last_wait_ms: no timed simq_comm_wait yet (simq_comm_time_waits(comm, 1) first)");
+    SIMQ_CHECK_HIP(hipEventSynchronize(comm->wait_t1));
+    SIMQ_CHECK_HIP(hipEventElapsedTime(ms, comm->wait_t0, comm->wait_t1));
+    return 0;
+}
+
 int simq_comm_destroy(simq_comm* comm) {
     if (!comm) return 0;
     if (comm->stream) (void)hipStreamSynchronize(comm->stream);
@@ -216,6 +241,8 @@ int simq_comm_destroy(simq_comm* comm) {
     for (int i = 0; i < kEvents; ++i)
         if (comm->fin[i]) (void)hipEventDestroy(comm->fin[i]);
     if (comm->done) (void)hipEventDestroy(comm->done);
+    if (comm->wait_t0) (void)hipEventDestroy(comm->wait_t0);
+    if (comm->wait_t1) (void)hipEventDestroy(comm->wait_t1);
     if (comm->stream) (void)hipStreamDestroy(comm->stream);
     delete comm;
     return 0;

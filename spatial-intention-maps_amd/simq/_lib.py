@@ -155,6 +155,8 @@ _SIGS = {
     'simq_comm_broadcast': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'simq_comm_wait': (c_int, [c_void_p, c_void_p]),
     'simq_comm_progress': (c_int, [c_void_p, c_void_p]),
+    'simq_comm_time_waits': (c_int, [c_void_p, c_int]),
+    'simq_comm_last_wait_ms': (c_int, [c_void_p, POINTER(c_float)]),
     'simq_comm_destroy': (c_int, [c_void_p]),
 }
 

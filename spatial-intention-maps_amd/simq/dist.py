@@ -197,6 +197,16 @@ class Comm:
     def wait(self):
         self._lib.call('simq_comm_wait', self.handle, self._stream())
 
+    def time_waits(self, on=True):
+        """Bracket every simq_comm_wait with timing events (simq_comm_time_waits): exposed communication time of the data-parallel step."""
+        self._lib.call('simq_comm_time_waits', self.handle, 1 if on else 0)
+
+    def last_wait_ms(self):
+        """Milliseconds the consumer stream stood in the last simq_comm_wait (blocks until that wait has been passed)."""
+        ms = ctypes.c_float()
+        self._lib.call('simq_comm_last_wait_ms', self.handle, ctypes.byref(ms))
+        return float(ms.value)
+
     def progress(self):
         """{'enqueued', 'completed', 'last'}: collectives this rank has enqueued on the communicator, those the device has finished, and
         what the last one was (simq_comm_progress) -- for a watchdog thread to say WHICH collective a hung rank sits in."""

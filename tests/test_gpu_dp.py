@@ -91,10 +91,16 @@ def _worker(rank, world, port, backend, use_comm, spec, out_dir, sync_bn=False):
         shard = assemble_batch(Transition(*zip(*trs[lo:hi])), dev, allow_all_final=True)
         gnf = sum(1 for t in trs if t[3] is not None)          # every rank sees the whole drawn minibatch: global non-final count
         out = {}
+        if comm is not None:
+            comm.time_waits(True)       # (bench.py's exposed-communication pass: timing events around the step's last simq_comm_wait)
         for s in range(steps):
             info = train_step(policy, target, shard, cases.GAMMA, hi - lo, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
                               use_double_dqn=True, process_group=pg, global_batch=gB, comm=comm, sync_bn=sync_bn,
                               global_nonfinal=gnf if sync_bn else None)
+            if comm is not None:
+                ms = comm.last_wait_ms()
+                assert 0.0 <= ms < 1e3, ms
+                out['exposed_ms'] = ms
             if s == 0:
                 g, tn = _unclipped(policy)
                 out.update(grad=g.numpy(), total_norm=tn, loss=info['loss'], td_error=info['td_error'],
