@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: how much of a step is the device idle?  Kernel trace of one bench.py configuration (streams as in production); per step the
 # wall span from the first kernel's start to the last kernel's end against the UNION of the kernels' busy intervals.
-# usage: tools/idle_gaps.sh <name> <bench args...>  -> gpurun_out/<name>_idle.txt
+# usage: tools/lease.sh idle 600 <name> <bench args...>  -> gpurun_out/<name>_idle.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 name=$1; shift
 O=$R/gpurun_out/ig_$name

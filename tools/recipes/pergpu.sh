@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: single-GPU rates of every config's PER-GPU shape (what the first multi-GPU run should show), stream overlaps on
+# single-GPU rates of every config's PER-GPU shape (what the first multi-GPU run should show), stream overlaps on
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 echo -n "configs1 / 2 GPUs: 16 per GPU fp32        "; bash tools/bv.sh --batch 16
 echo -n "weak32: 32 per GPU fp32                   "; bash tools/bv.sh

@@ -1,12 +1,12 @@
 #!/bin/bash
-# GPU box: the measurements behind profiles/r04_* (run from the repo root through gpurun, then copy gpurun_out/final/* to profiles/):
-#   1. python bench.py                      -> bench.json        (the judged line: fp32 configs[1] headline + bf16 configs[2] leg,
-#                                                                  both with a roofline object, cpu_baseline)
+# The measurements behind profiles/rNN_* (copy gpurun_out/final/* to profiles/ with the round's prefix afterwards):
+#   1. python bench.py                      -> bench.json   (the judged line: fp32 configs[1] headline + bf16 configs[2] leg, roofline, cpu_baseline)
 #   per workload W in {b32 = fp32 configs[1], bf16_b128 = bf16 configs[2]}:
-#   2. rocprofv3 --kernel-trace             -> bench_W_kernel_trace.txt   (same bench.py, 7 full steps, nothing else)
-#   3. rocprofv3 --pmc SQ_* (own pass)      -> bench_W_pmc_sq.txt         (matrix-pipe busy cycles)
-#   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> bench_W_pmc_traffic.txt + pmc_traffic[_bf16_b128].json
-#   5. the kernel trace again with the stream overlaps of the step off -> bench_W_kernel_trace_serial.txt
+#   2. rocprofv3 --kernel-trace             -> bench_W_kernel_trace.txt          (same bench.py, 7 full steps, nothing else)
+#   3. rocprofv3 --pmc SQ_* (own pass)      -> bench_W_pmc_sq.txt                (matrix-pipe busy cycles)
+#   4. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two own passes) -> bench_W_pmc_traffic.txt + pmc_traffic_W.json
+#   5. the kernel trace again on plans with every stream overlap off -> bench_W_kernel_trace_serial.txt (each kernel alone on the device:
+#      the view that matches bench.py's event timing of the roofline kernels)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
@@ -25,18 +25,18 @@ prof() {   # name, extra bench args...
   python tools/rocprof_summary.py $(find $O -name "kt_${name}_results.db") 7 > $O/bench_${name}_kernel_trace.txt
   python tools/rocprof_summary.py $(find $O -name "ps_${name}_results.db") 7 > $O/bench_${name}_pmc_sq.txt
   python tools/pmc_traffic.py $(find $O -name "pf_${name}_results.db") $(find $O -name "pw_${name}_results.db") $O/pmc_traffic_${name}.json > $O/bench_${name}_pmc_traffic.txt
+  python tools/rocprof_phases.py $(find $O -name "kt_${name}_results.db") > $O/phases_${name}.txt
+  python tools/rocprof_timeline.py $(find $O -name "kt_${name}_results.db") 0.5 > $O/timeline_${name}.txt
+  python tools/rocprof_by_shape.py $(find $O -name "kt_${name}_results.db") 3.5 0.5 > $O/launch_shapes_${name}.txt
 }
-prof b32
-serial() {   # name, extra bench args...: the same step with every kernel alone on the device (target-net forward, the policy's no-grad forward and
-             # the weight gradients on the main stream): the per-kernel durations the concurrent trace inflates (two kernels sharing the CUs each
-             # look longer) -- the view that matches bench.py's event timing of the roofline kernels
+serial() {   # name, extra bench args...
   local name=$1; shift
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $O -o ks_$name -- python $R/bench.py --no-cpu-baseline --no-extras --no-m1 --no-roofline --sustained-seconds 0 --steps 5 --warmup 2 --no-overlap --wgrad-overlap 0 --fwd-overlap 0 $* > $O/ks_$name.out 2> $O/ks_$name.err )
   python tools/rocprof_summary.py $(find $O -name "ks_${name}_results.db") 7 > $O/bench_${name}_kernel_trace_serial.txt
+  python tools/rocprof_by_shape.py $(find $O -name "ks_${name}_results.db") 3.5 0.5 > $O/launch_shapes_serial_${name}.txt
 }
-serial b32
-prof bf16_b128 --workload configs2
-serial bf16_b128 --workload configs2
+prof b32; serial b32
+prof bf16_b128 --workload configs2; serial bf16_b128 --workload configs2
 find $O -name "*.db" -delete
 find $O -type d -empty -delete
 tail -c 1500 $O/bench.json
