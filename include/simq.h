@@ -76,7 +76,7 @@ int simq_plan_create_ex(int num_input_channels, int num_output_channels, int pre
  * simq_plan_create_opts (NULL = defaults); struct_bytes must be sizeof(simq_plan_options). */
 typedef struct simq_plan_options {
     int struct_bytes;
-    /* fp32 plans: Winograd forms of the wide 3x3 layers */
+    /* fp32 plans: Winograd forms of the wide 3x3 layers (docs/history.md 4) */
     int winograd;                 /* 1: layers with Cin*Cout >= winograd_min_cc run as F(2x2,3x3) / F(4x4,3x3); 0: direct implicit GEMM */
     int winograd_min_cc;          /* 128*128: layers 2-4 */
     int winograd_f4_forward;      /* 1: the forwards nothing is differentiated through (target net, greedy next action, step()) in F(4x4,3x3) */
@@ -85,7 +85,7 @@ typedef struct simq_plan_options {
     int winograd_f4_fwd_grad_min_cc; /* 512*512 (0 = never).  With winograd_f4_grad = 2: the GRAD-MODE forward of the layers with Cin*Cout >= this
                                    * value runs in F(4x4,3x3) as well -- layer4's three 512->512 convolutions, 66 % of the grad-mode forward's
                                    * matrix flops.  Their round-off passes through no further residual block: the gradient study (19 batches
-                                   * against fp64) is unchanged by it, while 256*512 and below raise the gradient's error */
+                                   * against fp64) is unchanged by it, while 256*512 and below raise the gradient's error (docs/history.md 4) */
     int winograd_wgrad;           /* 1: weight gradients of the Winograd layers through the transform domain */
     int winograd_wgrad_f4;        /* 1: ... in F(4x4,3x3) where the tile count allows */
     /* bf16 plans: storage */

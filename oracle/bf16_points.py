@@ -147,7 +147,7 @@ def fcn_forward(state, x, training, points=True, update_buffers=True, taps=None)
         a1 = tap('head.a1', F.relu(bn_t(yh1, p + 'bn1')))           # fp32 activation; conv2 multiplies its bf16 plane
         z2 = conv(P.fwd(a1), P.w(state[p + 'conv2.weight']), state[p + 'conv2.bias'])
         z2 = P.bwd(z2)                              # (the gradient w.r.t. conv2's output is the bf16 operand of its weight gradient / dgrad)
-        # conv2 is 1x1: conv2(upsample(a)) == upsample(conv2(a)) (networks.py:21-22 commuted); BatchNorm 2 sees the 48x48 map
+        # conv2 is 1x1: conv2(upsample(a)) == upsample(conv2(a)) (networks.py:21-22 commuted, docs/history.md 4); BatchNorm 2 sees the 48x48 map
         yh2 = F.interpolate(z2, scale_factor=2, mode='bilinear', align_corners=True)
         a2 = F.relu(_bn_train(yh2, yh2, state[p + 'bn2.weight'], state[p + 'bn2.bias'], state, p + 'bn2', update_buffers))
         q = F.interpolate(a2, scale_factor=2, mode='bilinear', align_corners=True)

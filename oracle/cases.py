@@ -57,7 +57,7 @@ GRAD_STUDY_CASES = [('gs_b8_%02d' % i, (4, 5)[i % 2], (2, 1)[(i // 2) % 2], 8, 2
 # the same study at configs[3]'s per-GPU batch (64): is the HIP fp32 gradient as accurate as the reference's at the larger sizes too?
 GRAD_STUDY_B64_CASES = [('gs_b64_%02d' % i, 5, (2, 1)[i % 2], 64, 270 + i, 370 + i) for i in range(6)]
 # ... and at configs[1]'s own batch (32, Cin 4, Cout 2: the headline workload): twelve more batches, for the decision which layers' grad-mode
-# forward may run in F(4x4,3x3)
+# forward may run in F(4x4,3x3) (docs/history.md 4)
 GRAD_STUDY_B32_CASES = [('gs_b32x_%02d' % i, 4, 2, 32, 400 + i, 500 + i) for i in range(12)]
 # ... and at configs[2] / configs[4]'s per-GPU batch (128, Cin 5, Cout 2): twelve batches -- the single fixture train_c5o2_b128 sat at 2.6 x the
 # reference's own error (one unlucky batch or a regression?); the distribution answers it (round 4)

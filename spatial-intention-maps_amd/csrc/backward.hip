@@ -17,7 +17,7 @@ int bn_bwd(const Ctx& c, const BnL& bn, const float* g, const float* mask, const
     if (y_bf16 < 0) y_bf16 = c.ybf();
     SIMQ_REQUIRE(!mask_from_y || (reduced && !mask && !mask16), "bn_bwd: the recomputed mask needs the fused reduction and no mask tensor");
     if (!reduced) {
-        if (bn.C <= 128) {                                   // (blocks finish together: replicated slots)
+        if (bn.C <= 128) {                                   // (blocks finish together: replicated slots, docs/history.md 7)
             double* rep = reinterpret_cast<double*>(c.ws + c.L.colsum);
             SIMQ_CHECK_HIP(hipMemsetAsync(rep, 0, sizeof(double) * kStatReplicas * 2 * bn.C, c.stream));
             RC(launch_bn_bwd_reduce(g, mask, y, c.aux(bn, 2), c.aux(bn, 3), rep, rows, bn.C, c.stream, y_bf16, g_bf16, kStatReplicas));

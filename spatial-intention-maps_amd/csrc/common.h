@@ -48,7 +48,7 @@ int tune_env_int(const char* name, int dflt);
 // the caller's simq_launch_opts (include/simq.h), and the defaults below are what both start from.
 struct LaunchTune {
     int force_bm = 0, force_bn = 0;   // force one tile of a launcher's menu (0: the launcher's own rule); per-kernel tests and tools/
-    int tail_split = 0;               // conv_igemm.hip: balanced last round (measured step-negative)
+    int tail_split = 0;               // conv_igemm.hip: balanced last round (measured step-negative, docs/history.md 7)
     int plane_xcd = 1;                // conv_igemm.hip, batched GEMMs: whole transform elements per XCD
     int wgrad_xcd_group = 1;          // conv_wgrad*.hip: the tiles of a pixel range on one XCD -- 0 off, 1 the bf16 kernel only, 2 fp32 too
     int wgrad_ksplit = 0;             // conv_winograd.hip: K-split of the transform-domain weight-gradient GEMMs -- 0 by shape, 1 / 2 / 4 forced

@@ -3,7 +3,7 @@
 //
 // Reference operators: the 3x3 / stride 1 / pad 1 nn.Conv2d forwards of the BasicBlocks (resnet.py:31-47, 23-26) on the 24 x 24
 // maps of this network and their dgrads (train.py:132), i.e. the layers conv_igemm_bf16_pp.hip serves.  What that kernel showed
-// (tools/pp_check.py ablations): with the wave groups running one barrier apart the MFMA / fragment-read /
+// (tools/pp_check.py ablations, docs/history.md section 4): with the wave groups running one barrier apart the MFMA / fragment-read /
 // DMA-issue streams overlap, and what is left is the VOLUME staged through L2 -> LDS: an implicit GEMM re-stages every input
 // pixel once per filter tap (9 x), 2.6 GB per layer4 launch at B = 128.  Here, per 32-channel chunk,
 //   * the 26 x 26 halo patch of the image (zero border written by the DMA's range check) is staged ONCE -- 43 KB of pixels in a 52-KB
@@ -294,7 +294,7 @@ int try_conv_igemm_bf16_img(const IgemmBfArgs& a, hipStream_t stream) {
     if (a.Cin % BK != 0 || a.Cout % BN != 0 || a.M % (HW * HW) != 0 || a.x_bytes >= 0x7FFF0000u) return 0;
     static const int mode = SIMQ_TUNE_INT("SIMQ_BF16_IMG", 1);   // 0 = off
     if (mode == 0) return 0;
-#ifdef SIMQ_ABLATIONS      // SIMQ_BF16_IMG=2: the four-wave form (conv_igemm_bf16_img4.hip; measured slower) exists in libsimq_ablate.so only
+#ifdef SIMQ_ABLATIONS      // SIMQ_BF16_IMG=2: the four-wave form (conv_igemm_bf16_img4.hip; measured slower, docs/history.md 4) exists in libsimq_ablate.so only
     if (mode == 2) { if (int rc = try_conv_igemm_bf16_img4(a, stream)) return rc; }
 #endif
     int fbm = 0, fbn = 0;

@@ -779,7 +779,7 @@ bool winograd_f4_forward(const ConvGeom& g, int min_tiles) {      // (simq_plan_
 //   0            the differentiated path stays F(2x2,3x3) entirely.
 // simq_plan_options.winograd_f4_fwd_grad_min_cc (default 512*512) adds the GRAD-MODE forward of the layers with Cin*Cout at or above it:
 // layer4's three 512->512 convolutions -- their round-off passes through no further residual block and leaves the gradient study
-// (19 batches) unchanged, +4.4 % on the step; from 256->512 down the study's tail grows (tests/diag_f4_grad_layers.py).
+// (19 batches) unchanged, +4.4 % on the step; from 256->512 down the study's tail grows (docs/history.md 4, tests/diag_f4_grad_layers.py).
 
 int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvGeom& g, const ConvEpilogue& e, float* scratch,
                           hipStream_t stream, const InBn& in) {

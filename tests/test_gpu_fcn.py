@@ -601,7 +601,7 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list, 
     Second fixture (grad_study_b64.npz, six seeded batches of 64 = configs[3]'s per-GPU batch, where the fp32 plans pick their large-batch
     tiles and 36-plane Winograd problems): the same bars.  Third fixture (grad_study_b32.npz, twelve seeded batches of the headline workload's
     own shape -- 32 transitions, Cin 4, Cout 2): the same bars; it is the sample the choice of F(4x4,3x3) for the grad-mode forward of
-    layer4's 512->512 convolutions rests on (tests/diag_f4_grad_layers.py).  Fourth fixture (grad_study_b128.npz, round 4: twelve
+    layer4's 512->512 convolutions rests on (tests/diag_f4_grad_layers.py, docs/history.md 4).  Fourth fixture (grad_study_b128.npz, round 4: twelve
     batches of 128 = configs[2] / configs[4]'s per-GPU shape, Cin 5, Cout 2; reference fp32 median 2.9e-3): median <= 2 x (measured 1.5 x), eleven of
     the twelve cases within 3 x (measured: within 2 x) and none beyond 10 x.  The twelfth, gs_b128_09, sits at 6.8 x (2.0e-2) whatever the plan
     computes with -- Winograd forms or direct convolutions, fused or separate BatchNorm sums, one-hot or dense backward all give 2.01e-2 .. 2.06e-2 --
