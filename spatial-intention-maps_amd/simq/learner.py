@@ -359,7 +359,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
 
 _SIDE_STREAMS = {}
 FUSED_LIBRARY_STEP = True       # single-process steps go through ONE library call (simq_train_step) instead of ~15 ctypes calls
-OVERLAP_TARGET_FORWARD = os.environ.get('SIMQ_OVERLAP', '1') != '0'   # run the (independent) target-net forward on a side stream; bench.py turns it off
+OVERLAP_TARGET_FORWARD = True   # run the (independent) target-net forward on a side stream (module attribute: bench.py's serial roofline pass and --no-overlap turn it off; never read from the environment)
                                  # for its per-kernel HIP-event pass, where concurrent kernels would share the GPU
 
 
