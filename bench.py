@@ -86,6 +86,7 @@ def parse():
     ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
     ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_plan_options.fwd_overlap of every plan, A/B (2 = default: three forwards side by side)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_plan_options.plane_xcd of every plan (batched GEMM planes per XCD), A/B')
+    ap.add_argument('--early-target', type=int, default=None, choices=[0, 1], help='tools only: simq.learner.EARLY_TARGET_FORWARD (the target-net forward of a step beside the previous step), A/B')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
     ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
@@ -306,6 +307,9 @@ def main():
     if args.no_upload_stream:
         import simq.learner as _sl
         _sl.UPLOAD_STREAM = False
+    if args.early_target is not None:
+        import simq.learner as _sl
+        _sl.EARLY_TARGET_FORWARD = bool(args.early_target)
     if args.no_overlap:
         import simq.learner as _sl
         _sl.OVERLAP_TARGET_FORWARD = False

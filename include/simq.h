@@ -315,6 +315,12 @@ typedef struct simq_train_args {
                                   * TD / Huber launch -- behind the all-reduce with `comm`), on the library's own copy stream.  The
                                   * host then calls simq_train_loss_wait() instead of synchronising the stream: train.py:137-139's
                                   * loss.item() without waiting for backward + SGD, so that the next step is enqueued while this one runs */
+    void* target_stream;         /* NULL, or a stream the CALLER has already ordered behind everything the target-net forward reads (next_state,
+                                  * the target net's parameters / weight cache, the previous reader of q_tgt and t_ws): the forward of
+                                  * train.py:122 is then enqueued there WITHOUT waiting for `stream` -- it depends on nothing this step or the
+                                  * previous one computes, so it may run beside the previous step's backward pass and SGD (the host enqueues
+                                  * step t+1 while step t still runs, see loss_host) -- and `stream` waits for it where the values are
+                                  * gathered.  Needs side_stream (the three-forward form, fwd_overlap = 2); results are bit-identical. */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
 /* blocks until the loss_host copy of the last simq_train_step of `plan` on the current device has landed.  The step's streams must belong

@@ -99,11 +99,13 @@ int simq_train_step(const simq_train_args* a) {
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->third_ev, hipEventDisableTiming));
         }
         hipStream_t third = ps->third;
+        // (target_stream: the caller ordered it behind the target forward's inputs -- no wait for this step's or the previous step's work)
+        hipStream_t tstream = a->target_stream ? static_cast<hipStream_t>(a->target_stream) : side;
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
-        SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        if (!a->target_stream) SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
-        RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, side));
-        SIMQ_CHECK_HIP(hipEventRecord(ev_join, side));
+        RC(simq_forward(p, SIMQ_MODE_EVAL, Nn, a->t_params, a->t_wcache, a->t_bnbuf, a->next_state, a->q_tgt, a->t_ws, tstream));
+        SIMQ_CHECK_HIP(hipEventRecord(ev_join, tstream));
         Ctx cn{p, Nn, a->params, nullptr, a->bnbuf, static_cast<char*>(a->ws_tmp), make_layout(p, Nn), third};
         cn.wc = static_cast<char*>(const_cast<void*>(a->wcache)); cn.W = make_wlayout(p);
         cn.defer_running = true;

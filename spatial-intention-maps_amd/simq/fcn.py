@@ -231,6 +231,9 @@ class FCN(torch.nn.Module):
             lib.call('simq_weights_prepare', self.plan.handle, ptr(self.flat_params), ptr(self.wcache), stream_ptr(self.device_))
             self.weights_dirty = False
             self._weights_stamp += 1
+            # (a reader on another stream -- the early target-net forward of simq.learner -- orders itself behind the parameters' last change)
+            self._weights_event = torch.cuda.Event()
+            self._weights_event.record(torch.cuda.current_stream(self.device_))
 
     def _forward_raw(self, x_nhwc, mode, sync=None):
         """x_nhwc [B,96,96,Cin] fp32 contiguous on device -> q [B,Cout,96,96].  sync: a simq.dist.SyncBN (global-minibatch

@@ -61,11 +61,15 @@ class DeviceBatch:
     state [B,96,96,C] f32 NHWC, action [B] i64, reward [B] f32 (device);
     next_state [N',96,96,C] (non-final only), nonfinal_pos [N'] i32 device, non_final_mask host bool list.
     """
-    __slots__ = ('state', 'action', 'reward', 'next_state', 'nonfinal_pos', 'non_final_mask')
+    __slots__ = ('state', 'action', 'reward', 'next_state', 'nonfinal_pos', 'non_final_mask', 'ready_event')
 
-    def __init__(self, state, action, reward, next_state, nonfinal_pos, non_final_mask):
+    def __init__(self, state, action, reward, next_state, nonfinal_pos, non_final_mask, ready_event=None):
         self.state, self.action, self.reward = state, action, reward
         self.next_state, self.nonfinal_pos, self.non_final_mask = next_state, nonfinal_pos, non_final_mask
+        # set when the tensors were produced on a stream of their own (DeviceReplayBuffer.gather): the event behind their last writer.  The
+        # consuming stream has already been made to wait for it; a stream that wants to start EARLIER (the target-net forward of the next
+        # step beside the running step, EARLY_TARGET_FORWARD) waits for it itself.
+        self.ready_event = ready_event
 
 
 def assemble_batch(batch, device, allow_all_final=False):
@@ -91,8 +95,21 @@ def assemble_batch(batch, device, allow_all_final=False):
 
 
 _PACK_RINGS = {}        # device -> [pinned uint8 buffers, events, position]
-_UPLOAD_STREAMS = {}    # device -> the stream the packed per-batch uploads run on
+_UPLOAD_STREAMS = {}    # device -> the stream the packed per-batch uploads (and, by default, the ring's pushes and gathers) run on
+
+
+def _upload_stream(device):
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    up = _UPLOAD_STREAMS.get(device)
+    if up is None:
+        up = _UPLOAD_STREAMS[device] = torch.cuda.Stream(device)
+    return up
 UPLOAD_STREAM = True    # (A-B: False = the upload on the consuming stream, rounds 1-3)
+GATHER_ON_UPLOAD_STREAM = True   # DeviceReplayBuffer.gather: the HBM gathers behind the index copy on the upload stream (A-B: False = on the consuming stream)
+EARLY_TARGET_FORWARD = True      # train_step: the target-net forward of a step on a stream of its own that does not wait for the previous step (A-B)
+_EARLY_STREAMS = {}
 
 
 def _upload_packed(device, arrays, slots=4):
@@ -121,9 +138,7 @@ def _upload_packed(device, arrays, slots=4):
         # the copy depends on nothing the device is doing: on its own stream it runs while the previous step's kernels still do, and the
         # consuming stream only waits for its event (on the consuming stream it queued behind the whole previous step and the device idled
         # for the copy's latency at every step boundary).  The buffer comes from the upload stream's pool and is handed to the consumer.
-        up = _UPLOAD_STREAMS.get(device)
-        if up is None:
-            up = _UPLOAD_STREAMS[device] = torch.cuda.Stream(device)
+        up = _upload_stream(device)
         with torch.cuda.stream(up):
             devbuf = torch.empty(total, dtype=torch.uint8, device=device)
             devbuf.copy_(bufs[i][:total], non_blocking=True)
@@ -160,6 +175,9 @@ class _DeviceObs:
         return tuple(self.store.shape[1:])
 
     def __array__(self, dtype=None, copy=None):
+        up = _UPLOAD_STREAMS.get(self.store.device) if self.store.is_cuda else None     # (keys carry the device index, as tensor.device does)
+        if up is not None:
+            up.synchronize()               # (ring slots are written on the upload stream: _PinnedStaging.upload)
         a = self.store[self.slot].cpu().numpy()
         return a if dtype is None else a.astype(dtype, copy=False)
 
@@ -196,9 +214,21 @@ class _PinnedStaging:
         if self.events[i] is not None:
             self.events[i].synchronize()                       # the copy that last used this slot (32 pushes ago) is long done
         self.buf[i].copy_(torch.as_tensor(arr))                # host memcpy into pinned memory
-        dst.copy_(self.buf[i], non_blocking=True)              # asynchronous H2D on the current stream
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        # asynchronous H2D -- on the UPLOAD stream when the gathers run there (GATHER_ON_UPLOAD_STREAM): the ring is then written and read on
+        # one stream (stream order is the only ordering needed) and neither a push nor the next gather queues behind the learner's running
+        # step on the consuming stream.  Otherwise on the current stream, with an event for a gather elsewhere to wait on.
+        up = _upload_stream(self.device) if (UPLOAD_STREAM and GATHER_ON_UPLOAD_STREAM) else None
+        if up is not None:
+            with torch.cuda.stream(up):
+                dst.copy_(self.buf[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(up)
+            self.last_event = None
+        else:
+            dst.copy_(self.buf[i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.last_event = ev                               # (a gather on another stream orders itself behind the ring's last write)
         self.events[i] = ev
 
 
@@ -243,6 +273,9 @@ class DeviceReplayBuffer:
         s0 = self.position
         self.states[s0:s0 + n].copy_(torch.as_tensor(states))
         self.next_states[s0:s0 + n].copy_(torch.as_tensor(next_states))
+        if self.device.type == 'cuda':
+            self._bulk_event = torch.cuda.Event()
+            self._bulk_event.record(torch.cuda.current_stream(self.device))
         for i in range(n):
             self.buffer.append(Transition(_DeviceObs(self.states, s0 + i), int(actions[i]), float(rewards[i]),
                                           None if terminal[i] else _DeviceObs(self.next_states, s0 + i)))
@@ -272,6 +305,29 @@ class DeviceReplayBuffer:
             np.asarray([int(r.state) for r in recs], np.int64), np.asarray(nf, np.int64),
             np.asarray([r.action for r in recs], np.int64), np.asarray([r.reward for r in recs], np.float32),
             np.asarray([i for i, m in enumerate(mask) if m], np.int32)))
+        up = _upload_stream(dev) if (UPLOAD_STREAM and GATHER_ON_UPLOAD_STREAM) else None
+        if up is not None:
+            # the two gathers on the upload stream, behind the index copy they read: they depend on the ring and the indices only, not on the
+            # step that is still running on the consuming stream -- the minibatch is ready while that step runs, and a consumer that can start
+            # early (EARLY_TARGET_FORWARD) finds it there.  The ring's last push (a copy on the consuming stream) is waited for first.
+            main = torch.cuda.current_stream(dev)
+            ev_push = getattr(self._staging, 'last_event', None) if hasattr(self, '_staging') else None
+            if getattr(self, '_bulk_event', None) is not None:
+                up.wait_event(self._bulk_event)
+            if ev_push is not None:
+                up.wait_event(ev_push)
+            with torch.cuda.stream(up):
+                state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
+                lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), stream_ptr(dev))
+                next_state = torch.empty((len(nf), W, W, self.C), dtype=torch.float32, device=dev)
+                if nf:
+                    lib.call('simq_replay_gather', ptr(self.next_states), self.item, ptr(nindex), len(nf), ptr(next_state), stream_ptr(dev))
+                ready = torch.cuda.Event()
+                ready.record(up)
+            main.wait_event(ready)
+            for t in (state, next_state, index, nindex):
+                t.record_stream(main)
+            return DeviceBatch(state, action, reward, next_state, pos, mask, ready)
         state = torch.empty((B, W, W, self.C), dtype=torch.float32, device=dev)
         lib.call('simq_replay_gather', ptr(self.states), self.item, ptr(index), B, ptr(state), st)
         next_state = torch.empty((len(nf), W, W, self.C), dtype=torch.float32, device=dev)
@@ -581,10 +637,38 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
                    t_ws=target_net._workspace('tmp', Nn), state=b.state, next_state=next_state, action=b.action, reward=b.reward,
                    nonfinal_pos=nonfinal_pos, q=q, q_next=q_next, q_tgt=q_tgt, dq=dq, nsv=nsv, vals=vals, best=best, q_sa=q_sa,
                    y=y, td=td, out4=out4, opt_scratch=st_opt.scratch, total_norm=st_opt.total_norm)
+    # The target net's forward over the next states (train.py:122) reads nothing this step or the previous one computes.  When the
+    # minibatch was gathered on a stream of its own (DeviceBatch.ready_event) it goes to an "early" stream ordered behind exactly what it
+    # reads -- the gathered next states, the target net's weight cache, the last reader of the Q-map buffer it writes -- and runs beside
+    # the previous step's backward pass and SGD (the host enqueues this step while the previous one still runs: `sync` below).  Same
+    # kernels on the same operands: bit-identical.  The Q-map buffers alternate between two per net (a fresh torch.empty could be a block
+    # the previous step's queued kernels still use: the allocator only knows the consuming stream).
+    early = None
+    if (EARLY_TARGET_FORWARD and side is not None and use_double_dqn and Nn_real and not a.sync_bn and getattr(b, 'ready_event', None) is not None
+            and policy_net.plan.options.get('fwd_overlap', 2) == 2):
+        early = _EARLY_STREAMS.get(dev)
+        if early is None:
+            early = _EARLY_STREAMS[dev] = torch.cuda.Stream(dev)
+        slot = policy_net.__dict__.setdefault('_qtgt_slot', 0)
+        bufs = policy_net.__dict__.setdefault('_qtgt_bufs', [None, None])
+        frees = policy_net.__dict__.setdefault('_qtgt_free', [None, None])
+        if bufs[slot] is None or bufs[slot].numel() < Nn * n:
+            bufs[slot] = torch.empty(Nn * n, **f32)
+            frees[slot] = None
+        q_tgt = bufs[slot][:Nn * n].view(Nn, n)
+        tensors['q_tgt'] = q_tgt
+        early.wait_event(b.ready_event)
+        if getattr(target_net, '_weights_event', None) is not None:
+            early.wait_event(target_net._weights_event)
+        if frees[slot] is not None:
+            early.wait_event(frees[slot])
+        b.next_state.record_stream(early)
+        policy_net._qtgt_slot = slot ^ 1
     for k, t in tensors.items():
         setattr(a, k, None if t is None else t.data_ptr())
     a.stream = main.cuda_stream
     a.side_stream = side.cuda_stream if side is not None else None
+    a.target_stream = early.cuda_stream if early is not None else None
     loss_host = None
     if sync:
         # train.py:137-139 (loss.item()) without synchronising the stream: the library copies the four sums to pinned memory as soon as
@@ -594,7 +678,11 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
             loss_host = policy_net._loss_host = torch.empty(4, dtype=torch.float32).pin_memory()
         a.loss_host = loss_host.data_ptr()
     lib.call('simq_train_step', ctypes.byref(a))
-    if side is not None:
+    if early is not None:
+        ev = torch.cuda.Event()
+        ev.record(main)                     # (behind this step's q_gather: the buffer may be rewritten two steps from now)
+        policy_net._qtgt_free[policy_net._qtgt_slot ^ 1] = ev
+    elif side is not None:
         q_tgt.record_stream(side)
     # bookkeeping the separate calls do on the Python side
     policy_net._train_generation += 1

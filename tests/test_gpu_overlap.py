@@ -133,3 +133,49 @@ def test_plan_owned_streams_are_created_lazily_and_die_with_the_plan(env):
         assert torch.equal(grads, ref)
         del policy, _
         gc.collect()
+
+
+@pytest.mark.parametrize('precision,B', [('fp32', 8), ('bf16', 16)])
+def test_early_target_forward_across_steps_is_bit_identical(env, precision, B):
+    """Round 5: the target net's forward of step t + 1 (train.py:122) is enqueued on a stream of its own that does NOT wait for step t -- it
+    reads the gathered next states (gathered on the upload stream), the target net's weight cache and nothing the learner is computing --
+    and runs beside step t's backward pass.  A training loop shaped like the reference's (train.py:241-269: push one transition, sample from
+    the HBM ring, train(), every third step copy the policy's weights into the target net) must give the same losses, TD targets,
+    parameters and BatchNorm buffers BIT FOR BIT with the early stream on and off, on deterministic plans: the ring is pushed to and
+    gathered from on one stream, the early stream waits for the target net's last weight change and for the last reader of the Q-map
+    buffer it writes."""
+    import random
+    e, c = env, env['cases']
+    sl = e['sl']
+    cin, cout = 5, 2
+
+    def loop(early):
+        keep = (sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM)
+        sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM = early, early
+        try:
+            policy, target = _nets(e, precision, {'deterministic': 1}, cin, cout)
+            ring = e['simq'].DeviceReplayBuffer(64, cin)
+            trs = e['synth'].make_transitions(48, cin, cout, 11, terminal_frac=0.2)
+            for t in trs[:40]:
+                ring.push(*t)
+            random.seed(5)
+            out = []
+            for step in range(6):
+                ring.push(*trs[40 + step])                                   # the collector's hand-off (train.py:244)
+                batch = ring.gather(ring.sample_indices(B))
+                assert (getattr(batch, 'ready_event', None) is not None) == early
+                info = sl.train_step(policy, target, batch, c.GAMMA, B, c.LR, c.MOMENTUM, c.WEIGHT_DECAY, c.CLIP, use_double_dqn=True)
+                out.append((info['loss'], info['td_error'], policy._last['y'].clone(), policy._last['q_sa'].clone()))
+                if step % 3 == 2:
+                    target.copy_state_from(policy)                           # train.py:267-269
+            torch.cuda.synchronize()
+            return out, policy.flat_params.clone(), policy.bn_buffers.clone(), target.flat_params.clone()
+        finally:
+            sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM = keep
+    ref, p0, bn0, t0 = loop(False)
+    got, p1, bn1, t1 = loop(True)
+    for s, (a, b) in enumerate(zip(ref, got)):
+        assert a[0] == b[0] and a[1] == b[1], 'step %d: loss / td error differ: %r vs %r' % (s, a[:2], b[:2])
+        assert torch.equal(a[2], b[2]), 'step %d: TD targets differ (the target-net forward read stale next states or weights)' % s
+        assert torch.equal(a[3], b[3]), 'step %d: q_sa differs' % s
+    assert torch.equal(p0, p1) and torch.equal(bn0, bn1) and torch.equal(t0, t1)

@@ -43,7 +43,7 @@ def main():
         t_end = max(e for e in nwp if nxt_td is None or e < nxt_td)
         steps.append((prev_end, t_td, t_sq, t_end))
     steps = steps[len(steps) // 2:]                                              # steady state: the second half
-    agg = collections.OrderedDict((ph, dict(wall=0.0, b1=0.0, b2=0.0, cls=collections.Counter())) for ph in ('forward', 'backward', 'tail'))
+    agg = collections.OrderedDict((ph, dict(wall=0.0, b1=0.0, b2=0.0, mat=0.0, cls=collections.Counter(), lonely=collections.Counter())) for ph in ('forward', 'backward', 'tail'))
     for (a, b, cc, d) in steps:
         for ph, lo, hi in (('forward', a, b), ('backward', b, cc), ('tail', cc, d)):
             ev = []
@@ -51,23 +51,36 @@ def main():
                 if e <= lo or s >= hi:
                     continue
                 s2, e2 = max(s, lo), min(e, hi)
-                ev.append((s2, 1)); ev.append((e2, -1))
+                m = 1 if klass(n) == 'matrix' else 0
+                ev.append((s2, 1, m, n)); ev.append((e2, -1, -m, n))
                 agg[ph]['cls'][klass(n)] += (e2 - s2) / 1e3
-            ev.sort()
-            depth, last = 0, lo
-            for t, dd in ev:
+            ev.sort(key=lambda t: (t[0], t[1]))
+            depth, mdepth, last = 0, 0, lo
+            running = collections.Counter()
+            for t, dd, dm, n in ev:
                 if depth >= 1:
                     agg[ph]['b1'] += (t - last) / 1e3
                 if depth >= 2:
                     agg[ph]['b2'] += (t - last) / 1e3
+                if mdepth >= 1:
+                    agg[ph]['mat'] += (t - last) / 1e3
+                elif depth >= 1:                      # only non-matrix kernels on the device: attribute the interval to them
+                    for k, c in running.items():
+                        if c > 0:
+                            agg[ph]['lonely'][k] += (t - last) / 1e3 / sum(1 for v in running.values() if v > 0)
                 depth += dd
+                mdepth += dm
+                running[n] += dd
                 last = t
             agg[ph]['wall'] += (hi - lo) / 1e3
     n = max(len(steps), 1)
     print('# %d steady-state steps; per step, microseconds' % len(steps))
-    print('%-9s %9s %9s %9s   %s' % ('phase', 'wall', '>=1 busy', '>=2 busy', 'summed kernel time by class'))
+    print('%-9s %9s %9s %9s %11s   %s' % ('phase', 'wall', '>=1 busy', '>=2 busy', 'matrix busy', 'summed kernel time by class'))
     for ph, v in agg.items():
-        print('%-9s %9.1f %9.1f %9.1f   %s' % (ph, v['wall'] / n, v['b1'] / n, v['b2'] / n, '  '.join('%s %.1f' % (k, t / n) for k, t in v['cls'].most_common())))
+        print('%-9s %9.1f %9.1f %9.1f %11.1f   %s' % (ph, v['wall'] / n, v['b1'] / n, v['b2'] / n, v['mat'] / n, '  '.join('%s %.1f' % (k, t / n) for k, t in v['cls'].most_common())))
+    print('# wall time with NO matrix-class kernel on the device, by the kernels that ran then (us per step):')
+    for ph, v in agg.items():
+        print('%-9s %s' % (ph, '  '.join('%s %.1f' % (k[:34], t / n) for k, t in v['lonely'].most_common(12))))
     print('step wall %.1f us' % (sum(v['wall'] for v in agg.values()) / n))
 
 
