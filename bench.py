@@ -206,8 +206,8 @@ def cpu_baseline(cin, cout, batch):
 
 
 PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summaries newest first, kernel whose bytes per launch `roofline.traffic` quotes)
-    'fp32': (('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),   # (name prefix)
-    'bf16': (('r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
+    'fp32': (('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),   # (name prefix)
+    'bf16': (('r05_pmc_traffic_bf16_b128.json', 'r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
 }
 DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
 
@@ -582,7 +582,7 @@ def main():
             'ms_per_step_instrumented': round(dt_inst / steps * 1e3, 3),
             'timed': 'HIP-event pairs around every launch of the kernel over %d steps behind the timed region, each kernel ALONE on the device '
                      '(the step\'s stream overlaps off for these steps only; `value` is the overlapped step); the matching rocprofv3 trace is '
-                     'profiles/r04_bench_%s_kernel_trace_serial.txt, the overlapped step\'s profiles/r04_bench_%s_kernel_trace.txt' % (
+                     'profiles/r05_bench_%s_kernel_trace_serial.txt, the overlapped step\'s profiles/r05_bench_%s_kernel_trace.txt' % (
                          steps, 'b32' if precision == 'fp32' else 'bf16_b128', 'b32' if precision == 'fp32' else 'bf16_b128'),
         }
 
