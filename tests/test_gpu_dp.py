@@ -88,7 +88,16 @@ def _worker(rank, world, port, backend, use_comm, spec, out_dir, sync_bn=False):
         policy, target = _make_nets(simq, cin, cout, wseed, precision, dev)
         comm = sdist.Comm(dist.group.WORLD) if use_comm else None
         pg = None if use_comm else dist.group.WORLD
-        shard = assemble_batch(Transition(*zip(*trs[lo:hi])), dev, allow_all_final=True)
+        if use_comm:
+            # through the HBM ring, as bench.py --gpus N draws its shards: the gathers run on the upload stream and the target net's
+            # forward on the early stream (learner.EARLY_TARGET_FORWARD) beside the communicator's collectives
+            ring = simq.DeviceReplayBuffer(max(64, gB), cin, device=dev)
+            for t in trs:
+                ring.push(*t)
+            shard = ring.gather(list(range(lo, hi)), allow_all_final=True)
+            assert shard.ready_event is not None
+        else:
+            shard = assemble_batch(Transition(*zip(*trs[lo:hi])), dev, allow_all_final=True)
         gnf = sum(1 for t in trs if t[3] is not None)          # every rank sees the whole drawn minibatch: global non-final count
         out = {}
         if comm is not None:
