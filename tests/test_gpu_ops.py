@@ -620,6 +620,28 @@ def test_conv_winograd_wgrad_ksplit(L, B, Cin, Cout, splits):
     assert rel(out[splits][0], out[1][0]) < 6e-5               # (two summation orders of a gradient whose own error is 0.6-3e-5)
 
 
+@pytest.mark.parametrize('M,N,K,P', [(1152, 512, 512, 36), (1044, 256, 128, 36), (4608, 128, 128, 16), (512, 512, 1152, 36), (200, 64, 48, 5)],
+                         ids=['f4_l4_b32', 'f4_b29_ragged_rows', 'f2_l2_b32', 'wgrad_l4', 'small_odd_planes'])
+def test_gemm_f32_batched_is_an_exact_fp32_contraction(L, M, N, K, P):
+    """simq_gemm_f32_batched -- the transform-domain contraction of the Winograd layers, the dominant kernel of the fp32 step, on its own:
+    P independent y_g = x_g * w_g^T against fp64 at fp32 round-off (v_mfma_f32_16x16x4_f32 chains: 1e-6 of the range), a NaN-filled
+    destination (every tile written, rows past M never), and the two block -> (plane, tile) walks bit-identical."""
+    g = torch.Generator().manual_seed(5 + M + N + K)
+    x = torch.randn(P, M, K, generator=g).cuda(); w = torch.randn(P, N, K, generator=g).cuda()
+    ref = torch.bmm(x.double(), w.double().transpose(1, 2))
+    ys = []
+    for on in (1, 0):
+        y = torch.full((P, M, N), float('nan'), device='cuda')
+        L.lib.call('simq_gemm_f32_batched', L.ptr(x), L.ptr(w), L.ptr(y), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(plane_xcd=on))
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        ys.append(y)
+    assert float((ys[0].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert torch.equal(ys[0], ys[1])
+    with pytest.raises(Exception, match='not supported'):
+        L.lib.call('simq_gemm_f32_batched', L.ptr(x), L.ptr(w), L.ptr(ys[0]), M, N - 1, K, P, L.stream_ptr())
+
+
 def test_conv_winograd_rejects_unsupported_geometry(L):
     """Odd map sizes / channel counts the transform kernels cannot tile are refused with a message, not mis-computed."""
     x = torch.zeros(1, 23, 23, 64, device='cuda'); w = torch.zeros(64, 3, 3, 64, device='cuda'); y = torch.zeros(1, 23, 23, 64, device='cuda')
