@@ -185,6 +185,9 @@ def test_ragged_and_degenerate_batches(simq_mod):
         policy.forward_nhwc(torch.zeros(1, 96, 96, cin + 1, device='cuda'))      # wrong channel count
 
 
+_FP32_FAMILIES_B32 = ('gemm_f32_batched', 'winograd_f4', 'winograd_f2', 'winograd_f4_wgrad', 'stem_conv_f32')
+
+
 def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
     """BASELINE configs[1] at its own size: two consecutive simq.train calls on the seeded B=32 batch against
     tests/golden/train_c4o2_b32.npz (written by oracle/gen_golden.py after a bit-exact match of the oracle with the
@@ -201,7 +204,14 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
     policy.train()
     target.eval()
     opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    from simq import _lib
+    _lib.lib.call('simq_launch_counts_reset')
     info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    ran = _lib.launch_counts()
+    # the kernels bench.py times at this size are the ones compared here: Winograd planes through the exact-fp32 batched GEMM,
+    # the image-tile 1x1 / strided convolutions, the fp32 stem; nothing of the bf16 families
+    missing = [f for f in _FP32_FAMILIES_B32 if ran.get(f, 0) == 0]
+    assert not missing and not [f for f in ran if 'bf16' in f or f.endswith('16')], (missing, ran)
     rel1 = lambda a, b: abs(a - b) / abs(b)
     assert rel1(info1['loss'], float(g['loss'][0])) < 1e-4 and rel1(info1['td_error'], float(g['td_error'][0])) < 1e-4
     q_sa, y = policy._last['q_sa'].cpu().double().numpy(), policy._last['y'].cpu().double().numpy()
