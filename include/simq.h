@@ -124,11 +124,13 @@ typedef struct simq_plan_options {
                                    * the start of the step.  Steps under SyncBN keep form 0. */
     int wgrad_overlap;            /* 4.  The weight gradient of every residual-block convolution runs on a side stream beside the dgrads of the walk --
                                    * simq_train_step's side stream, or a plan-owned one (per device, destroyed with the plan) when a backward entry
-                                   * point is called on its own; the caller's stream is joined before the call returns its last launch.  fp32 plans:
+                                   * point is called on its own; the caller's stream is joined before the call returns its last launch.
                                    * 4 = until the temporaries of the block are written again two blocks later (a second set of gradient temporaries
-                                   * in the workspace), 1 = until the end of the residual block, 3 = beside the dgrad of the same convolution only;
-                                   * 2 = as 1 for every precision (measured slower for bf16); 0 = behind the dgrad on the caller's stream: no hidden
-                                   * stream at all (graph capture, profilers that must see every launch on the caller's stream). */
+                                   * in the workspace; matrix-core plans: for the default planes-only form, with dy1 on a plane of its own -- other
+                                   * matrix-core plans keep the serial order); fp32 plans only: 1 = until the end of the residual block, 3 = beside
+                                   * the dgrad of the same convolution only; 2 = as 1 for every precision (measured slower for bf16); 0 = behind the
+                                   * dgrad on the caller's stream: no hidden stream at all (graph capture, profilers that must see every launch on
+                                   * the caller's stream). */
     int plane_xcd;                /* 1.  The batched transform-domain GEMMs of the Winograd layers walk whole transform elements per XCD; 0 = launch order */
     int wgrad_xcd_group;          /* 1.  Pixel-split weight-gradient kernels place the tiles that share a pixel range on one XCD: 1 = the bf16 kernel
                                    * only, 2 = the fp32 kernel too (measured slower there), 0 = launch order */

@@ -85,12 +85,19 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     // in the transform-domain form each is [HBM-bound transforms | matrix-bound GEMM | HBM-bound transform], so side by side one's
     // transforms run under the other's GEMM.  cw = this context on the side stream with its own Winograd scratch; fork() after dy is
     // final, join() before the buffer that holds dy is written again (the next BatchNorm backward of the walk).
-    // fp32 plans only: the bf16 kernels of both halves hold 140-160 KB of LDS per block, two of them cannot share a CU, and side by side
-    // they only take turns (measured: 13 893 -> 13 516 tr/s on configs[2]; fp32 configs[1] 3466 -> 3524 in the pairwise form below)
-    const bool ov = c.wstream != nullptr && (wov == 2 || ((wov == 1 || wov == 3 || wov == 4) && !c.mc()));
+    // (fp32 configs[1] 3466 -> 3524 in the pairwise form below)
+    // Matrix-core plans (round 5): the pairwise forms stay off -- the bf16 kernels of both halves hold 140-160 KB of LDS per block, two of them
+    // cannot share a CU, and a weight gradient that must finish before the next BatchNorm backward only takes turns with its dgrad (2:
+    // 14 690 -> 14 470 tr/s on configs[2]).  The PIPED form (4) pays there too: up to one block behind, a weight gradient also runs beside
+    // the HBM-bound BatchNorm backward launches of the walk, which hold no LDS (14 690 -> 14 970, +1.9 %, three alternating pairs).  It
+    // needs the gradient temporaries as planes only (Ctx::planes_only, the default); other matrix-core plans keep the serial order.
+    const bool mc_piped = c.mc() && wov == 4 && c.planes_only() && L.DP[2] >= 0 && L.S2[0] >= 0;
+    const bool ov = c.wstream != nullptr && (wov == 2 || mc_piped || ((wov == 1 || wov == 3 || wov == 4) && !c.mc()));
     // ... and in fp32 the gradient w.r.t. conv1's output (dy1) is formed IN PLACE over bn1's incoming gradient (an elementwise pass), so that
     // dy2 stays alive and conv2's weight gradient may run until the end of the block instead of until bn1's backward
-    const bool wide = ov && !c.mc() && wov != 3;       // (3: the pairwise form, A-B runs)
+    // (matrix-core plans: dy1 gets a plane of its own, Layout::DP[2], instead)
+    const bool wide_mc = ov && mc_piped;
+    const bool wide = (ov && !c.mc() && wov != 3) || wide_mc;       // (3: the pairwise form, A-B runs)
     // ... and (4) with a second set of gradient temporaries the blocks alternate between, the main stream does not wait for a block's weight
     // gradients at the end of the block but only before the set is written again, two blocks later: the side stream runs up to one block behind
     const bool piped = wide && wov == 4 && L.S2[0] >= 0 && c.ev_wdone[0] && c.ev_wdone[1];
@@ -195,7 +202,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         float* T2 = S[(gi + 3) & 3];
         const int set = (i_hi - i) & 1;                      // (piped) the temporaries of this block: the S buffers or the second set
         if (piped) {
-            if (set) { T0 = Act(); T0.f = c.f(L.S2[0]); T1 = Act(); T1.f = c.f(L.S2[1]); T2 = c.f(L.S2[2]); }
+            if (set) {
+                T0 = Act(); T0.f = c.f(L.S2[0]); T0.pl = c.planes(L.DP2[0], smax);
+                T1 = Act(); T1.f = c.f(L.S2[1]); T1.pl = c.planes(L.DP2[1], smax);
+                T2 = c.f(L.S2[2]);
+            }
             if (i_hi - i >= 2) SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wdone[set], 0));   // block i + 2's weight gradients read them
         }
         // planes-only mode: the BN input gradients are consumed as planes (wgrad / dgrad operands), the ReLU masks come from
@@ -233,7 +244,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(conv_dgrad(c, b.c2, T0, T2, nullptr, 24, f1, gb));
         RC(trace(TL.blk[i].da1, T2, nel * gsz));
         Act D1 = T0;                                         // dy1: over dy2, or (wide) in place over the gradient bn1 receives
-        if (wide) { D1 = Act(); D1.f = T2; }
+        if (wide) { D1 = Act(); D1.f = T2; D1.fv = !po; if (wide_mc) D1.pl = c.planes((piped && set) ? L.DP2[2] : L.DP[2], smax); }
         else RC(join());                                     // (bn1's backward writes dy1 over dy2)
         RC(bn_bwd(c, b.b1, T2, m_a1, c.f(o.y1), D1, nullptr, rows, !no_fuse, m16_a1, -1, gb, mfy));
         RC(trace(TL.blk[i].dy1, dptr(D1), nel * dsz));
@@ -278,11 +289,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
 }  // namespace simq
 
 // Side stream + events for the weight-gradient overlap of a backward pass called on its own (simq_backward*, FCN.backward): the
-// plan's, per device (PlanStreams), created on first use and destroyed with the plan.  fp32 plans only (the overlap is off for the
-// matrix-core precisions, see backward_impl); wgrad_overlap = 0 keeps every launch on the caller's stream.
+// plan's, per device (PlanStreams), created on first use and destroyed with the plan.  Matrix-core plans: the piped form (4) and the
+// A-B form 2 only, see backward_impl; wgrad_overlap = 0 keeps every launch on the caller's stream.
 static int attach_backward_side(Ctx& c) {
     const int wov = c.p->opt.wgrad_overlap;
-    if (c.wstream || wov == 0 || (c.mc() && wov != 2)) return 0;
+    if (c.wstream || wov == 0 || (c.mc() && wov != 2 && wov != 4)) return 0;
     PlanStreams* ps = nullptr;
     int dev = 0;
     RC(plan_streams(c.p, &ps, &dev));

@@ -51,7 +51,7 @@ Layout make_layout(const simq_plan* p, int B) {
     L.defer = take(p->nbnbuf * (int64_t)sizeof(double));
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
     for (int i = 0; i < 4; ++i) L.S[i] = take(smax);
-    L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = -1;
+    L.p_pooled = L.p_up1 = L.DP[0] = L.DP[1] = L.DP[2] = L.DP2[0] = L.DP2[1] = L.DP2[2] = -1;
     for (int i = 0; i < 8; ++i) L.blk[i].p_a1 = L.blk[i].p_out = -1;
     if (p->precision != SIMQ_PREC_FP32) {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
@@ -68,7 +68,13 @@ Layout make_layout(const simq_plan* p, int B) {
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.fwd_total = off;          // everything a FORWARD pass touches ends here; what follows is scratch of the backward pass only
     L.wino2 = L.wino >= 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
-    for (int i = 0; i < 3; ++i) L.S2[i] = p->precision == SIMQ_PREC_FP32 ? take(smax) : -1;
+    const bool piped_mc = p->precision != SIMQ_PREC_FP32 && p->opt.wgrad_overlap == 4;   // (backward_impl: planes-only plans use them)
+    for (int i = 0; i < 3; ++i) L.S2[i] = (p->precision == SIMQ_PREC_FP32 || piped_mc) ? take(smax) : -1;
+    if (piped_mc) {
+        const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
+        L.DP[2] = take((int64_t)B * 294912 * h);
+        for (int i = 0; i < 3; ++i) L.DP2[i] = take((int64_t)B * 294912 * h);
+    }
     L.wslab = p->precision == SIMQ_PREC_BF16 ? take(conv_wgrad_bf16_slab_bytes()) : -1;
     L.dslab = p->opt.deterministic ? take(kWgradDetSlabFloats * f) : -1;
     L.total = off;

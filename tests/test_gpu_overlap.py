@@ -67,23 +67,27 @@ def test_overlapped_step_equals_the_serial_step_bit_for_bit(env, B):
         assert torch.equal(r['params'], ref['params']), 'parameters differ (wgrad_overlap %d, fwd_overlap %d)' % (wgrad, fwd)
 
 
-def test_overlapped_bf16_step_keeps_the_buffers_of_the_serial_step(env):
-    # bf16: the weight gradients stay on the main stream (LDS-bound kernels); the three forwards run side by side
-    ref = _two_steps(env, 0, 0, 16, precision='bf16')
-    r = _two_steps(env, 4, 2, 16, precision='bf16')
-    assert r['loss'] == ref['loss']
-    for k in ('bn', 'grads', 'params'):
-        assert torch.equal(r[k], ref[k]), k
+@pytest.mark.parametrize('precision,B', [('bf16', 16), ('bf16', 128), ('bf16x3', 16)])
+def test_overlapped_bf16_step_keeps_the_buffers_of_the_serial_step(env, precision, B):
+    # bf16: the three forwards side by side; the weight gradients up to one block behind the dgrads on planes of their own (4, the default)
+    # or beside them until the end of the block (2)
+    ref = _two_steps(env, 0, 0, B, precision=precision)
+    for wgrad, fwd in ((4, 2), (2, 2), (4, 0)):
+        r = _two_steps(env, wgrad, fwd, B, precision=precision)
+        assert r['loss'] == ref['loss'], (wgrad, fwd)
+        for k in ('bn', 'grads', 'params'):
+            assert torch.equal(r[k], ref[k]), (k, wgrad, fwd)
 
 
-def test_standalone_backward_on_the_plan_side_stream(env):
+@pytest.mark.parametrize('precision,B,modes', [('fp32', 8, (0, 4, 1)), ('bf16', 16, (0, 4, 2))])
+def test_standalone_backward_on_the_plan_side_stream(env, precision, B, modes):
     # FCN.backward / simq_backward_phase: dense upstream gradient, weight gradients on the plan-owned side stream (wgrad_overlap = 0: none)
     from simq._lib import MODE_TRAIN
     e = env
-    B, cin, cout = 8, 4, 2
+    cin, cout = 4, 2
     out = {}
-    for wgrad in (0, 4, 1):
-        policy, _ = _nets(e, 'fp32', {'deterministic': 1, 'wgrad_overlap': wgrad}, cin, cout)
+    for wgrad in modes:
+        policy, _ = _nets(e, precision, {'deterministic': 1, 'wgrad_overlap': wgrad}, cin, cout)
         g = torch.Generator().manual_seed(5)
         x = torch.randn(B, 96, 96, cin, generator=g).cuda()
         for _ in range(2):
@@ -93,7 +97,7 @@ def test_standalone_backward_on_the_plan_side_stream(env):
         torch.cuda.synchronize()
         out[wgrad] = (q.detach().clone(), policy.flat_grads.clone())
     assert float(out[0][1].abs().max()) > 0
-    for wgrad in (4, 1):
+    for wgrad in modes[1:]:
         assert torch.equal(out[wgrad][0], out[0][0])
         assert torch.equal(out[wgrad][1], out[0][1]), 'standalone backward: gradient differs with wgrad_overlap %d' % wgrad
 
