@@ -127,6 +127,9 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
     const bool no_fuse_head = !p->opt.fuse_bn_backward_sums;   // (diagnostics: separate reduction kernels)
+    const bool head_side = piped && phase != 2;                // the head's weight gradients on the side stream (see below)
+    Act dyh = dyact(S[0], 0);                                  // gradient w.r.t. conv1's output (BatchNorm 1's input gradient)
+    Act t2 = dyact(S[1], 1);                                   // U^T dy: gradient w.r.t. conv2's 24x24 output
     if (phase != 2) {
     if (oh) {   // B non-zeros: conv3 backward + bilinear transpose at those pixels only
         RC(launch_head_onehot_bwd(c.f(L.ah2), c.params + p->h3.w_off, oh->action, oh->q_sa, oh->y, oh->grad_scale, S[1],
@@ -138,20 +141,27 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
                                  c.dslab()));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
     }
-    Act dyh = dyact(S[0], 0);
+    // (piped: the head's two weight gradients run on the side stream too.  Their dy operands live in the SECOND set of temporaries, which
+    // the walk below does not touch before its second block -- that block then waits for them like for any earlier user of the set.
+    // Four alternating pairs of 60 steps: bf16 configs[2] 14 737 -> 15 016 tr/s, fp32 configs[1] 3906 -> 3908.)
+    if (head_side) {
+        dyh.f = c.f(L.S2[0]); dyh.pl = c.planes(L.DP2[0], smax);
+        t2.f = c.f(L.S2[1]); t2.pl = c.planes(L.DP2[1], smax);
+    }
+    const Ctx& ch = head_side ? cw : c;                              // where the head's weight gradients are launched
     bool hb1_fused = false;
     {   // BatchNorm 2 at 48x48; conv2 and everything behind it at 24x24 (the forward pass's order, transposed)
         Act dy2; dy2.f = S[0];                                       // (fp32 only: its consumer is the bilinear transpose)
         RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
-        Act t2 = dyact(S[1], 1);                                     // U^T dy: gradient w.r.t. conv2's 24x24 output
         RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
         RC(launch_colsum_rep(t2.f, cs, c.grads + p->h2.b_off, rows, 32, kStatReplicas, c.stream));   // (the bilinear weights of a pixel sum to 1)
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
+        if (head_side) RC(fork());
         if (c.lazy1()) {                                             // (a1 was never stored: conv2's weight gradient re-applies bn1 + ReLU to yh1)
             Act yh1; yh1.f = c.f(L.yh1);
-            RC(conv_wgrad(c, p->h2, yh1, t2, 24, c.inbn_saved(p->hb1)));
+            RC(conv_wgrad(ch, p->h2, yh1, t2, 24, c.inbn_saved(p->hb1)));
         } else {
-            RC(conv_wgrad(c, p->h2, a1, t2, 24));
+            RC(conv_wgrad(ch, p->h2, a1, t2, 24));
         }
         ConvEpilogue fh;                                             // ... whose epilogue also leaves BatchNorm 1's backward sums
         // (fp32 plans: 35 us of reduction pass saved.  The matrix-core plans keep the pass: their K = 32 dgrad runs the register-staged
@@ -167,8 +177,10 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         hb1_fused = fuse_hb1;
     }
     RC(bn_bwd(c, p->hb1, S[2], c.lazy1() ? nullptr : c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused, nullptr, -1, 0, c.lazy1()));
-    RC(launch_colsum_rep(S[0], cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, c.stream));
-    RC(conv_wgrad(c, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
+    RC(launch_colsum_rep(dyh.f, cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, c.stream));
+    if (head_side) RC(fork());
+    RC(conv_wgrad(ch, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
+    if (head_side) SIMQ_CHECK_HIP(hipEventRecord(c.ev_wdone[1], c.wstream));
     }
     // every dgrad that completes the gradient of a block output (or of a block's inner activation) also
     // accumulates sum(dz), sum(dz*xhat) of the BatchNorm(s) that consume that gradient next
@@ -187,7 +199,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         return e;
     };
     const int gb = c.gbf();
-    if (phase != 2) RC(conv_dgrad(c, p->h1, dyact(S[0], 0), S[1], nullptr, 24, fuse_block_out(7), gb));
+    if (phase != 2) RC(conv_dgrad(c, p->h1, dyh, S[1], nullptr, 24, fuse_block_out(7), gb));
     const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
     const int i_hi = phase == 2 ? kPhaseSplitBlock - 1 : 7, i_lo = phase == 1 ? kPhaseSplitBlock : 0;
     for (int i = i_hi; i >= i_lo; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
@@ -207,7 +219,8 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
                 T1 = Act(); T1.f = c.f(L.S2[1]); T1.pl = c.planes(L.DP2[1], smax);
                 T2 = c.f(L.S2[2]);
             }
-            if (i_hi - i >= 2) SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wdone[set], 0));   // block i + 2's weight gradients read them
+            if (i_hi - i >= 2 || (head_side && i_hi - i == 1))       // block i + 2's weight gradients (or the head's) read them
+                SIMQ_CHECK_HIP(hipStreamWaitEvent(c.stream, c.ev_wdone[set], 0));
         }
         // planes-only mode: the BN input gradients are consumed as planes (wgrad / dgrad operands), the ReLU masks come from
         // the activations' planes

@@ -68,8 +68,8 @@ Layout make_layout(const simq_plan* p, int B) {
     L.wino = p->wino_scratch_per_sample > 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
     L.fwd_total = off;          // everything a FORWARD pass touches ends here; what follows is scratch of the backward pass only
     L.wino2 = L.wino >= 0 ? take(((int64_t)B * p->wino_scratch_per_sample + p->wino_du_floats) * f) : -1;
-    const bool piped_mc = p->precision != SIMQ_PREC_FP32 && p->opt.wgrad_overlap == 4;   // (backward_impl: planes-only plans use them)
-    for (int i = 0; i < 3; ++i) L.S2[i] = (p->precision == SIMQ_PREC_FP32 || piped_mc) ? take(smax) : -1;
+    const bool piped_mc = p->precision != SIMQ_PREC_FP32;   // (used by planes-only plans with wgrad_overlap 4; the layout does not depend on scheduling options)
+    for (int i = 0; i < 3; ++i) L.S2[i] = take(smax);
     if (piped_mc) {
         const int64_t h = (int64_t)sizeof(uint16_t) * p->np();
         L.DP[2] = take((int64_t)B * 294912 * h);

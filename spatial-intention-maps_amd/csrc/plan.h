@@ -107,11 +107,11 @@ struct Layout {
                      // statistics update is deferred (BnRef::defer) leaves them here
     int64_t S[4];
     // bf16 planes (matrix-core precisions only): conv inputs, dy scratch, weights + flipped/transposed weights
-    int64_t p_pooled, p_up1, DP[3];   // DP[2]: wgrad_overlap 4 (dy1's own plane, so that dy2 outlives bn1's backward)
+    int64_t p_pooled, p_up1, DP[3];   // DP[2]: dy1's own plane (wgrad_overlap 4: dy2 outlives bn1's backward)
     int64_t DP2[3];  // wgrad_overlap 4: the planes of the second set of gradient temporaries (see S2), -1 otherwise
     int64_t wino;    // Winograd V | Mt scratch (fp32 plans with Winograd layers), -1 otherwise
     int64_t wino2;   // a second one for the weight gradients that run beside the dgrads on the side stream (backward only), -1 otherwise
-    int64_t S2[3];   // backward only (fp32 plans; matrix-core plans with wgrad_overlap 4): a second set of gradient temporaries, so that a block's weight gradients may still run
+    int64_t S2[3];   // backward only: a second set of gradient temporaries, so that a block's weight gradients may still run
                      // on the side stream while the next block's BatchNorm backwards / dgrads write theirs (-1 otherwise)
     int64_t wslab;   // partial tiles of the image-tile bf16 weight-gradient kernel (plain-bf16 plans: 75.5 MB at any batch), -1 otherwise
     int64_t dslab;   // deterministic plans: per-split partial tiles of the pixel-split weight-gradient kernels (64 MB), -1 otherwise
