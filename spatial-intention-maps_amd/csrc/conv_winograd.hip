@@ -334,8 +334,10 @@ __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restri
     if constexpr (XBN) inbn_commit(in);
 }
 
-// y = A^T m A (4x4 outputs per tile) + the forward epilogue of igemm_epilogue.h (bias, BatchNorm batch statistics, folded-BN affine,
-// residual, ReLU); no fused BN-backward reduction: these launches are never part of a backward walk
+// y = A^T m A (4x4 outputs per tile) + the epilogue of igemm_epilogue.h (bias, BatchNorm batch statistics, folded-BN affine, residual,
+// ReLU; for the dgrads -- backward.hip runs them in this form too -- the fused BatchNorm-backward sums of the layer(s) that consume the
+// gradient next).  One thread = one tile x 4 channels: 2 / 1 channels per thread (2-4 x the waves of a B = 32 launch) measured SLOWER
+// here and 4-6 % faster in the input transform, nothing on the step (profiles/r05_wino4f_channels_per_thread.txt).
 __global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restrict__ Mt, const EpiArgs p, int B, int H, int W, int C, int T) {
     __shared__ float red[4][256][4];
     const int lanes = C >> 2, tpb = 256 / lanes;
