@@ -301,6 +301,8 @@ typedef struct simq_train_args {
     float* params; void* wcache; float* bnbuf; float* grads; float* momentum_buf; void* ws_train; void* ws_tmp;   /* policy */
     const float* t_params; const void* t_wcache; float* t_bnbuf; void* t_ws;                                      /* target */
     const float* state; const float* next_state; const int64_t* action; const float* reward; const int32_t* nonfinal_pos;
+                                 /* (read until the END of the call's stream work: the grad-mode forward convolves `state` in place and the first
+                                  * convolution's weight gradient reads it again -- no copy into the workspace) */
     float* q; float* q_next; float* q_tgt; float* dq;               /* [batch|num_nonfinal][Cout*96*96] scratch / outputs */
     float* nsv; float* vals; int64_t* best; float* q_sa; float* y; float* td; float* out4;
     void* opt_scratch; float* total_norm;

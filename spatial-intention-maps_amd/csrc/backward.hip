@@ -293,7 +293,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     Act T1; T1.f = S[(gi + 2) & 3];
     const bool stem16 = c.W.stem16 >= 0;             // plain-bf16 plans: dy as a bf16 plane only, weight gradient on the bf16 matrix cores
     if (stem16) { T1 = dyact(S[(gi + 2) & 3], 1); T1.fv = false; }
-    Act x0; x0.f = c.f(L.x);
+    Act x0; x0.f = c.x_ext ? const_cast<float*>(c.x_ext) : c.f(L.x);
     const int y0_bf16 = c.W.stem16 >= 0 ? 1 : 0;     // pre-BN output: fp32, or bf16 from stem_conv_bf16
     const bool no_stem_fuse = !p->opt.fuse_stem_backward_sums || !p->opt.fuse_bn_backward_sums;   // diagnostics
     double* srep = reinterpret_cast<double*>(c.ws + L.red) + p->stem_rep_off;
@@ -359,10 +359,11 @@ TraceLayout make_trace_layout(const simq_plan* p, int B) {
 int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                               const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                               void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
-                              hipEvent_t ev_wjoin, hipEvent_t ev_wdone0, hipEvent_t ev_wdone1) {
+                              hipEvent_t ev_wjoin, hipEvent_t ev_wdone0, hipEvent_t ev_wdone1, const float* x_ext) {
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     c.sync = sync;
+    c.x_ext = x_ext;
     if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; c.ev_wdone[0] = ev_wdone0; c.ev_wdone[1] = ev_wdone1; }
     else RC(attach_backward_side(c));
     if (d_dq) return backward_impl(c, d_dq, phase);

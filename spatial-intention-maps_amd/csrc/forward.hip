@@ -98,13 +98,13 @@ int forward_impl(const Ctx& c, int mode, const float* d_x, float* d_q) {
     const Layout& L = c.L;
     const int B = c.B;
     // the input is kept only where a backward pass will read it again (the stem's weight gradient); the other forwards convolve d_x in place
-    if (mode == SIMQ_MODE_TRAIN)
+    if (mode == SIMQ_MODE_TRAIN && !c.x_ext)
         SIMQ_CHECK_HIP(hipMemcpyAsync(c.f(L.x), d_x, (size_t)B * 96 * 96 * p->cin * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
     if (mode != SIMQ_MODE_EVAL)
         SIMQ_CHECK_HIP(hipMemsetAsync(c.ws + L.red, 0, p->red_total * sizeof(double), c.stream));
     const int64_t rows = (int64_t)B * 576;
     // stem: conv 7x7 s2 -> BN -> ReLU -> maxpool 3x3 s2   (resnet.py:94-97); always the fp32 kernel (Cin is 3..10)
-    Act x0; x0.f = mode == SIMQ_MODE_TRAIN ? c.f(L.x) : const_cast<float*>(d_x);
+    Act x0; x0.f = (mode == SIMQ_MODE_TRAIN && !c.x_ext) ? c.f(L.x) : const_cast<float*>(d_x);
     const int stem16 = c.W.stem16 >= 0 ? 1 : 0;      // plain-bf16 plans: bf16 matrix cores, bf16 pre-BN output (stem_conv_bf16.hip)
     if (stem16) {
         RC(launch_stem_conv_bf16(x0.f, reinterpret_cast<const uint16_t*>(c.wc + c.W.stem16), reinterpret_cast<uint16_t*>(c.f(L.y0)),
@@ -258,6 +258,22 @@ int simq_forward_sync(const simq_plan* plan, int mode, int batch, const float* d
     c.sync = sync;
     return forward_impl(c, mode, d_x, d_q);
 }
+
+}  // extern "C"
+
+namespace simq {
+int forward_sync_inplace(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf, const float* d_x,
+                         float* d_q, void* d_workspace, hipStream_t stream, const simq_sync* sync) {
+    RC(check_sync(sync, batch));
+    Ctx c{plan, batch, d_params, nullptr, d_bnbuf, static_cast<char*>(d_workspace), make_layout(plan, batch), stream};
+    c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
+    c.sync = sync;
+    c.x_ext = d_x;
+    return forward_impl(c, SIMQ_MODE_TRAIN, d_x, d_q);
+}
+}  // namespace simq
+
+extern "C" {
 
 int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnbuf, void* d_workspace, void* stream, const simq_sync* sync) {
     SIMQ_REQUIRE(plan && d_workspace && sync && sync->reduce && layout_batch >= 1, "forward_sync_null: bad argument");

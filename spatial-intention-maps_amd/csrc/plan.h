@@ -149,7 +149,11 @@ struct Ctx {
     // backward inside simq_train_step: the weight gradients run on this stream beside the dgrads of the same layer (fork / join events)
     hipStream_t wstream = nullptr;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
-    hipEvent_t ev_wdone[2] = {nullptr, nullptr};   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
+    hipEvent_t ev_wdone[2] = {nullptr, nullptr};
+    // simq_train_step: the minibatch the caller handed over stays valid for the whole call's stream work, so the grad-mode forward
+    // convolves it in place and the stem's weight gradient reads it again at the end of the backward pass -- no copy into the workspace
+    // (nullptr: the forward keeps a copy in L.x for a backward pass that is a call of its own)
+    const float* x_ext = nullptr;   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
     // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
     // inspection aid: simq_backward_traced copies the gradient tensors of the walk here as they become final (TraceLayout), nullptr otherwise
     char* trace = nullptr;
@@ -249,7 +253,10 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
 int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                        const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                        void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
-                       hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr);
+                       hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr, const float* x_ext = nullptr);
+// simq_forward_sync in train mode on the caller's minibatch in place (simq_train_step; see Ctx::x_ext)
+int forward_sync_inplace(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf, const float* d_x,
+                         float* d_q, void* d_workspace, hipStream_t stream, const simq_sync* sync);
 int check_sync(const simq_sync* sync, int batch);
 
 // the plan's stream set of the calling thread's current device (created on first use); *out = nullptr when the device index is out of range

@@ -112,7 +112,7 @@ int simq_train_step(const simq_train_args* a) {
         RC(forward_impl(cn, SIMQ_MODE_TRAIN_NOGRAD, a->next_state, a->q_next));
         RC(launch_q_argmax(a->q_next, Nn, n, a->best, nullptr, third));
         SIMQ_CHECK_HIP(hipEventRecord(ps->third_ev, third));
-        RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
+        RC(forward_sync_inplace(p, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114 (a->state in place)
         SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ps->third_ev, 0));
         RC(launch_bn_running_deferred(a->bnbuf, reinterpret_cast<const double*>(cn.ws + cn.L.defer), p->nbnbuf, main));     // update #2
         SIMQ_CHECK_HIP(hipStreamWaitEvent(main, ev_join, 0));
@@ -122,7 +122,7 @@ int simq_train_step(const simq_train_args* a) {
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
     }
-    RC(simq_forward_sync(p, SIMQ_MODE_TRAIN, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114
+    RC(forward_sync_inplace(p, B, a->params, a->wcache, a->bnbuf, a->state, a->q, a->ws_train, main, sync));   // train.py:114 (a->state in place)
     // the target-net forward depends on nothing the policy net computes: side stream, joined before its Q-map is read.  It is
     // forked BEHIND the policy's train-mode forward so that it overlaps the policy's next-state forward: both run on the
     // ~29 non-final samples, whose tiles do not fill whole rounds of the CUs, and fill each other's tails (+1.7 % on the step
@@ -162,7 +162,7 @@ int simq_train_step(const simq_train_args* a) {
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;
         return backward_sync_side(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync,
-                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1);
+                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1, a->state);
     };
     if (!a->comm) {
         RC(backward(0));
