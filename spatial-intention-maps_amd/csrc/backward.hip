@@ -124,6 +124,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     const int64_t smax = (int64_t)B * 294912;
     auto dyact = [&](float* buf, int which) { Act a; a.f = buf; a.pl = c.planes(L.DP[which], smax); return a; };
     double* cs = reinterpret_cast<double*>(c.ws + L.colsum);
+    double* cs_side = cs + kStatReplicas * 2 * 128;           // the side stream's own slots (bn_bwd's unfused sums use the first half on the main stream)
     const int64_t rows = (int64_t)B * 576;
     // ---- head (networks.py:18-26 reversed) ----
     const bool no_fuse_head = !p->opt.fuse_bn_backward_sums;   // (diagnostics: separate reduction kernels)
@@ -149,14 +150,19 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         t2.f = c.f(L.S2[1]); t2.pl = c.planes(L.DP2[1], smax);
     }
     const Ctx& ch = head_side ? cw : c;                              // where the head's weight gradients are launched
+    // ... and, matrix-core plans, the two bias gradients (three small launches each) with them, off the head's serial chain: four alternating
+    // pairs of 80 steps, bf16 configs[2] 14 733-14 857 -> 14 740-14 894 tr/s (+0.4 %); fp32 configs[1] 3922-3944 -> 3867-3926: stays on the walk's stream
+    static const int bias_side_on = SIMQ_TUNE_INT("SIMQ_HEAD_BIAS_SIDE", 1);      // (ablation build: A-B)
+    const bool bias_side = head_side && c.mc() && bias_side_on;
     bool hb1_fused = false;
     {   // BatchNorm 2 at 48x48; conv2 and everything behind it at 24x24 (the forward pass's order, transposed)
         Act dy2; dy2.f = S[0];                                       // (fp32 only: its consumer is the bilinear transpose)
         RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
         RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
-        RC(launch_colsum_rep(t2.f, cs, c.grads + p->h2.b_off, rows, 32, kStatReplicas, c.stream));   // (the bilinear weights of a pixel sum to 1)
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         if (head_side) RC(fork());
+        // the bias gradient (three small launches) goes where the weight gradient goes: off the head's serial chain when that is the side stream
+        RC(launch_colsum_rep(t2.f, bias_side ? cs_side : cs, c.grads + p->h2.b_off, rows, 32, kStatReplicas, bias_side ? ch.stream : c.stream));   // (the bilinear weights of a pixel sum to 1)
         if (c.lazy1()) {                                             // (a1 was never stored: conv2's weight gradient re-applies bn1 + ReLU to yh1)
             Act yh1; yh1.f = c.f(L.yh1);
             RC(conv_wgrad(ch, p->h2, yh1, t2, 24, c.inbn_saved(p->hb1)));
@@ -177,8 +183,8 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         hb1_fused = fuse_hb1;
     }
     RC(bn_bwd(c, p->hb1, S[2], c.lazy1() ? nullptr : c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused, nullptr, -1, 0, c.lazy1()));
-    RC(launch_colsum_rep(dyh.f, cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, c.stream));
     if (head_side) RC(fork());
+    RC(launch_colsum_rep(dyh.f, bias_side ? cs_side : cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, bias_side ? ch.stream : c.stream));
     RC(conv_wgrad(ch, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
     if (head_side) SIMQ_CHECK_HIP(hipEventRecord(c.ev_wdone[1], c.wstream));
     }

@@ -46,7 +46,8 @@ Layout make_layout(const simq_plan* p, int B) {
     L.up2 = take((int64_t)B * 9216 * 32 * f);
     L.aux = take(p->aux_total * f);
     L.red = take(p->red_total * (int64_t)sizeof(double));
-    L.colsum = take(kStatReplicas * 2 * 128 * sizeof(double));   // replicated scratch slots: bias-gradient column sums of the head
+    L.colsum = take(2 * kStatReplicas * 2 * 128 * sizeof(double));   // replicated scratch slots: bias-gradient column sums of the head and the unfused
+                                                                     // BatchNorm-backward sums (first half: the walk's stream, second half: the side stream's)
                                                                  // convolutions, non-fused BatchNorm-backward sums (C <= 128)
     L.defer = take(p->nbnbuf * (int64_t)sizeof(double));
     const int64_t smax = (int64_t)B * 294912 * f;   // = B*576*512 = B*2304*128 = B*9216*32 floats
