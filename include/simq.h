@@ -136,6 +136,11 @@ typedef struct simq_plan_options {
                                    * only, 2 = the fp32 kernel too (measured slower there), 0 = launch order */
     int tail_split;               /* 0.  fp32 implicit GEMM: balanced last round (K-sliced tail tiles + fix-up kernel); pays only when the forwards run
                                    * serialised; changes the fp32 summation order of the sliced tiles */
+    int early_target_after_block; /* 4.  simq_train_args.target_stream (the target net's forward of step t+1 on a stream that does not wait for step t):
+                                   * that forward additionally waits until step t's backward walk reaches residual block N (7 = layer4's second block,
+                                   * the first of the walk ... 0 = layer1's first, the last), so that it runs beside the END of that backward pass, the
+                                   * optimiser step and the weight-cache refresh -- the part of a step with the fewest matrix kernels -- instead of
+                                   * racing through the start of the backward pass.  -1 = no such wait.  Ordering only: results are bit-identical. */
 } simq_plan_options;
 void simq_plan_options_default(simq_plan_options* options);
 int simq_plan_create_opts(int num_input_channels, int num_output_channels, int precision, const simq_plan_options* options,

@@ -209,6 +209,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     const int gi = 1;   // S[gi] holds the gradient w.r.t. the current block's output
     const int i_hi = phase == 2 ? kPhaseSplitBlock - 1 : 7, i_lo = phase == 1 ? kPhaseSplitBlock : 0;
     for (int i = i_hi; i >= i_lo; --i) {   // BasicBlock.forward reversed, resnet.py:31-47
+        if (c.ev_late && i == c.late_block) SIMQ_CHECK_HIP(hipEventRecord(c.ev_late, c.stream));
         const BlockL& b = p->blocks[i];
         const Layout::Blk& o = L.blk[i];
         const Act xin = i == 0 ? c.act(L.pooled, L.p_pooled, rows * 64)
@@ -365,11 +366,12 @@ TraceLayout make_trace_layout(const simq_plan* p, int B) {
 int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                               const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                               void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
-                              hipEvent_t ev_wjoin, hipEvent_t ev_wdone0, hipEvent_t ev_wdone1, const float* x_ext) {
+                              hipEvent_t ev_wjoin, hipEvent_t ev_wdone0, hipEvent_t ev_wdone1, const float* x_ext, hipEvent_t ev_late, int late_block) {
     Ctx c{plan, batch, d_params, d_grads, nullptr, static_cast<char*>(d_workspace), make_layout(plan, batch), static_cast<hipStream_t>(stream)};
     c.wc = static_cast<char*>(const_cast<void*>(d_wcache)); c.W = make_wlayout(plan);
     c.sync = sync;
     c.x_ext = x_ext;
+    c.ev_late = ev_late; c.late_block = late_block;
     if (wstream && ev_wfork && ev_wjoin) { c.wstream = wstream; c.ev_wfork = ev_wfork; c.ev_wjoin = ev_wjoin; c.ev_wdone[0] = ev_wdone0; c.ev_wdone[1] = ev_wdone1; }
     else RC(attach_backward_side(c));
     if (d_dq) return backward_impl(c, d_dq, phase);

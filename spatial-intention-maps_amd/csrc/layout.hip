@@ -202,6 +202,7 @@ void simq_plan_options_default(simq_plan_options* o) {
     o->fuse_bn_backward_sums = 1; o->fuse_stem_backward_sums = 1;
     o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1; o->deterministic = 0;
     o->wgrad_ksplit = 0; o->fwd_overlap = 2; o->wgrad_overlap = 4; o->plane_xcd = 1; o->wgrad_xcd_group = 1; o->tail_split = 0;
+    o->early_target_after_block = 4;
 }
 
 void simq_launch_opts_default(simq_launch_opts* o) {
@@ -235,6 +236,8 @@ int simq_plan_create_opts(int cin, int cout, int precision, const simq_plan_opti
         SIMQ_REQUIRE(opt.fwd_overlap >= 0 && opt.fwd_overlap <= 2, "plan_create: fwd_overlap = %d (0, 1 or 2)", opt.fwd_overlap);
         SIMQ_REQUIRE(opt.wgrad_overlap >= 0 && opt.wgrad_overlap <= 4, "plan_create: wgrad_overlap = %d (0 .. 4)", opt.wgrad_overlap);
         SIMQ_REQUIRE(opt.wgrad_xcd_group >= 0 && opt.wgrad_xcd_group <= 2, "plan_create: wgrad_xcd_group = %d (0, 1 or 2)", opt.wgrad_xcd_group);
+        SIMQ_REQUIRE(opt.early_target_after_block >= -1 && opt.early_target_after_block <= 7, "plan_create: early_target_after_block = %d (-1 .. 7)",
+                     opt.early_target_after_block);
     }
     SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
     SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);
@@ -294,7 +297,7 @@ void simq_plan_destroy(simq_plan* plan) {
         for (hipStream_t* st : streams)
             if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
         hipEvent_t* events[] = {&s.bwd_ev[0], &s.bwd_ev[1], &s.bwd_ev[2], &s.bwd_ev[3], &s.third_ev, &s.step_ev[0], &s.step_ev[1], &s.step_ev[2],
-                                &s.step_ev[3], &s.step_ev[4], &s.step_ev[5], &s.copy_ready, &s.copy_done};
+                                &s.step_ev[3], &s.step_ev[4], &s.step_ev[5], &s.step_ev[6], &s.copy_ready, &s.copy_done};
         for (hipEvent_t* ev : events)
             if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     }

@@ -58,7 +58,8 @@ struct PlanStreams {
     hipEvent_t bwd_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t third = nullptr;                    // simq_train_step: the policy's no-grad forward beside the other two (fwd_overlap = 2)
     hipEvent_t third_ev = nullptr;
-    hipEvent_t step_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // simq_train_step: fork / join of the caller's side stream
+    hipEvent_t step_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool late_recorded = false;                     // step_ev[6] was recorded inside a step's backward walk (simq_plan_options.early_target_after_block)   // simq_train_step: fork / join of the caller's side stream
     hipStream_t copy = nullptr;                     // simq_train_step: out4 -> pinned host memory without a stream synchronisation
     hipEvent_t copy_ready = nullptr, copy_done = nullptr;
     bool copy_pending = false;
@@ -153,7 +154,9 @@ struct Ctx {
     // simq_train_step: the minibatch the caller handed over stays valid for the whole call's stream work, so the grad-mode forward
     // convolves it in place and the stem's weight gradient reads it again at the end of the backward pass -- no copy into the workspace
     // (nullptr: the forward keeps a copy in L.x for a backward pass that is a call of its own)
-    const float* x_ext = nullptr;   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
+    const float* x_ext = nullptr;
+    hipEvent_t ev_late = nullptr; int late_block = -1;   // recorded on `stream` in front of residual block `late_block` of the backward walk: the NEXT
+                                                         // step's early target forward waits for it (simq_plan_options.early_target_after_block)   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
     // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
     // inspection aid: simq_backward_traced copies the gradient tensors of the walk here as they become final (TraceLayout), nullptr otherwise
     char* trace = nullptr;
@@ -253,7 +256,8 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
 int backward_sync_side(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                        const int64_t* d_action, const float* d_q_sa, const float* d_y, float grad_scale, float* d_grads,
                        void* d_workspace, int phase, void* stream, const simq_sync* sync, hipStream_t wstream, hipEvent_t ev_wfork,
-                       hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr, const float* x_ext = nullptr);
+                       hipEvent_t ev_wjoin, hipEvent_t ev_wdone0 = nullptr, hipEvent_t ev_wdone1 = nullptr, const float* x_ext = nullptr,
+                       hipEvent_t ev_late = nullptr, int late_block = -1);
 // simq_forward_sync in train mode on the caller's minibatch in place (simq_train_step; see Ctx::x_ext)
 int forward_sync_inplace(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, float* d_bnbuf, const float* d_x,
                          float* d_q, void* d_workspace, hipStream_t stream, const simq_sync* sync);

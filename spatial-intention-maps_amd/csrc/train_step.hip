@@ -74,12 +74,13 @@ int simq_train_step(const simq_train_args* a) {
         SIMQ_REQUIRE(ps, "train_step: device index %d out of range", dev);
         if (!ps->step_ev[0]) {
             std::lock_guard<std::mutex> lk(p->mu);
-            for (int i = 0; i < 6; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->step_ev[i], hipEventDisableTiming));
+            for (int i = 0; i < 7; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->step_ev[i], hipEventDisableTiming));
         }
         ev_fork = ps->step_ev[0]; ev_join = ps->step_ev[1]; ev_wfork = ps->step_ev[2]; ev_wjoin = ps->step_ev[3];
         ev_wdone0 = ps->step_ev[4]; ev_wdone1 = ps->step_ev[5];
     }
     const int fwd_overlap = p->opt.fwd_overlap;      // simq_plan_options.fwd_overlap (2: three forwards side by side)
+    const int late_block = p->opt.early_target_after_block;
     // SyncBN option of the data-parallel form: the train-mode BatchNorms see the statistics of the global minibatch
     simq_sync sync_storage{comm_reduce_f64, a->comm, a->global_batch, a->comm ? simq_comm_world_size(a->comm) : 1};
     const simq_sync* sync = (a->comm && a->sync_bn) ? &sync_storage : nullptr;
@@ -101,6 +102,12 @@ int simq_train_step(const simq_train_args* a) {
         hipStream_t third = ps->third;
         // (target_stream: the caller ordered it behind the target forward's inputs -- no wait for this step's or the previous step's work)
         hipStream_t tstream = a->target_stream ? static_cast<hipStream_t>(a->target_stream) : side;
+        // ... except for a point of the PREVIOUS step's backward walk (simq_plan_options.early_target_after_block): started at once, this forward
+        // races through the start of that backward pass, where the dgrads and the piped weight gradients already fill the matrix cores, and
+        // is done before the walk reaches the narrow layers, the optimiser step and the weight-cache refresh, which then run alone.  Held back
+        // until the walk is in front of block 4, it covers those instead (alternating A/B on one box, tools/ab_step.py, 80 steps: fp32
+        // configs[1] 3934-3950 -> 4006-4015 tr/s, bf16 configs[2] 14 311-14 471 -> 14 567-14 765; profiles/r05_ab_early_target_delay.txt)
+        if (late_block >= 0 && a->target_stream && ps->late_recorded) SIMQ_CHECK_HIP(hipStreamWaitEvent(tstream, ps->step_ev[6], 0));
         SIMQ_CHECK_HIP(hipEventRecord(ev_fork, main));
         if (!a->target_stream) SIMQ_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         SIMQ_CHECK_HIP(hipStreamWaitEvent(third, ev_fork, 0));
@@ -162,7 +169,8 @@ int simq_train_step(const simq_train_args* a) {
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;
         return backward_sync_side(p, B, a->params, a->wcache, a->dq, a->action, a->q_sa, a->y, gscale, a->grads, a->ws_train, phase, main, sync,
-                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1, a->state);
+                                  side, ev_wfork, ev_wjoin, ev_wdone0, ev_wdone1, a->state,
+                                  (ps && late_block >= 0) ? ps->step_ev[6] : nullptr, late_block);
     };
     if (!a->comm) {
         RC(backward(0));
@@ -178,6 +186,7 @@ int simq_train_step(const simq_train_args* a) {
         RC(comm_wait(a->comm, main));
         if (a->loss_host) RC(loss_copy(p, a->out4, a->loss_host, main, false));            // (summed over the ranks)
     }
+    if (ps && late_block >= 0) ps->late_recorded = true;            // (both phases of the data-parallel form together visit every block once)
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);

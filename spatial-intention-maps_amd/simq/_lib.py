@@ -48,7 +48,7 @@ class PlanOptions(ctypes.Structure):
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
         'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
         'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'deterministic', 'bn1_mask_from_preact',
-        'wgrad_ksplit', 'fwd_overlap', 'wgrad_overlap', 'plane_xcd', 'wgrad_xcd_group', 'tail_split')]
+        'wgrad_ksplit', 'fwd_overlap', 'wgrad_overlap', 'plane_xcd', 'wgrad_xcd_group', 'tail_split', 'early_target_after_block')]
 
 
 class LaunchOpts(ctypes.Structure):

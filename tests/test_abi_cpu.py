@@ -48,7 +48,7 @@ def test_no_process_global_behaviour_switch_is_exported(L):
         assert plan.options[k] == v
     d = L.Plan(4, 2).options
     assert (d['fwd_overlap'], d['wgrad_overlap'], d['plane_xcd'], d['wgrad_ksplit'], d['wgrad_xcd_group'], d['tail_split']) == (2, 4, 1, 0, 1, 0)
-    for bad in ({'wgrad_ksplit': 3}, {'fwd_overlap': 3}, {'wgrad_overlap': 5}, {'wgrad_xcd_group': -1}):
+    for bad in ({'wgrad_ksplit': 3}, {'fwd_overlap': 3}, {'wgrad_overlap': 5}, {'wgrad_xcd_group': -1}, {'early_target_after_block': 8}):
         with pytest.raises(L.SimqError):
             L.Plan(4, 2, options=bad)
     o = L.launch_opts(tile=(96, 64), plane_xcd=0)
@@ -281,7 +281,8 @@ def test_plan_options_are_a_property_of_the_plan_and_not_of_the_environment(L, m
     assert d == {'winograd': 1, 'winograd_min_cc': 128 * 128, 'winograd_f4_forward': 1, 'winograd_f4_min_tiles': 256, 'winograd_f4_grad': 2,
                  'winograd_f4_fwd_grad_min_cc': 512 * 512, 'winograd_wgrad': 1, 'winograd_wgrad_f4': 1, 'stem_bf16': 1, 'bf16_act_grads': 1, 'keep_fp32_activations': 0,
                  'fold_eval_bn_bf16': 1, 'fuse_bn_backward_sums': 1, 'fuse_stem_backward_sums': 1, 'fuse_bn1_apply': 1, 'deterministic': 0, 'bn1_mask_from_preact': 1,
-                 'wgrad_ksplit': 0, 'fwd_overlap': 2, 'wgrad_overlap': 4, 'plane_xcd': 1, 'wgrad_xcd_group': 1, 'tail_split': 0}
+                 'wgrad_ksplit': 0, 'fwd_overlap': 2, 'wgrad_overlap': 4, 'plane_xcd': 1, 'wgrad_xcd_group': 1, 'tail_split': 0,
+                 'early_target_after_block': 4}
     p = L.Plan(5, 1, 'bf16', options={'stem_bf16': 0, 'keep_fp32_activations': 1})
     assert p.options['stem_bf16'] == 0 and p.options['keep_fp32_activations'] == 1 and p.options['winograd'] == 1
     # the Winograd weight cache exists only when the option is on: the option changes the plan, not a global

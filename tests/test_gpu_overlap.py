@@ -139,15 +139,16 @@ def test_plan_owned_streams_are_created_lazily_and_die_with_the_plan(env):
         gc.collect()
 
 
-@pytest.mark.parametrize('precision,B', [('fp32', 8), ('bf16', 16)])
-def test_early_target_forward_across_steps_is_bit_identical(env, precision, B):
+@pytest.mark.parametrize('precision,B,after_block', [('fp32', 8, 4), ('bf16', 16, 4), ('fp32', 8, -1), ('bf16', 16, 0), ('fp32', 8, 7)])
+def test_early_target_forward_across_steps_is_bit_identical(env, precision, B, after_block):
     """Round 5: the target net's forward of step t + 1 (train.py:122) is enqueued on a stream of its own that does NOT wait for step t -- it
     reads the gathered next states (gathered on the upload stream), the target net's weight cache and nothing the learner is computing --
     and runs beside step t's backward pass.  A training loop shaped like the reference's (train.py:241-269: push one transition, sample from
     the HBM ring, train(), every third step copy the policy's weights into the target net) must give the same losses, TD targets,
     parameters and BatchNorm buffers BIT FOR BIT with the early stream on and off, on deterministic plans: the ring is pushed to and
     gathered from on one stream, the early stream waits for the target net's last weight change and for the last reader of the Q-map
-    buffer it writes."""
+    buffer it writes.  `after_block` = simq_plan_options.early_target_after_block: the point of step t's backward walk that forward is held
+    back to (4 by default, -1 none, 7 / 0 the first / last residual block of the walk) -- ordering only."""
     import random
     e, c = env, env['cases']
     sl = e['sl']
@@ -157,7 +158,8 @@ def test_early_target_forward_across_steps_is_bit_identical(env, precision, B):
         keep = (sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM)
         sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM = early, early
         try:
-            policy, target = _nets(e, precision, {'deterministic': 1}, cin, cout)
+            policy, target = _nets(e, precision, {'deterministic': 1, 'early_target_after_block': after_block}, cin, cout)
+            assert policy.plan.options['early_target_after_block'] == after_block
             ring = e['simq'].DeviceReplayBuffer(64, cin)
             trs = e['synth'].make_transitions(48, cin, cout, 11, terminal_frac=0.2)
             for t in trs[:40]:
