@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 400            /* 0.4.0 */
+#define SIMQ_VERSION 401            /* 0.4.1: simq_plan_options.early_target_after_block */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
