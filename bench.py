@@ -86,7 +86,9 @@ def parse():
     ap.add_argument('--no-upload-stream', action='store_true', help='tools only: the per-batch index upload on the consuming stream (A/B)')
     ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_plan_options.fwd_overlap of every plan, A/B (2 = default: three forwards side by side)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_plan_options.plane_xcd of every plan (batched GEMM planes per XCD), A/B')
-    ap.add_argument('--early-target', type=int, default=None, choices=[0, 1], help='tools only: simq.learner.EARLY_TARGET_FORWARD (the target-net forward of a step beside the previous step), A/B')
+    ap.add_argument('--early-target', type=int, default=None, choices=[0, 1], help='tools only: StepOptions.early_target_forward of every learner (the target-net forward of a step beside the previous step), A/B')
+    ap.add_argument('--group-streams', type=int, default=1, choices=[0, 1], help='tools only: multi-net workloads (configs3): 1 = every robot group issues its step on a launch stream of its own (the groups run side by side), 0 = one after the other on one stream (rounds 1-5), A/B')
+    ap.add_argument('--group-issue', default='defer', choices=['defer', 'stagger'], help="tools only: with --group-streams 1: 'defer' = enqueue every group's step, then wait for the losses (simq.train_groups); 'stagger' = wait for each group's loss before enqueueing the next group's step")
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
     ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
@@ -298,21 +300,17 @@ def main():
     import simq
     from simq import dist as sdist, synth
     from simq._lib import MODE_TRAIN, lib, ptr, stream_ptr
-    from simq.learner import _opt_state, train_step
+    from simq.learner import StepOptions, _opt_state, learner_streams, train_step
     # A/B switches are plan options (include/simq.h simq_plan_options): the library has no process-global state to flip
     plan_opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.plan_option}
     for name in ('plane_xcd', 'fwd_overlap', 'wgrad_overlap', 'wgrad_xcd_group'):
         if getattr(args, name) is not None:
             plan_opts[name] = getattr(args, name)
-    if args.no_upload_stream:
-        import simq.learner as _sl
-        _sl.UPLOAD_STREAM = False
-    if args.early_target is not None:
-        import simq.learner as _sl
-        _sl.EARLY_TARGET_FORWARD = bool(args.early_target)
-    if args.no_overlap:
-        import simq.learner as _sl
-        _sl.OVERLAP_TARGET_FORWARD = False
+    # ... and the host side has none either (round 6): how a learner issues its step is a StepOptions value handed to every train_step call,
+    # where a ring runs its copies and gathers is an option of the ring
+    step_opts = StepOptions(overlap_target_forward=not args.no_overlap,
+                            early_target_forward=True if args.early_target is None else bool(args.early_target))
+    ring_upload_stream = not args.no_upload_stream
     if lib.build_flags != 0:
         sys.exit('bench.py: %s is the ablation build (simq_build_flags = %d); the benchmark runs the product library only' % (lib.path, lib.build_flags))
 
@@ -396,14 +394,20 @@ def main():
             policy.train()
             target.eval()
             # synthetic replay, resident in HBM before the timed region (same content on every rank), filled in chunks
-            ring = simq.DeviceReplayBuffer(replay_items, cin, device=dev)
+            ring = simq.DeviceReplayBuffer(replay_items, cin, device=dev, upload_stream=ring_upload_stream)
             for c0 in range(0, replay_items, 1000):
                 trs = synth.make_transitions(min(1000, replay_items - c0), cin, cout, 5 + 31 * gi + c0, terminal_frac=0.1)
                 ring.push_many(np.stack([t[0] for t in trs]), [t[1] for t in trs], [t[2] for t in trs],
                                np.stack([t[3] if t[3] is not None else np.zeros_like(t[0]) for t in trs]),
                                [t[3] is None for t in trs])
-            groups.append(dict(policy=policy, target=target, ring=ring, opt=_opt_state(policy, None), drawn=None, cin=cin, cout=cout))
+            # several robot groups (train.py:255-257): independent networks -- every group issues its step on a launch stream of its own
+            # (simq.learner.LearnerStreams) and the groups' steps run side by side on the device
+            own = len(nets) > 1 and bool(args.group_streams) and pg is None
+            ls = learner_streams(policy, own_launch_stream=own)
+            groups.append(dict(policy=policy, target=target, ring=ring, opt=_opt_state(policy, None), drawn=None, cin=cin, cout=cout,
+                               opts=step_opts, ls=ls))
         random.seed(1234)                   # every rank draws the same global minibatches, then takes its slice
+        torch.cuda.synchronize(dev)         # (the rings were filled on the current stream; the groups' launch streams start behind that)
 
         def draw(g):
             idx = g['ring'].sample_indices(gB)
@@ -418,14 +422,26 @@ def main():
             # step are enqueued while this step still runs (a full stream synchronisation per step left the device idle for 70-90 us
             # at every step boundary: tools/idle_gaps.sh).  Picks, their order per group and the work per step are unchanged; the
             # timed region ends with a device synchronisation.
-            info = None
+            # Several groups with launch streams of their own: every group's draw + step is enqueued on ITS stream; 'defer' waits for the
+            # losses only after all groups' steps are enqueued (what simq.train_groups does), 'stagger' group by group.
+            info, pending = None, []
             for g in groups:
-                batch = g['drawn'] if g['drawn'] is not None else draw(g)
-                info = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
-                                  opt_state=g['opt'], process_group=pg, global_batch=gB, sync=True, comm=comm)
-                if log_exposed:
-                    exposed_log.append(comm.last_wait_ms())
-                g['drawn'] = draw(g)
+                launch = g['ls'].launch
+                with torch.cuda.stream(launch if launch is not None else torch.cuda.current_stream(dev)):
+                    batch = g['drawn'] if g['drawn'] is not None else draw(g)
+                    defer = launch is not None and args.group_issue == 'defer'
+                    info = train_step(g['policy'], g['target'], batch, GAMMA, B, LR, MOMENTUM, WD, CLIP, use_double_dqn=True,
+                                      opt_state=g['opt'], process_group=pg, global_batch=gB, sync='defer' if defer else True, comm=comm,
+                                      options=g['opts'])
+                    if log_exposed:
+                        exposed_log.append(comm.last_wait_ms())
+                    g['drawn'] = draw(g)
+                if defer:
+                    pending.append(info)
+                elif not np.isfinite(info['loss']):
+                    sys.exit('bench: non-finite loss %r' % (info,))
+            for pnd in pending:
+                info = pnd.result()
                 if not np.isfinite(info['loss']):
                     sys.exit('bench: non-finite loss %r' % (info,))
             return info
@@ -526,10 +542,12 @@ def main():
         `steps` more steps with every stream overlap of the step off (target-net forward, the policy's no-grad forward and the weight
         gradients all on the launch stream), so that every bracket times one kernel ALONE on the device: a roofline fraction is a
         property of the kernel, and two kernels sharing the CUs each look slower than either is."""
-        import simq.learner as slearner
         from simq._lib import Plan
-        keep = slearner.OVERLAP_TARGET_FORWARD
-        slearner.OVERLAP_TARGET_FORWARD = False
+        # (the learners' own step options for these steps: everything on ONE launch stream -- no side / early stream, no per-group stream)
+        kept = [(g, g['opts'], g['ls'].launch) for g in groups_of_step]
+        for g in groups_of_step:
+            g['opts'] = StepOptions(overlap_target_forward=False, early_target_forward=False)
+            g['ls'].launch = None
         # a SECOND plan per net -- same network, same buffer layout, fwd_overlap = wgrad_overlap = 0 -- serves these steps: what a plan
         # schedules is a property of the plan (simq_plan_options), nothing process-global is flipped
         swapped = []
@@ -548,8 +566,9 @@ def main():
         dt_inst = time.perf_counter() - t1
         out = (ctypes.c_double * 12)()
         lib.call('simq_profile_stop', out, 3)
-        slearner.OVERLAP_TARGET_FORWARD = keep
         torch.cuda.synchronize(dev)
+        for g, o, launch in kept:
+            g['opts'], g['ls'].launch = o, launch
         for net, plan in swapped:
             net.plan = plan
         dom = {'launches': out[0], 'ms': out[1], 'flops': out[2], 'bytes': out[3]}      # kind 0: the dominant kernel of the precision
@@ -660,6 +679,7 @@ def main():
                                       wl['per_gpu'], ' and net' if n_nets > 1 else '', args.replay),
                        'workload_key': wl['name'], 'nets': n_nets, 'global_batch': gB, 'per_gpu_batch': wl['per_gpu'],
                        'transitions_per_step': gB * n_nets, 'parallelism': 'dp%d' % world,
+                       'concurrent_groups': (args.group_issue if (n_nets > 1 and args.group_streams and world == 1) else None),
                        'gradient_transport': transport, 'simq_comm_world_size': comm_world, 'backend': args.backend if world > 1 else None,
                        'flop_per_transition': flop_m2, 'flop_per_transition_fwd_bwd_only': flop_m1,
                        'last_loss': info['loss'], 'last_td_error': info['td_error']},

@@ -207,7 +207,10 @@ int simq_forward(const simq_plan* plan, int mode, int batch, const float* d_para
 /* ---- autograd backward of FCN.forward (loss.backward(), train.py:132) ----------------------------
  * d_workspace must be the one used by the matching simq_forward(mode=TRAIN) call.
  * d_dq     [batch][Cout][96][96] upstream gradient (dense).
- * d_grads  flat gradient buffer (param layout); OVERWRITTEN.                                  */
+ * d_grads  flat gradient buffer (param layout); OVERWRITTEN.
+ * The matching forward must be a simq_forward / simq_forward_sync call: simq_train_step convolves the caller's minibatch IN PLACE and leaves
+ * no copy of it in the workspace, so a backward entry point called on its own behind a simq_train_step would differentiate the first
+ * convolution against whatever an earlier simq_forward left there (the Python host refuses that: FCN._train_workspace_for_backward). */
 int simq_backward(const simq_plan* plan, int batch, const float* d_params, const void* d_wcache, const float* d_dq,
                   float* d_grads, void* d_workspace, void* stream);
 
@@ -329,7 +332,8 @@ typedef struct simq_train_args {
                                   * train.py:122 is then enqueued there WITHOUT waiting for `stream` -- it depends on nothing this step or the
                                   * previous one computes, so it may run beside the previous step's backward pass and SGD (the host enqueues
                                   * step t+1 while step t still runs, see loss_host) -- and `stream` waits for it where the values are
-                                  * gathered.  Needs side_stream (the three-forward form, fwd_overlap = 2); results are bit-identical. */
+                                  * gathered.  Needs the three-forward form (side_stream, fwd_overlap = 2, double DQN, non-final next states, no SyncBN):
+                                  * an ERROR otherwise (round 6; it used to be ignored silently).  Results are bit-identical. */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
 /* blocks until the loss_host copy of the last simq_train_step of `plan` on the current device has landed.  The step's streams must belong

@@ -58,8 +58,11 @@ struct PlanStreams {
     hipEvent_t bwd_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t third = nullptr;                    // simq_train_step: the policy's no-grad forward beside the other two (fwd_overlap = 2)
     hipEvent_t third_ev = nullptr;
+    // simq_train_step: [0] / [1] fork / join of the caller's side stream around the forwards, [2] / [3] of the weight gradients beside the
+    // backward walk, [4] / [5] "the side stream is done with gradient temporaries set 0 / 1", [6] the walk is in front of residual block
+    // simq_plan_options.early_target_after_block (the NEXT step's early target forward waits for it)
     hipEvent_t step_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool late_recorded = false;                     // step_ev[6] was recorded inside a step's backward walk (simq_plan_options.early_target_after_block)   // simq_train_step: fork / join of the caller's side stream
+    bool late_recorded = false;                     // step_ev[6] was recorded inside the LAST step's backward walk
     hipStream_t copy = nullptr;                     // simq_train_step: out4 -> pinned host memory without a stream synchronisation
     hipEvent_t copy_ready = nullptr, copy_done = nullptr;
     bool copy_pending = false;
@@ -150,16 +153,16 @@ struct Ctx {
     // backward inside simq_train_step: the weight gradients run on this stream beside the dgrads of the same layer (fork / join events)
     hipStream_t wstream = nullptr;
     hipEvent_t ev_wfork = nullptr, ev_wjoin = nullptr;
-    hipEvent_t ev_wdone[2] = {nullptr, nullptr};
+    hipEvent_t ev_wdone[2] = {nullptr, nullptr};   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
     // simq_train_step: the minibatch the caller handed over stays valid for the whole call's stream work, so the grad-mode forward
     // convolves it in place and the stem's weight gradient reads it again at the end of the backward pass -- no copy into the workspace
     // (nullptr: the forward keeps a copy in L.x for a backward pass that is a call of its own)
     const float* x_ext = nullptr;
     hipEvent_t ev_late = nullptr; int late_block = -1;   // recorded on `stream` in front of residual block `late_block` of the backward walk: the NEXT
-                                                         // step's early target forward waits for it (simq_plan_options.early_target_after_block)   // "the side stream is done with temporaries set 0 / 1" (weight gradients one block behind)
-    // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
+                                                         // step's early target forward waits for it (simq_plan_options.early_target_after_block)
     // inspection aid: simq_backward_traced copies the gradient tensors of the walk here as they become final (TraceLayout), nullptr otherwise
     char* trace = nullptr;
+    // rows a train-mode BatchNorm normalises over: the local rows, or their share of the global minibatch
     double bn_rows(int64_t rows) const { return sync ? (double)rows / (double)B * (double)sync->global_batch : (double)rows; }
     int sync_reduce(double* buf, int64_t count) const { return sync ? sync->reduce(sync->user, buf, count, stream) : 0; }
     float* f(int64_t off) const { return reinterpret_cast<float*>(ws + off); }

@@ -93,6 +93,10 @@ int simq_train_step(const simq_train_args* a) {
     // (fp32 configs[1] +4.7 ... +5.9 %, bf16 configs[2] +2.6 %).  Not under SyncBN (its collectives order the streams); the plain
     // data-parallel step has no collective before its backward pass and takes it.
     const bool three = fwd_overlap == 2 && side && Nn > 0 && a->use_double_dqn && !sync;
+    // target_stream is an ordering promise of the caller (it made that stream wait for the target forward's inputs INSTEAD of this step's
+    // launch stream): only the three-forward form keeps it -- any other form would silently run that forward behind the launch stream
+    SIMQ_REQUIRE(!a->target_stream || three, "train_step: target_stream needs the three-forward form (fwd_overlap = 2, a side stream, double DQN, "
+                 "non-final next states, no SyncBN)");
     if (three) {
         if (!ps->third) {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -186,7 +190,9 @@ int simq_train_step(const simq_train_args* a) {
         RC(comm_wait(a->comm, main));
         if (a->loss_host) RC(loss_copy(p, a->out4, a->loss_host, main, false));            // (summed over the ranks)
     }
-    if (ps && late_block >= 0) ps->late_recorded = true;            // (both phases of the data-parallel form together visit every block once)
+    // (both phases of the data-parallel form together visit every block once.)  A step that recorded no such event -- early_target_after_block < 0 --
+    // clears the mark: a later step must not wait on an event of some unrelated earlier walk
+    if (ps) ps->late_recorded = late_block >= 0;
     RC(launch_clip_sgd(a->params, a->grads, a->momentum_buf, p->nparams, a->max_norm, a->lr, a->momentum, a->weight_decay,
                        a->first_step, a->opt_scratch, a->total_norm, main));                                         // train.py:133-135
     return simq_weights_prepare(p, a->params, a->wcache, main);

@@ -19,6 +19,9 @@ _LAZY = {
     'Transition': ('.learner', 'Transition'),
     'train': ('.learner', 'train'),
     'train_step': ('.learner', 'train_step'),
+    'train_groups': ('.learner', 'train_groups'),
+    'StepOptions': ('.learner', 'StepOptions'),
+    'learner_streams': ('.learner', 'learner_streams'),
     'train_step_dataparallel': ('.learner', 'train_step_dataparallel'),
     'train_intention': ('.learner', 'train_intention'),
     'train_intention_step': ('.learner', 'train_intention_step'),

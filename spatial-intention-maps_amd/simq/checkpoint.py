@@ -87,6 +87,9 @@ def to_host_ring(buf):
     host = _learner.ReplayBuffer(buf.capacity)
     host.position = buf.position
     cache = {}
+    # the ring's slots are written by asynchronous H2D copies on the upload stream (or on whichever stream pushed): the D2H copies below run
+    # on the current stream and are ordered behind none of them -- wait until every push so far has landed
+    buf.sync_ring()
 
     def fetch(obs):
         if obs is None:

@@ -95,6 +95,9 @@ class FCN(torch.nn.Module):
                 self.fc_bias = torch.nn.Parameter(torch.zeros(1000, device=self.device_))
         self._ws = {}
         self._train_generation = 0
+        self._train_input_inplace = False   # the last grad-mode forward was simq_train_step's (minibatch convolved in place, no copy in the workspace)
+        self._last_step_event = self._last_step_stream = None   # the learner's last step on this net (as policy OR target), see _order_behind_last_step
+        self.step_options = None            # simq.learner.StepOptions of the learner this net is the policy of (None: the defaults)
         self.wcache = torch.empty(max(int(lib.c.simq_wcache_bytes(self.plan.handle)), 16), dtype=torch.uint8, device=self.device_)
         self.weights_dirty = True      # set whenever flat_params changes; the next forward refreshes the weight cache
         self._weights_stamp = 0
@@ -133,8 +136,27 @@ class FCN(torch.nn.Module):
             sd[key] = t
         self.load_state_dict(sd)
 
+    # ------------------------------------------------------------------ ordering against the learner's own stream
+    def _mark_step(self, stream):
+        """A learner step that reads or writes this net's buffers was just enqueued on `stream`."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._last_step_event, self._last_step_stream = ev, stream
+
+    def _order_behind_last_step(self):
+        """A learner may issue its steps on a launch stream of its own (simq.learner.LearnerStreams: concurrent robot groups).  Whatever
+        touches this net next on ANOTHER stream -- a forward of DQNPolicy.step, state_dict() for a checkpoint, the target sync of
+        train.py:267-269 -- is ordered behind that step here, so that the caller keeps the reference's single-stream semantics without a join
+        at the end of every loop pass.  Same stream: stream order already holds, nothing is enqueued."""
+        ev = self._last_step_event
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device_)
+            if cur != self._last_step_stream:
+                cur.wait_event(ev)
+
     def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
         """Reference-format state dict (138 keys, OIHW conv weights)."""
+        self._order_behind_last_step()
         out = OrderedDict() if destination is None else destination
         pre = prefix + self.key_prefix
         by_name = {name: (off, shape, kind) for name, off, shape, kind in self.plan.tensors}
@@ -165,6 +187,7 @@ class FCN(torch.nn.Module):
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts reference-format dicts with or without the DataParallel 'module.' prefix."""
+        self._order_behind_last_step()
         sd = {}
         for k, v in state_dict.items():
             sd[k[len(arch.PREFIX):] if k.startswith(arch.PREFIX) else k] = v
@@ -204,6 +227,8 @@ class FCN(torch.nn.Module):
 
     def copy_state_from(self, other):
         """target.load_state_dict(policy.state_dict()) (train.py:214,269) without the OIHW round trip."""
+        self._order_behind_last_step()
+        other._order_behind_last_step()
         with torch.no_grad():
             self.flat_params.copy_(other.flat_params)
             self.bn_buffers.copy_(other.bn_buffers)
@@ -228,6 +253,7 @@ class FCN(torch.nn.Module):
 
     def _ensure_weights(self):
         if self.weights_dirty:
+            self._order_behind_last_step()
             lib.call('simq_weights_prepare', self.plan.handle, ptr(self.flat_params), ptr(self.wcache), stream_ptr(self.device_))
             self.weights_dirty = False
             self._weights_stamp += 1
@@ -246,8 +272,10 @@ class FCN(torch.nn.Module):
                             % (W, W, self.num_input_channels, tuple(x_nhwc.shape)))
         if B < 1:
             raise SimqError('simq.FCN: empty batch')
+        self._order_behind_last_step()
         if mode == MODE_TRAIN:
             self._train_generation += 1
+            self._train_input_inplace = False      # this forward keeps its copy of the input in the workspace
         ws = self._workspace('train' if mode == MODE_TRAIN else 'tmp', B)
         q = torch.empty((B, self.num_output_channels, W, W), dtype=torch.float32, device=self.device_)
         self._ensure_weights()
@@ -262,12 +290,21 @@ class FCN(torch.nn.Module):
                 self.num_batches_tracked[k] += 1
         return q
 
-    def _backward_raw(self, dq, batch, phase=0):
-        """dq [B,Cout,96,96] -> flat gradient buffer (overwritten).  phase 1 / 2: the two halves of the walk
-        (head + layer4, then the rest) for callers that overlap the gradient all-reduce with phase 2."""
+    def _train_workspace_for_backward(self):
         ws = self._ws.get('train')
         if ws is None:
             raise SimqError('simq.FCN: backward without a grad-mode forward')
+        if self._train_input_inplace:
+            raise SimqError('simq.FCN: the last grad-mode forward ran inside simq.train (simq_train_step convolves the minibatch in place and keeps no '
+                            'copy in the workspace): a backward pass called on its own would differentiate the first convolution against a stale '
+                            'input -- run a grad-mode forward first')
+        self._order_behind_last_step()
+        return ws
+
+    def _backward_raw(self, dq, batch, phase=0):
+        """dq [B,Cout,96,96] -> flat gradient buffer (overwritten).  phase 1 / 2: the two halves of the walk
+        (head + layer4, then the rest) for callers that overlap the gradient all-reduce with phase 2."""
+        ws = self._train_workspace_for_backward()
         lib.call('simq_backward_phase', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq),
                  ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_))
         return self.flat_grads
@@ -275,9 +312,7 @@ class FCN(torch.nn.Module):
     def _backward_onehot(self, action, q_sa, y, grad_scale, batch, phase=0, sync=None):
         """Backward of the TD loss from its one-hot upstream gradient dQ[b][action[b]] = clamp(q_sa - y, -1, 1) * grad_scale
         (no dense dQ map); same phases as _backward_raw.  sync: as in _forward_raw."""
-        ws = self._ws.get('train')
-        if ws is None:
-            raise SimqError('simq.FCN: backward without a grad-mode forward')
+        ws = self._train_workspace_for_backward()
         if sync is not None:
             lib.call('simq_backward_sync', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), None, ptr(action), ptr(q_sa),
                      ptr(y), float(grad_scale), ptr(self.flat_grads), ptr(ws), phase, stream_ptr(self.device_), sync.bind(ws))
@@ -360,9 +395,7 @@ class FCN(torch.nn.Module):
         kept (teacher-forced tests).  Returns (flat gradient buffer, lookup) with lookup('layer<l>.<b>.<g_out|dy2|dz|dyd|da1|dy1|g_in>') ->
         [B,24,24,C] tensor in the plan's storage type."""
         import ctypes
-        ws = self._ws.get('train')
-        if ws is None:
-            raise SimqError('simq.FCN: backward without a grad-mode forward')
+        ws = self._train_workspace_for_backward()
         trace = torch.empty(int(lib.c.simq_backward_trace_bytes(self.plan.handle, batch)), dtype=torch.uint8, device=self.device_)
         lib.call('simq_backward_traced', self.plan.handle, batch, ptr(self.flat_params), ptr(self.wcache), ptr(dq.contiguous()), ptr(self.flat_grads),
                  ptr(ws), ptr(trace), stream_ptr(self.device_))

@@ -68,7 +68,7 @@ class DeviceBatch:
         self.next_state, self.nonfinal_pos, self.non_final_mask = next_state, nonfinal_pos, non_final_mask
         # set when the tensors were produced on a stream of their own (DeviceReplayBuffer.gather): the event behind their last writer.  The
         # consuming stream has already been made to wait for it; a stream that wants to start EARLIER (the target-net forward of the next
-        # step beside the running step, EARLY_TARGET_FORWARD) waits for it itself.
+        # step beside the running step, StepOptions.early_target_forward) waits for it itself.
         self.ready_event = ready_event
 
 
@@ -106,15 +106,41 @@ def _upload_stream(device):
     if up is None:
         up = _UPLOAD_STREAMS[device] = torch.cuda.Stream(device)
     return up
-UPLOAD_STREAM = True    # (A-B: False = the upload on the consuming stream, rounds 1-3)
-GATHER_ON_UPLOAD_STREAM = True   # DeviceReplayBuffer.gather: the HBM gathers behind the index copy on the upload stream (A-B: False = on the consuming stream)
-EARLY_TARGET_FORWARD = True      # train_step: the target-net forward of a step on a stream of its own that does not wait for the previous step (A-B)
-_EARLY_STREAMS = {}
 
 
-def _upload_packed(device, arrays, slots=4):
+def sync_uploads(device):
+    """Host-side wait for everything issued on `device`'s upload stream (ring pushes, index uploads, gathers): what a reader of the ring
+    on ANOTHER stream (a checkpoint's D2H copies, `np.asarray(record.state)`) needs before it may look at a slot."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    up = _UPLOAD_STREAMS.get(device)
+    if up is not None:
+        up.synchronize()
+
+
+class StepOptions(namedtuple('StepOptions', ('fused', 'overlap_target_forward', 'early_target_forward'))):
+    """How ONE learner issues its TD step -- a property of the call (train_step(options=...)) or of the learner (FCN.step_options, which
+    the drop-in train() reads), never of the process (round 6: the module-level A/B switches of rounds 3-5 are gone, as the library's
+    simq_tune_* setters went in round 5).
+      fused                    the step is ONE library call (simq_train_step) instead of ~15 ctypes calls issued from Python
+      overlap_target_forward   the (independent) target-net forward on the learner's side stream (False: everything on the launch stream --
+                               bench.py's per-kernel roofline pass, where concurrent kernels would share the device)
+      early_target_forward     the target-net forward of a step on a stream of its own that does not wait for the previous step (needs a
+                               minibatch gathered on the upload stream: DeviceBatch.ready_event)"""
+    __slots__ = ()
+
+    def __new__(cls, fused=True, overlap_target_forward=True, early_target_forward=True):
+        return super().__new__(cls, bool(fused), bool(overlap_target_forward), bool(early_target_forward))
+
+
+DEFAULT_STEP_OPTIONS = StepOptions()
+
+
+def _upload_packed(device, arrays, slots=4, upload_stream=True):
     """numpy arrays -> device tensors of the same dtypes through ONE asynchronous H2D copy out of a small ring of pinned host buffers
-    (a buffer is reused only after the copy that last read it has finished).  Non-CUDA devices: plain copies."""
+    (a buffer is reused only after the copy that last read it has finished).  Non-CUDA devices: plain copies.
+    upload_stream=False: the copy on the consuming stream (A/B of rounds 1-3's form)."""
     if device.type != 'cuda':
         return tuple(torch.from_numpy(a).to(device) for a in arrays)
     offs, total = [], 0
@@ -134,7 +160,7 @@ def _upload_packed(device, arrays, slots=4):
         if a.size:
             host[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
     main = torch.cuda.current_stream(device)
-    if UPLOAD_STREAM:
+    if upload_stream:
         # the copy depends on nothing the device is doing: on its own stream it runs while the previous step's kernels still do, and the
         # consuming stream only waits for its event (on the consuming stream it queued behind the whole previous step and the device idled
         # for the copy's latency at every step boundary).  The buffer comes from the upload stream's pool and is handed to the consumer.
@@ -175,9 +201,8 @@ class _DeviceObs:
         return tuple(self.store.shape[1:])
 
     def __array__(self, dtype=None, copy=None):
-        up = _UPLOAD_STREAMS.get(self.store.device) if self.store.is_cuda else None     # (keys carry the device index, as tensor.device does)
-        if up is not None:
-            up.synchronize()               # (ring slots are written on the upload stream: _PinnedStaging.upload)
+        if self.store.is_cuda:
+            sync_uploads(self.store.device)    # (ring slots are written on the upload stream: _PinnedStaging.upload)
         a = self.store[self.slot].cpu().numpy()
         return a if dtype is None else a.astype(dtype, copy=False)
 
@@ -196,8 +221,9 @@ class _PinnedStaging:
     uploaded with asynchronous H2D copies, so `push` returns as soon as the ndarray is staged and the environment can keep stepping
     while the copy (and the learner's kernels) run.  A slot is reused only after the copy that last read it has finished."""
 
-    def __init__(self, item_shape, device, slots=32):
+    def __init__(self, item_shape, device, slots=32, on_upload_stream=True):
         self.device = device
+        self.on_upload_stream = bool(on_upload_stream)
         self.enabled = device.type == 'cuda' and torch.cuda.is_available()
         self.slots = slots
         self.pos = 0
@@ -214,10 +240,10 @@ class _PinnedStaging:
         if self.events[i] is not None:
             self.events[i].synchronize()                       # the copy that last used this slot (32 pushes ago) is long done
         self.buf[i].copy_(torch.as_tensor(arr))                # host memcpy into pinned memory
-        # asynchronous H2D -- on the UPLOAD stream when the gathers run there (GATHER_ON_UPLOAD_STREAM): the ring is then written and read on
-        # one stream (stream order is the only ordering needed) and neither a push nor the next gather queues behind the learner's running
-        # step on the consuming stream.  Otherwise on the current stream, with an event for a gather elsewhere to wait on.
-        up = _upload_stream(self.device) if (UPLOAD_STREAM and GATHER_ON_UPLOAD_STREAM) else None
+        # asynchronous H2D -- on the UPLOAD stream when the gathers run there (the ring's `upload_stream` option): the ring is then written
+        # and read on one stream (stream order is the only ordering needed) and neither a push nor the next gather queues behind the
+        # learner's running step on the consuming stream.  Otherwise on the current stream, with an event for a gather elsewhere to wait on.
+        up = _upload_stream(self.device) if self.on_upload_stream else None
         if up is not None:
             with torch.cuda.stream(up):
                 dst.copy_(self.buf[i], non_blocking=True)
@@ -241,16 +267,37 @@ class DeviceReplayBuffer:
     `random.sample(self.buffer, B)` makes under the same seed (golden: tests/golden/sampler.npz).
     """
 
-    def __init__(self, capacity, num_input_channels, device=None):
+    def __init__(self, capacity, num_input_channels, device=None, upload_stream=True):
         self.capacity = int(capacity)
         self.C = int(num_input_channels)
         self.device = torch.device('cuda' if device is None else device)
         self.item = W * W * self.C
         self.states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
         self.next_states = torch.empty((self.capacity, W, W, self.C), dtype=torch.float32, device=self.device)
-        self._staging = _PinnedStaging((W, W, self.C), self.device)
+        self._set_upload_mode(upload_stream)
+        self._staging = _PinnedStaging((W, W, self.C), self.device, on_upload_stream=self.ring_on_upload_stream)
         self.buffer = []
         self.position = 0
+
+    def _set_upload_mode(self, upload_stream):
+        """upload_stream: True (default) -- pushes, the per-batch index upload and the gathers all run on the device's upload stream, beside
+        whatever the learner has queued on the consuming stream (a gathered DeviceBatch then carries `ready_event`); 'index' -- only the
+        index upload does, the gathers run on the consuming stream (round 4's form); False -- everything on the consuming stream.  A
+        property of THIS ring (round 6; it was a module-level switch)."""
+        if upload_stream not in (True, False, 'index'):
+            raise SimqError("DeviceReplayBuffer: upload_stream must be True, False or 'index' (got %r)" % (upload_stream,))
+        self.upload_stream = upload_stream
+        self.ring_on_upload_stream = upload_stream is True and self.device.type == 'cuda'
+
+    def sync_ring(self):
+        """Host-side wait until every push so far has landed in HBM (the H2D copies run on the upload stream / the pushing stream):
+        for readers that look at ring slots outside stream order -- checkpoint.to_host_ring, np.asarray(record.state)."""
+        if self.device.type != 'cuda':
+            return
+        sync_uploads(self.device)
+        for ev in (getattr(self, '_bulk_event', None), getattr(getattr(self, '_staging', None), 'last_event', None)):
+            if ev is not None:
+                ev.synchronize()
 
     def push(self, state, action, reward, next_state):
         if len(self.buffer) < self.capacity:
@@ -304,12 +351,12 @@ class DeviceReplayBuffer:
         index, nindex, action, reward, pos = _upload_packed(dev, (
             np.asarray([int(r.state) for r in recs], np.int64), np.asarray(nf, np.int64),
             np.asarray([r.action for r in recs], np.int64), np.asarray([r.reward for r in recs], np.float32),
-            np.asarray([i for i, m in enumerate(mask) if m], np.int32)))
-        up = _upload_stream(dev) if (UPLOAD_STREAM and GATHER_ON_UPLOAD_STREAM) else None
+            np.asarray([i for i, m in enumerate(mask) if m], np.int32)), upload_stream=self.upload_stream is not False)
+        up = _upload_stream(dev) if self.ring_on_upload_stream else None
         if up is not None:
             # the two gathers on the upload stream, behind the index copy they read: they depend on the ring and the indices only, not on the
             # step that is still running on the consuming stream -- the minibatch is ready while that step runs, and a consumer that can start
-            # early (EARLY_TARGET_FORWARD) finds it there.  The ring's last push (a copy on the consuming stream) is waited for first.
+            # early (StepOptions.early_target_forward) finds it there.  The ring's last push (a copy on the consuming stream) is waited for first.
             main = torch.cuda.current_stream(dev)
             ev_push = getattr(self._staging, 'last_event', None) if hasattr(self, '_staging') else None
             if getattr(self, '_bulk_event', None) is not None:
@@ -348,7 +395,7 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
     pool_slots: observations the pool can hold (default capacity + 25 %, enough when pushes alias as the collector's do;
     independent state / next_state arrays need up to 2 * capacity)."""
 
-    def __init__(self, capacity, num_input_channels, device=None, pool_slots=None):
+    def __init__(self, capacity, num_input_channels, device=None, pool_slots=None, upload_stream=True):
         self.capacity = int(capacity)
         self.C = int(num_input_channels)
         self.device = torch.device('cuda' if device is None else device)
@@ -356,7 +403,8 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
         n = int(pool_slots) if pool_slots is not None else self.capacity + max(256, self.capacity // 4)
         self.pool = torch.empty((n, W, W, self.C), dtype=torch.float32, device=self.device)
         self.states = self.next_states = self.pool          # both gathers of the base class read the one pool
-        self._staging = _PinnedStaging((W, W, self.C), self.device)
+        self._set_upload_mode(upload_stream)
+        self._staging = _PinnedStaging((W, W, self.C), self.device, on_upload_stream=self.ring_on_upload_stream)
         self._free = list(range(n - 1, -1, -1))
         self._ref = [0] * n
         self._recent = {}                                   # id(ndarray) -> (slot, ndarray): observations uploaded lately
@@ -413,17 +461,47 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
         return len(self._ref) - len(self._free)
 
 
-_SIDE_STREAMS = {}
-FUSED_LIBRARY_STEP = True       # single-process steps go through ONE library call (simq_train_step) instead of ~15 ctypes calls
-OVERLAP_TARGET_FORWARD = True   # run the (independent) target-net forward on a side stream (module attribute: bench.py's serial roofline pass and --no-overlap turn it off; never read from the environment)
-                                 # for its per-kernel HIP-event pass, where concurrent kernels would share the GPU
+class LearnerStreams:
+    """The streams ONE learner (a policy net with its target net, optimiser state and ring: one robot group of train.py:180-195, or an
+    intention net) issues its steps on.  Round 6: they belong to the learner, not to the device -- the robot groups of train.py:255-257 and
+    the intention nets of train.py:259-261 are independent networks, and with a launch stream (and side / early streams) each their steps run
+    side by side on the device instead of one after the other (tests/test_gpu_overlap.py: bit-identical per net to the sequential order).
+      launch   None: the step is issued on the caller's current stream (a single learner).  A stream: the step is issued THERE; it is
+               ordered behind the caller's stream at the moment of the call, and whoever touches the nets next on another stream is
+               ordered behind the step (FCN._order_behind_last_step) -- no join at the end of the loop pass is needed.
+      side     target-net forward / weight gradients beside the launch stream (StepOptions.overlap_target_forward)
+      early    the target-net forward that does not wait for the previous step (StepOptions.early_target_forward)"""
+    __slots__ = ('device', 'launch', '_side', '_early')
+
+    def __init__(self, device, own_launch_stream=False):
+        self.device = torch.device(device)
+        self.launch = torch.cuda.Stream(self.device) if own_launch_stream else None
+        self._side = self._early = None
+
+    @property
+    def side(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
+    @property
+    def early(self):
+        if self._early is None:
+            self._early = torch.cuda.Stream(self.device)
+        return self._early
 
 
-def _side_stream(dev):
-    key = (dev.type, dev.index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
+def learner_streams(policy_net, own_launch_stream=None):
+    """The LearnerStreams of `policy_net` (created on first use).  own_launch_stream=True gives the learner a launch stream of its own
+    (train_groups / bench.py's multi-net workloads do that for every robot group); None leaves it as it is."""
+    ls = getattr(policy_net, '_learner_streams', None)
+    if ls is None:
+        ls = policy_net._learner_streams = LearnerStreams(policy_net.device_, bool(own_launch_stream))
+    elif own_launch_stream and ls.launch is None:
+        ls.launch = torch.cuda.Stream(ls.device)
+    elif own_launch_stream is False:
+        ls.launch = None
+    return ls
 
 
 class _OptState:
@@ -479,10 +557,33 @@ def _hyper(optimizer):
     return float(g['lr']), float(g.get('momentum', 0.0)), float(g.get('weight_decay', 0.0))
 
 
+class PendingStep:
+    """What train_step(sync='defer') returns: the step is enqueued, `result()` waits for the copy of its four loss sums (issued right behind
+    the TD / Huber launch, long before backward + SGD finish) and returns train()'s dict.  Lets a caller enqueue the steps of several
+    learners before it waits for any of them (train_groups)."""
+    __slots__ = ('_plan', '_host', '_gB', '_info')
+
+    def __init__(self, plan, host, gB):
+        self._plan, self._host, self._gB, self._info = plan, host, gB, None
+
+    def result(self):
+        if self._info is None:
+            lib.call('simq_train_loss_wait', self._plan.handle)
+            o = self._host.tolist()                                             # train.py:138-139 (.item())
+            self._info = {'td_error': o[1] / self._gB, 'loss': o[0] / self._gB}
+        return self._info
+
+
 def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, momentum, weight_decay,
                grad_norm_clipping, use_double_dqn=True, opt_state=None, process_group=None, global_batch=None,
-               sync=True, comm=None, sync_bn=False, global_nonfinal=None):
+               sync=True, comm=None, sync_bn=False, global_nonfinal=None, options=None):
     """One TD step (train.py:108-141) entirely on the device, over the nets' flat buffers.
+
+    options: a StepOptions (default: policy_net.step_options, else DEFAULT_STEP_OPTIONS) -- how this learner issues the step.
+    The step is issued on the learner's launch stream when it has one (learner_streams(policy_net, own_launch_stream=True):
+    concurrent robot groups), otherwise on the caller's current stream.
+    sync: True -- returns {'td_error','loss'} floats (as the reference's .item() calls do); False -- the device tensor [sum_huber, sum_td];
+    'defer' (single-process fused step only) -- a PendingStep whose result() gives the dict.
 
     Data-parallel: pass `global_batch` and either `comm` (simq.dist.Comm: libsimq's RCCL communicator -- the step stays ONE
     library call, the gradient buckets travel on the communicator's stream) or `process_group` (torch.distributed
@@ -493,13 +594,26 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     GLOBAL minibatch (44 small all-reduces per step), which makes the N-rank step the single-device step on the whole minibatch
     instead of DataParallel's per-replica BatchNorm; `global_nonfinal` = number of non-final next states in the WHOLE minibatch
     (every rank draws the same minibatch, so each knows it) sizes the double-DQN forward's global statistics.
-    Returns {'td_error','loss'} floats (sync=True, as the reference's .item() calls do) or the
-    device tensor [sum_huber, sum_td] (sync=False).
     """
     if not isinstance(policy_net, FCN) or not isinstance(target_net, FCN):
         raise SimqError('simq.train needs simq.FCN networks (got %s / %s); there is no torch fallback'
                         % (type(policy_net).__name__, type(target_net).__name__))
     dev = policy_net.device_
+    opts = options if options is not None else (getattr(policy_net, 'step_options', None) or DEFAULT_STEP_OPTIONS)
+    ls = learner_streams(policy_net)
+    caller = torch.cuda.current_stream(dev)
+    if ls.launch is not None and ls.launch != caller:
+        # this learner's own launch stream: ordered behind the caller's stream as of now (the minibatch, a target sync ... were issued
+        # there), then everything below runs with it as the current stream
+        ls.launch.wait_stream(caller)
+        if isinstance(batch, DeviceBatch):
+            for t in (batch.state, batch.action, batch.reward, batch.next_state, batch.nonfinal_pos):
+                t.record_stream(ls.launch)
+        with torch.cuda.stream(ls.launch):
+            return train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, momentum, weight_decay, grad_norm_clipping,
+                              use_double_dqn, opt_state, process_group, global_batch, sync, comm, sync_bn, global_nonfinal, opts)
+    policy_net._order_behind_last_step()
+    target_net._order_behind_last_step()
     parallel = process_group is not None or comm is not None
     if sync_bn and not parallel:
         raise SimqError('train_step: sync_bn needs a process group or a communicator (one process has nothing to synchronise)')
@@ -520,9 +634,11 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     policy_net._workspace('tmp', B)
     target_net._workspace('tmp', B)
 
-    if (process_group is None or comm is not None) and FUSED_LIBRARY_STEP:
+    if (process_group is None or comm is not None) and opts.fused:
         return _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                                 use_double_dqn, st_opt, sync, comm, sync_bn, global_nonfinal)
+                                 use_double_dqn, st_opt, sync, comm, sync_bn, global_nonfinal, opts, ls)
+    if sync == 'defer':
+        raise SimqError("train_step: sync='defer' needs the fused single-process step")
     bn_sync = sdist.SyncBN(gB, group=process_group, comm=comm) if sync_bn else None
     bn_sync_nf = sdist.SyncBN(global_nonfinal, group=process_group, comm=comm) if (sync_bn and global_nonfinal) else None
     reduce_async = (lambda t: sdist.allreduce_async(t, process_group)) if comm is None else comm.all_reduce
@@ -533,7 +649,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     # on a side stream, forked behind the train-mode forward so that it overlaps the policy's next-state forward (both work
     # on the ~29 non-final samples and fill each other's partially filled rounds of CUs).
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else main
+    side = ls.side if opts.overlap_target_forward else main
     Nn = b.next_state.shape[0]
     nsv = torch.empty(B, dtype=torch.float32, device=dev)
     vals = torch.empty(max(Nn, 1), dtype=torch.float32, device=dev)
@@ -592,6 +708,8 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     st_opt.initialised = True
     policy_net.weights_dirty = True      # parameters moved: the next forward refreshes the derived weight cache
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q}
+    policy_net._mark_step(main)
+    target_net._mark_step(main)
     if not sync:
         return out4
     o = out4.tolist()                                                       # train.py:138-139 (.item() host sync)
@@ -599,7 +717,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
 
 
 def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, momentum, weight_decay, grad_norm_clipping,
-                      use_double_dqn, st_opt, sync, comm=None, sync_bn=False, global_nonfinal=None):
+                      use_double_dqn, st_opt, sync, comm=None, sync_bn=False, global_nonfinal=None, opts=DEFAULT_STEP_OPTIONS, ls=None):
     """train_step through simq_train_step: the same launches in the same order, sequenced inside the library (with `comm`: the
     data-parallel form, gradient buckets all-reduced on the communicator's stream between the backward phases and the SGD)."""
     dev = policy_net.device_
@@ -618,7 +736,9 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     vec = torch.empty(5 * B + 4, **f32)
     nsv, vals, q_sa, y, td, out4 = vec[:B], vec[B:2 * B], vec[2 * B:3 * B], vec[3 * B:4 * B], vec[4 * B:5 * B], vec[5 * B:]
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev) if OVERLAP_TARGET_FORWARD else None
+    if ls is None:
+        ls = learner_streams(policy_net)
+    side = ls.side if opts.overlap_target_forward else None
     a = TrainArgs()
     a.struct_bytes = ctypes.sizeof(TrainArgs)
     a.plan = policy_net.plan.handle
@@ -631,10 +751,11 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     a.use_double_dqn, a.first_step = int(bool(use_double_dqn)), 0 if st_opt.initialised else 1
     a.gamma, a.lr, a.momentum, a.weight_decay = float(discount_factor), lr, momentum, weight_decay
     a.max_norm = float(grad_norm_clipping) if grad_norm_clipping is not None else 0.0
+    t_ws = target_net._workspace('tmp', Nn)
     tensors = dict(params=policy_net.flat_params, wcache=policy_net.wcache, bnbuf=policy_net.bn_buffers, grads=policy_net.flat_grads,
                    momentum_buf=st_opt.momentum, ws_train=policy_net._workspace('train', B), ws_tmp=policy_net._workspace('tmp', Nn),
                    t_params=target_net.flat_params, t_wcache=target_net.wcache, t_bnbuf=target_net.bn_buffers,
-                   t_ws=target_net._workspace('tmp', Nn), state=b.state, next_state=next_state, action=b.action, reward=b.reward,
+                   t_ws=t_ws, state=b.state, next_state=next_state, action=b.action, reward=b.reward,
                    nonfinal_pos=nonfinal_pos, q=q, q_next=q_next, q_tgt=q_tgt, dq=dq, nsv=nsv, vals=vals, best=best, q_sa=q_sa,
                    y=y, td=td, out4=out4, opt_scratch=st_opt.scratch, total_norm=st_opt.total_norm)
     # The target net's forward over the next states (train.py:122) reads nothing this step or the previous one computes.  When the
@@ -644,17 +765,23 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     # kernels on the same operands: bit-identical.  The Q-map buffers alternate between two per net (a fresh torch.empty could be a block
     # the previous step's queued kernels still use: the allocator only knows the consuming stream).
     early = None
-    if (EARLY_TARGET_FORWARD and side is not None and use_double_dqn and Nn_real and not a.sync_bn and getattr(b, 'ready_event', None) is not None
+    if (opts.early_target_forward and side is not None and use_double_dqn and Nn_real and not a.sync_bn and getattr(b, 'ready_event', None) is not None
             and policy_net.plan.options.get('fwd_overlap', 2) == 2):
-        early = _EARLY_STREAMS.get(dev)
-        if early is None:
-            early = _EARLY_STREAMS[dev] = torch.cuda.Stream(dev)
+        early = ls.early
         slot = policy_net.__dict__.setdefault('_qtgt_slot', 0)
         bufs = policy_net.__dict__.setdefault('_qtgt_bufs', [None, None])
         frees = policy_net.__dict__.setdefault('_qtgt_free', [None, None])
+        fresh = False
         if bufs[slot] is None or bufs[slot].numel() < Nn * n:
             bufs[slot] = torch.empty(Nn * n, **f32)
             frees[slot] = None
+            fresh = True
+        # a buffer the early stream writes that was allocated just now (the Q-map slot, or the target net's forward workspace after it grew)
+        # comes from the launch stream's pool and may be a block kernels still queued THERE are using: the early stream waits for them once
+        # (in steady state nothing is allocated and the early stream is ordered behind its inputs only)
+        if fresh or policy_net.__dict__.get('_early_tws') != t_ws.data_ptr():
+            early.wait_stream(main)
+            policy_net._early_tws = t_ws.data_ptr()
         q_tgt = bufs[slot][:Nn * n].view(Nn, n)
         tensors['q_tgt'] = q_tgt
         early.wait_event(b.ready_event)
@@ -694,11 +821,15 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     policy_net._weights_stamp += 1
     st_opt.initialised = True
     policy_net._last = {'q_sa': q_sa, 'y': y, 'td': td, 'q': q.view(B, policy_net.num_output_channels, W, W)}
+    # simq_train_step convolved the minibatch in place: the workspace holds no copy of it, so a backward entry point called on its own
+    # before the next grad-mode forward would differentiate the stem against a stale input (FCN._backward_* refuse)
+    policy_net._train_input_inplace = True
+    policy_net._mark_step(main)
+    target_net._mark_step(main)
     if not sync:
         return out4
-    lib.call('simq_train_loss_wait', policy_net.plan.handle)
-    o = loss_host.tolist()                                                  # train.py:138-139 (.item())
-    return {'td_error': o[1] / gB, 'loss': o[0] / gB}
+    pending = PendingStep(policy_net.plan, loss_host, gB)
+    return pending if sync == 'defer' else pending.result()
 
 
 def train_step_dataparallel(policy_net, target_net, global_batch, discount_factor, lr, momentum, weight_decay, grad_norm_clipping,
@@ -785,15 +916,12 @@ def train(cfg, policy_net, target_net, optimizer, batch, transform_fn, discount_
     st = _opt_state(policy_net, optimizer)
     info = train_step(policy_net, target_net, batch, discount_factor, cfg.batch_size, lr, momentum, weight_decay,
                       cfg.grad_norm_clipping, use_double_dqn=cfg.use_double_dqn, opt_state=st)
-    if momentum != 0:   # expose the (aliased) momentum buffers exactly where torch.optim.SGD keeps them
-        params = [getattr(policy_net, pname) for _, pname, _ in policy_net._param_names]
-        for p, v in zip(params, st.views):
-            optimizer.state[p]['momentum_buffer'] = v
+    _expose_momentum(policy_net, optimizer, st, momentum)
     return info
 
 
 def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state=None, process_group=None,
-                         global_batch=None, sync=True, comm=None):
+                         global_batch=None, sync=True, comm=None, _on_launch_stream=False):
     """One intention-map supervision step (train.py:143-158) on the device: split the ground-truth map (last state
     channel) off the replay states, train-mode forward of FCN(C-1, 1), BCE-with-logits + its gradient in one kernel,
     backward, momentum SGD (no clipping on this path).  Returns {'loss_intention': float} or, with sync=False, the
@@ -804,6 +932,16 @@ def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_s
     if intention_net.num_output_channels != 1:
         raise SimqError('train_intention: the intention net has one output channel (policies.py:93)')
     dev = intention_net.device_
+    ls = learner_streams(intention_net)
+    caller = torch.cuda.current_stream(dev)
+    if ls.launch is not None and ls.launch != caller and not _on_launch_stream:
+        # the intention net's own launch stream (train_intention_groups: beside the robot groups' TD steps)
+        ls.launch.wait_stream(caller)
+        if isinstance(batch, DeviceBatch):
+            batch.state.record_stream(ls.launch)
+        with torch.cuda.stream(ls.launch):
+            return train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state, process_group, global_batch, sync, comm, True)
+    intention_net._order_behind_last_step()
     if isinstance(batch, DeviceBatch):
         full = batch.state
     else:
@@ -844,9 +982,26 @@ def train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_s
     st_opt.initialised = True
     intention_net.weights_dirty = True
     intention_net._last = {'logits': logits, 'target': target}
+    intention_net._mark_step(torch.cuda.current_stream(dev))
     if not sync:
         return loss_sum
+    if sync == 'defer':
+        return _PendingIntention(loss_sum, gB, torch.cuda.current_stream(dev))
     return {'loss_intention': float(loss_sum.item()) / (gB * W * W)}                                  # train.py:155-156
+
+
+class _PendingIntention:
+    """train_intention_step(sync='defer'): the summed loss is read back on the stream that produced it when result() is called."""
+    __slots__ = ('_loss', '_gB', '_stream', '_info')
+
+    def __init__(self, loss_sum, gB, stream):
+        self._loss, self._gB, self._stream, self._info = loss_sum, gB, stream, None
+
+    def result(self):
+        if self._info is None:
+            with torch.cuda.stream(self._stream):
+                self._info = {'loss_intention': float(self._loss.item()) / (self._gB * W * W)}       # train.py:155-156
+        return self._info
 
 
 def train_intention(intention_net, optimizer, batch, transform_fn):
@@ -854,8 +1009,56 @@ def train_intention(intention_net, optimizer, batch, transform_fn):
     lr, momentum, weight_decay = _hyper(optimizer)
     st = _opt_state(intention_net, optimizer)
     info = train_intention_step(intention_net, batch, lr, momentum, weight_decay, opt_state=st)
-    if momentum != 0:
-        params = [getattr(intention_net, pname) for _, pname, _ in intention_net._param_names]
+    _expose_momentum(intention_net, optimizer, st, momentum)
+    return info
+
+
+def _expose_momentum(net, optimizer, st, momentum):
+    if momentum != 0:   # the (aliased) momentum buffers exactly where torch.optim.SGD keeps them
+        params = [getattr(net, pname) for _, pname, _ in net._param_names]
         for p, v in zip(params, st.views):
             optimizer.state[p]['momentum_buffer'] = v
-    return info
+
+
+def train_groups(cfg, policy_nets, target_nets, optimizers, batches, transform_fn, discount_factors,
+                 intention_nets=None, optimizers_intention=None, concurrent=True):
+    """One pass of the reference's training loop body over ALL robot groups (train.py:253-261) as one call:
+
+        for i in range(num_robot_groups):
+            train_info = train(cfg, policy_nets[i], target_nets[i], optimizers[i], batches[i], transform_fn, discount_factors[i])
+            if cfg.use_predicted_intention:
+                train_info.update(train_intention(intention_nets[i], optimizers_intention[i], batches[i], transform_fn))
+
+    The groups' Q-networks and the intention networks are independent networks with their own parameters, optimiser state, workspaces
+    and plans.  With concurrent=True every learner issues its step on a launch stream of its own (LearnerStreams) and the host enqueues ALL
+    steps before it waits for the first loss, so the steps run side by side on the device: one net's HBM-bound phases (Winograd transforms,
+    BatchNorm passes, optimiser step) under the other's matrix-core phases.  Per net the same kernels run on the same operands in the same
+    order: every net's results are what the sequential loop gives (bit-identical on deterministic plans, tests/test_gpu_overlap.py).
+    No join at the end: anything that touches one of the nets later on another stream is ordered behind its step
+    (FCN._order_behind_last_step).
+    batches[i]: what replay_buffers[i].sample(cfg.batch_size) returned (a DeviceBatch or the reference's Transition-of-tuples), or None to
+    skip the group.  Returns the list of train_info dicts (None for skipped groups)."""
+    n = len(policy_nets)
+    pend, pend_int = [None] * n, [None] * n
+    for i in range(n):
+        if batches[i] is None:
+            continue
+        lr, momentum, weight_decay = _hyper(optimizers[i])
+        st = _opt_state(policy_nets[i], optimizers[i])
+        learner_streams(policy_nets[i], own_launch_stream=True if concurrent else None)
+        pend[i] = train_step(policy_nets[i], target_nets[i], batches[i], discount_factors[i], cfg.batch_size, lr, momentum, weight_decay,
+                             cfg.grad_norm_clipping, use_double_dqn=cfg.use_double_dqn, opt_state=st, sync='defer')
+        _expose_momentum(policy_nets[i], optimizers[i], st, momentum)
+        if intention_nets is not None:
+            lr, momentum, weight_decay = _hyper(optimizers_intention[i])
+            st = _opt_state(intention_nets[i], optimizers_intention[i])
+            learner_streams(intention_nets[i], own_launch_stream=True if concurrent else None)
+            pend_int[i] = train_intention_step(intention_nets[i], batches[i], lr, momentum, weight_decay, opt_state=st, sync='defer')
+            _expose_momentum(intention_nets[i], optimizers_intention[i], st, momentum)
+    infos = [None] * n
+    for i in range(n):
+        if pend[i] is not None:
+            infos[i] = dict(pend[i].result())
+            if pend_int[i] is not None:
+                infos[i].update(pend_int[i].result())
+    return infos

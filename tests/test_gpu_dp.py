@@ -90,7 +90,7 @@ def _worker(rank, world, port, backend, use_comm, spec, out_dir, sync_bn=False):
         pg = None if use_comm else dist.group.WORLD
         if use_comm:
             # through the HBM ring, as bench.py --gpus N draws its shards: the gathers run on the upload stream and the target net's
-            # forward on the early stream (learner.EARLY_TARGET_FORWARD) beside the communicator's collectives
+            # forward on the early stream (StepOptions.early_target_forward) beside the communicator's collectives
             ring = simq.DeviceReplayBuffer(max(64, gB), cin, device=dev)
             for t in trs:
                 ring.push(*t)

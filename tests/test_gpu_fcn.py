@@ -541,13 +541,8 @@ def test_library_fused_step_equals_composed_step(simq_mod, double_dqn):
     res = []
     for fused in (True, False):
         policy, target = make_net(simq_mod, cin, cout, 61, True), make_net(simq_mod, cin, cout, 62, False)
-        old = sl.FUSED_LIBRARY_STEP
-        sl.FUSED_LIBRARY_STEP = fused
-        try:
-            infos = [sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
-                                   use_double_dqn=double_dqn) for _ in range(2)]
-        finally:
-            sl.FUSED_LIBRARY_STEP = old
+        infos = [sl.train_step(policy, target, batch, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                               use_double_dqn=double_dqn, options=sl.StepOptions(fused=fused)) for _ in range(2)]
         res.append((infos, policy._last['q_sa'].clone(), policy._last['y'].clone(), policy.flat_params.clone(),
                     policy.bn_buffers.clone(), dict(policy.num_batches_tracked)))
     (ia, qa, ya, pa, ba, na), (ib, qb, yb, pb, bb, nb) = res

@@ -188,15 +188,32 @@ def test_ragged_and_degenerate_batches(simq_mod):
 _FP32_FAMILIES_B32 = ('gemm_f32_batched', 'winograd_f4', 'winograd_f2', 'winograd_f4_wgrad', 'stem_conv_f32')
 
 
-def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
+@pytest.mark.parametrize('through_ring', [False, True], ids=['host_batch', 'hbm_ring_early_stream'])
+def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir, through_ring):
     """BASELINE configs[1] at its own size: two consecutive simq.train calls on the seeded B=32 batch against
     tests/golden/train_c4o2_b32.npz (written by oracle/gen_golden.py after a bit-exact match of the oracle with the
-    imported reference train.train; fp64 gradient summary = per-tensor L2 norm + 16 sampled elements)."""
+    imported reference train.train; fp64 gradient summary = per-tensor L2 norm + 16 sampled elements).
+    through_ring (round 6): the SCHEDULE bench.py times -- the same 32 transitions pushed into a DeviceReplayBuffer and gathered on the
+    upload stream (DeviceBatch.ready_event), so that the second call's target-net forward runs on the early stream beside the first call's
+    backward pass and SGD (no host synchronisation between the two calls: the post-step-1 state the fp64 oracle starts from is cloned
+    ON the launch stream).  A host batch (the other case) has no ready_event and never takes that path."""
     from oracle import learner as olearner
     from simq import arch
     name, cin, cout, B, wseed, dseed = cases.TRAIN_CASES_FULL[0]
     g = np.load('%s/%s.npz' % (golden_dir, name))
     cfg, batch = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed)
+    ring = None
+    if through_ring:
+        ring = simq_mod.DeviceReplayBuffer(64, cin)
+        for t in zip(batch.state, batch.action, batch.reward, batch.next_state):
+            ring.push(*t)
+
+    def draw():
+        if ring is None:
+            return batch
+        b = ring.gather(list(range(B)))
+        assert b.ready_event is not None
+        return b
     policy = simq_mod.FCN(cin, cout)
     target = simq_mod.FCN(cin, cout)
     policy.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, wseed)))
@@ -205,23 +222,36 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
     target.eval()
     opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
     from simq import _lib
+    snap = simq_mod.FCN(cin, cout)           # (receives the post-step-1 state; built here: its initialisation copies from pageable memory and would stall the stream between the calls)
+    torch.cuda.synchronize()
     _lib.lib.call('simq_launch_counts_reset')
-    info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    info1 = simq_mod.train(cfg, policy, target, opt, draw(), olearner.apply_transform, cases.GAMMA)
     ran = _lib.launch_counts()
+    # what the checks of the first call read, cloned in stream order (no host synchronisation: the second call is enqueued while the first
+    # one's backward pass still runs, as in bench.py's loop) ...
+    last1 = {k: policy._last[k].clone() for k in ('q_sa', 'y')}
+    tn1, grads1 = policy._simq_opt_state.total_norm.clone(), policy.flat_grads.clone()
+    snap.flat_params.copy_(policy.flat_params)
+    snap.bn_buffers.copy_(policy.bn_buffers)
+    snap.num_batches_tracked = type(policy.num_batches_tracked)(policy.num_batches_tracked)
+    # ... and the second call right behind it
+    info2 = simq_mod.train(cfg, policy, target, opt, draw(), olearner.apply_transform, cases.GAMMA)
+    last2 = {k: policy._last[k].clone() for k in ('q_sa', 'y')}
+    assert ('_qtgt_bufs' in policy.__dict__) == through_ring          # the early stream (two alternating Q-map buffers) was taken only through the ring
     # the kernels bench.py times at this size are the ones compared here: Winograd planes through the exact-fp32 batched GEMM,
     # the image-tile 1x1 / strided convolutions, the fp32 stem; nothing of the bf16 families
     missing = [f for f in _FP32_FAMILIES_B32 if ran.get(f, 0) == 0]
     assert not missing and not [f for f in ran if 'bf16' in f or f.endswith('16')], (missing, ran)
     rel1 = lambda a, b: abs(a - b) / abs(b)
     assert rel1(info1['loss'], float(g['loss'][0])) < 1e-4 and rel1(info1['td_error'], float(g['td_error'][0])) < 1e-4
-    q_sa, y = policy._last['q_sa'].cpu().double().numpy(), policy._last['y'].cpu().double().numpy()
+    q_sa, y = last1['q_sa'].cpu().double().numpy(), last1['y'].cpu().double().numpy()
     assert np.abs(q_sa - g['q_sa']).max() <= 1e-4 * np.abs(g['q_sa']).max()
     assert np.abs(y - g['y']).max() <= 1e-4 * np.abs(g['y']).max()
     # gradient (clipped in place) against the fp64 summary: total norm, per-tensor norms, sampled elements
-    tn = float(policy._simq_opt_state.total_norm.item())
+    tn = float(tn1.item())
     assert rel1(tn, float(g['total_norm64'])) < 5e-2
     coef = min(1.0, cases.CLIP / (tn + 1e-6))
-    gflat = policy.flat_grads.detach().cpu().double() / coef
+    gflat = grads1.detach().cpu().double() / coef
     keys = [str(k) for k in g['grad_keys']]
     got = {}
     for (pname, _, kind), (off, n, shape) in zip(policy._param_names, policy._grad_views):
@@ -237,11 +267,10 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir):
         if g['grad64'][i][0] > 1e-3 * float(g['total_norm64']):          # tensors that carry gradient mass
             assert abs(mine[0] - g['grad64'][i][0]) <= 5e-2 * g['grad64'][i][0], k
     assert (num / den) ** 0.5 <= 5e-2, 'sampled-gradient rel-L2 error %.3g (reference fp32 itself: %.3g)' % ((num / den) ** 0.5, float(g['ref_fp32_grad_relerr']))
-    sd1, sd_target = step2_oracle.snapshot(policy), step2_oracle.snapshot(target)
-    info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    sd1, sd_target = step2_oracle.snapshot(snap), step2_oracle.snapshot(target)
     # the second call per transition at 1e-4 against the fp64 oracle run from the HIP path's own post-step-1 state
     # (tests/step2_oracle.py); against the golden trajectory -- chaotic on these synthetic problems -- only a sanity bound
-    step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)
+    step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, last2['q_sa'].cpu().numpy(), last2['y'].cpu().numpy(), info2)
     assert rel1(info2['loss'], float(g['loss'][1])) < 0.1 and rel1(info2['td_error'], float(g['td_error'][1])) < 0.1
     sd = policy.state_dict()
     assert all(int(sd[k]) == 4 for k in sd if k.endswith('num_batches_tracked'))

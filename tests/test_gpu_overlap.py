@@ -139,7 +139,8 @@ def test_plan_owned_streams_are_created_lazily_and_die_with_the_plan(env):
         gc.collect()
 
 
-@pytest.mark.parametrize('precision,B,after_block', [('fp32', 8, 4), ('bf16', 16, 4), ('fp32', 8, -1), ('bf16', 16, 0), ('fp32', 8, 7)])
+@pytest.mark.parametrize('precision,B,after_block', [('fp32', 8, 4), ('bf16', 16, 4), ('fp32', 8, -1), ('bf16', 16, 0), ('fp32', 8, 7),
+                                                     ('fp32', 32, 4), ('bf16', 128, 4)])
 def test_early_target_forward_across_steps_is_bit_identical(env, precision, B, after_block):
     """Round 5: the target net's forward of step t + 1 (train.py:122) is enqueued on a stream of its own that does NOT wait for step t -- it
     reads the gathered next states (gathered on the upload stream), the target net's weight cache and nothing the learner is computing --
@@ -148,36 +149,38 @@ def test_early_target_forward_across_steps_is_bit_identical(env, precision, B, a
     parameters and BatchNorm buffers BIT FOR BIT with the early stream on and off, on deterministic plans: the ring is pushed to and
     gathered from on one stream, the early stream waits for the target net's last weight change and for the last reader of the Q-map
     buffer it writes.  `after_block` = simq_plan_options.early_target_after_block: the point of step t's backward walk that forward is held
-    back to (4 by default, -1 none, 7 / 0 the first / last residual block of the walk) -- ordering only."""
+    back to (4 by default, -1 none, 7 / 0 the first / last residual block of the walk) -- ordering only.
+    Round 6: ('fp32', 32, 4) and ('bf16', 128, 4) are the two schedules bench.py TIMES (configs[1] / configs[2]: ring-gathered minibatches of
+    32 / 128, early stream on, block 4) -- a buffer-reuse race would depend on size and timing, so it is looked for at those sizes; and the
+    switches are a StepOptions value of the call + an option of the ring, no longer module globals."""
     import random
     e, c = env, env['cases']
     sl = e['sl']
     cin, cout = 5, 2
 
+    n0 = max(40, B + B // 4)                                                 # transitions in the ring before the first draw
+    trs = e['synth'].make_transitions(n0 + 8, cin, cout, 11, terminal_frac=0.2)
+
     def loop(early):
-        keep = (sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM)
-        sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM = early, early
-        try:
-            policy, target = _nets(e, precision, {'deterministic': 1, 'early_target_after_block': after_block}, cin, cout)
-            assert policy.plan.options['early_target_after_block'] == after_block
-            ring = e['simq'].DeviceReplayBuffer(64, cin)
-            trs = e['synth'].make_transitions(48, cin, cout, 11, terminal_frac=0.2)
-            for t in trs[:40]:
-                ring.push(*t)
-            random.seed(5)
-            out = []
-            for step in range(6):
-                ring.push(*trs[40 + step])                                   # the collector's hand-off (train.py:244)
-                batch = ring.gather(ring.sample_indices(B))
-                assert (getattr(batch, 'ready_event', None) is not None) == early
-                info = sl.train_step(policy, target, batch, c.GAMMA, B, c.LR, c.MOMENTUM, c.WEIGHT_DECAY, c.CLIP, use_double_dqn=True)
-                out.append((info['loss'], info['td_error'], policy._last['y'].clone(), policy._last['q_sa'].clone()))
-                if step % 3 == 2:
-                    target.copy_state_from(policy)                           # train.py:267-269
-            torch.cuda.synchronize()
-            return out, policy.flat_params.clone(), policy.bn_buffers.clone(), target.flat_params.clone()
-        finally:
-            sl.EARLY_TARGET_FORWARD, sl.GATHER_ON_UPLOAD_STREAM = keep
+        policy, target = _nets(e, precision, {'deterministic': 1, 'early_target_after_block': after_block}, cin, cout)
+        assert policy.plan.options['early_target_after_block'] == after_block
+        ring = e['simq'].DeviceReplayBuffer(max(64, 2 * B), cin, upload_stream=early)
+        for t in trs[:n0]:
+            ring.push(*t)
+        random.seed(5)
+        out = []
+        for step in range(6):
+            ring.push(*trs[n0 + step])                                       # the collector's hand-off (train.py:244)
+            batch = ring.gather(ring.sample_indices(B))
+            assert (getattr(batch, 'ready_event', None) is not None) == early
+            info = sl.train_step(policy, target, batch, c.GAMMA, B, c.LR, c.MOMENTUM, c.WEIGHT_DECAY, c.CLIP, use_double_dqn=True,
+                                 options=sl.StepOptions(early_target_forward=early))
+            assert ('_qtgt_bufs' in policy.__dict__) == early                # (the early stream's two alternating Q-map buffers exist only then)
+            out.append((info['loss'], info['td_error'], policy._last['y'].clone(), policy._last['q_sa'].clone()))
+            if step % 3 == 2:
+                target.copy_state_from(policy)                               # train.py:267-269
+        torch.cuda.synchronize()
+        return out, policy.flat_params.clone(), policy.bn_buffers.clone(), target.flat_params.clone()
     ref, p0, bn0, t0 = loop(False)
     got, p1, bn1, t1 = loop(True)
     for s, (a, b) in enumerate(zip(ref, got)):
@@ -185,3 +188,114 @@ def test_early_target_forward_across_steps_is_bit_identical(env, precision, B, a
         assert torch.equal(a[2], b[2]), 'step %d: TD targets differ (the target-net forward read stale next states or weights)' % s
         assert torch.equal(a[3], b[3]), 'step %d: q_sa differs' % s
     assert torch.equal(p0, p1) and torch.equal(bn0, bn1) and torch.equal(t0, t1)
+
+
+def _group_nets(e, precision, seeds):
+    """Two robot groups as train.py:180-195 builds them for lifting_2_pushing_2 (policies.py:35-42: Cout 2 and 1) + their rings."""
+    groups = []
+    for gi, cout in enumerate((2, 1)):
+        cin = 5
+        policy = e['simq'].FCN(cin, cout, precision=precision, options={'deterministic': 1})
+        target = e['simq'].FCN(cin, cout, precision=precision, options={'deterministic': 1})
+        policy.load_state_dict(e['ofcn'].state_from_numpy(e['synth'].make_state_dict(cin, cout, seeds[0] + gi)))
+        target.load_state_dict(e['ofcn'].state_from_numpy(e['synth'].make_state_dict(cin, cout, seeds[1] + gi)))
+        policy.train(); target.eval()
+        ring = e['simq'].DeviceReplayBuffer(96, cin)
+        for t in e['synth'].make_transitions(72, cin, cout, 31 + gi, terminal_frac=0.15):
+            ring.push(*t)
+        opt = torch.optim.SGD(policy.parameters(), lr=e['cases'].LR, momentum=e['cases'].MOMENTUM, weight_decay=e['cases'].WEIGHT_DECAY)
+        groups.append(dict(policy=policy, target=target, ring=ring, opt=opt, cout=cout))
+    return groups
+
+
+@pytest.mark.parametrize('precision,B', [('fp32', 16), ('bf16', 32)])
+def test_concurrent_robot_groups_equal_the_sequential_loop_bit_for_bit(env, precision, B):
+    """Round 6 (train.py:253-261): the robot groups' Q-networks -- and the intention networks -- are independent, so simq.train_groups gives
+    every learner a launch stream (+ side / early streams) of its own and enqueues all steps before it waits for a loss; the groups' steps
+    then run side by side on the device.  Per net the same kernels run on the same operands in the same order, so on deterministic plans
+    every net's losses, TD targets, parameters, momentum and BatchNorm buffers over a sample / train / target-sync loop must equal the
+    reference's sequential loop (simq.train group after group on one stream) BIT FOR BIT -- including a DQNPolicy-style forward on the
+    caller's stream right behind the pass (ordered behind the learner's own stream by FCN._order_behind_last_step, no join in the loop)
+    and a target sync (train.py:267-269) issued from the caller's stream while the groups' streams may still be running."""
+    import random
+    import types
+    e, c = env, env['cases']
+    sl = e['sl']
+    cfg = types.SimpleNamespace(batch_size=B, use_double_dqn=True, grad_norm_clipping=c.CLIP)
+    probe = torch.from_numpy(e['synth'].make_states(2, 5, 91)[0][None]).cuda()
+
+    def loop(concurrent):
+        groups = _group_nets(e, precision, (3, 40))
+        random.seed(17)
+        log = []
+        for step in range(5):
+            batches = [g['ring'].sample(B) for g in groups]                                        # train.py:256
+            if concurrent:
+                infos = sl.train_groups(cfg, [g['policy'] for g in groups], [g['target'] for g in groups], [g['opt'] for g in groups],
+                                        batches, None, [0.85, 0.85])
+                assert all(sl.learner_streams(g['policy']).launch is not None for g in groups)
+            else:
+                infos = [sl.train(cfg, g['policy'], g['target'], g['opt'], b, None, 0.85) for g, b in zip(groups, batches)]
+            for g, info in zip(groups, infos):
+                # policy.step's forward (policies.py:57-66, eval mode) on the CALLER's stream, right behind the pass
+                g['policy'].eval()
+                q = g['policy'].forward_nhwc(probe)
+                g['policy'].train()
+                log.append((info['loss'], info['td_error'], g['policy']._last['y'].clone(), g['policy']._last['q_sa'].clone(), q.clone()))
+            if step % 2 == 1:
+                for g in groups:
+                    g['target'].load_state_dict(g['policy'].state_dict())                        # train.py:267-269
+        torch.cuda.synchronize()
+        fin = [(g['policy'].flat_params.clone(), g['policy'].bn_buffers.clone(), g['policy']._simq_opt_state.momentum.clone(),
+                g['target'].flat_params.clone(), dict(g['policy'].num_batches_tracked)) for g in groups]
+        return log, fin
+    ref_log, ref_fin = loop(False)
+    got_log, got_fin = loop(True)
+    assert all(abs(a[0]) < 1e6 for a in ref_log)
+    for i, (a, b) in enumerate(zip(ref_log, got_log)):
+        assert a[0] == b[0] and a[1] == b[1], 'pass %d group %d: loss / td error differ: %r vs %r' % (i // 2, i % 2, a[:2], b[:2])
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), 'pass %d group %d: TD targets / q_sa differ' % (i // 2, i % 2)
+        assert torch.equal(a[4], b[4]), 'pass %d group %d: the forward on the caller stream saw other parameters' % (i // 2, i % 2)
+    for gi, (a, b) in enumerate(zip(ref_fin, got_fin)):
+        assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4], 'group %d: final state differs' % gi
+
+
+def test_concurrent_groups_with_intention_nets_equal_the_sequential_loop(env):
+    """train.py:259-261 beside :255-257: the intention nets' supervision steps on launch streams of their own next to the robot groups' TD
+    steps (simq.train_groups(intention_nets=...)): same losses and parameters as train() + train_intention() group after group."""
+    import random
+    import types
+    e, c = env, env['cases']
+    sl = e['sl']
+    B = 8
+    cfg = types.SimpleNamespace(batch_size=B, use_double_dqn=True, grad_norm_clipping=c.CLIP)
+
+    def loop(concurrent):
+        groups = _group_nets(e, 'fp32', (5, 60))
+        inets, iopts = [], []
+        for gi in range(2):
+            net = e['simq'].FCN(4, 1, options={'deterministic': 1})
+            net.load_state_dict(e['ofcn'].state_from_numpy(e['synth'].make_state_dict(4, 1, 70 + gi)))
+            net.train()
+            inets.append(net)
+            iopts.append(torch.optim.SGD(net.parameters(), lr=c.LR, momentum=c.MOMENTUM, weight_decay=c.WEIGHT_DECAY))
+        random.seed(23)
+        log = []
+        for step in range(3):
+            batches = [g['ring'].sample(B) for g in groups]
+            if concurrent:
+                infos = sl.train_groups(cfg, [g['policy'] for g in groups], [g['target'] for g in groups], [g['opt'] for g in groups],
+                                        batches, None, [0.85, 0.85], intention_nets=inets, optimizers_intention=iopts)
+            else:
+                infos = []
+                for g, b, net, opt in zip(groups, batches, inets, iopts):
+                    info = sl.train(cfg, g['policy'], g['target'], g['opt'], b, None, 0.85)                  # train.py:257
+                    info.update(sl.train_intention(net, opt, b, None))                                        # train.py:259-261
+                    infos.append(info)
+            log += [(i['loss'], i['td_error'], i['loss_intention']) for i in infos]
+        torch.cuda.synchronize()
+        return log, [n.flat_params.clone() for n in inets] + [g['policy'].flat_params.clone() for g in groups]
+    ref_log, ref_p = loop(False)
+    got_log, got_p = loop(True)
+    assert ref_log == got_log, (ref_log, got_log)
+    assert all(torch.equal(a, b) for a, b in zip(ref_p, got_p))
