@@ -208,7 +208,8 @@ def cpu_baseline(cin, cout, batch):
 
 
 PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summaries newest first, kernel whose bytes per launch `roofline.traffic` quotes)
-    'fp32': (('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),   # (name prefix)
+    'fp32': (('r06_pmc_traffic.json',), 'gemm_split3_kernel'),   # (name prefix; round 6: the transform-domain GEMMs on the bf16 matrix cores)
+    'fp32_mfma': (('r06_pmc_traffic_fp32_mfma.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),
     'bf16': (('r05_pmc_traffic_bf16_b128.json', 'r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
 }
 DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
@@ -236,9 +237,12 @@ def pmc_traffic(precision):
 
 
 KERNEL_NAMES = {
-    'fp32': 'igemm_conv_kernel<64,64,true,true> (batched transform-domain GEMM of the Winograd layers -- 128->256, 256- and 512-channel 3x3 '
-            'convolutions: 16 GEMMs per launch for the grad-mode forward in F(2x2,3x3), 36 for the no-grad forwards, dgrads and weight '
-            'gradients in F(4x4,3x3); v_mfma_f32_16x16x4_f32; achieved = EXECUTED flops / time)',
+    'fp32': 'gemm_split3_kernel (batched transform-domain GEMM of the Winograd layers -- 128->256, 256- and 512-channel 3x3 convolutions: 16 GEMMs per '
+            'launch for the grad-mode forward in F(2x2,3x3), 36 for the no-grad forwards, dgrads and weight gradients in F(4x4,3x3) -- on the bf16 '
+            'matrix cores: both fp32 operands split exactly into three bf16 pieces while staged, six v_mfma_f32_32x32x16_bf16 partial products per '
+            'fp32 product, fp32 accumulate; achieved = EXECUTED bf16 flops (6 x the fp32 contraction\'s) / time, priced against the dense bf16 peak)',
+    'fp32_mfma': 'igemm_conv_kernel<64,64,true,true> (the same batched transform-domain GEMMs on v_mfma_f32_16x16x4_f32, simq_plan_options.gemm_split = 0: '
+                 'the form of rounds 1-5; achieved = EXECUTED fp32 flops / time)',
     'bf16x3': 'igemm_bf16_kernel<NP=2> (split-bf16 implicit GEMM, 3 x v_mfma_f32_16x16x32_bf16 per product; '
               'achieved counts ALGORITHMIC flops, matrix-core work is 3x that)',
     'bf16': 'igemm_bf16_img_kernel (image-tile 3x3 convolution: one 24x24 map x 128 channels per block, halo patch in LDS, ping-pong wave '
@@ -375,7 +379,7 @@ def main():
         torch.cuda.synchronize(dev)
         dog.disarm()
 
-    def run_workload(nets, B, precision, steps, warmup, replay_items):
+    def run_workload(nets, B, precision, steps, warmup, replay_items, leg_opts=None):
         """nets: [(Cin, Cout)] -- one policy/target pair, optimiser state and replay ring per robot group (train.py:180-195);
         B: this rank's transitions per net and step."""
         gB = B * world
@@ -387,7 +391,7 @@ def main():
             # PyTorch defaults for the head): the same seed on every rank gives identical DataParallel replicas, and TD errors
             # stay O(1) so that many steps of synthetic training remain finite
             torch.manual_seed(20260928 + gi)
-            popt = dict(plan_opts) or None
+            popt = dict(plan_opts, **(leg_opts or {})) or None
             policy = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
             target = simq.FCN(cin, cout, device=dev, precision=precision, options=popt)
             target.copy_state_from(policy)
@@ -579,11 +583,29 @@ def main():
         # convolution it implements); bf16: the image-tile kernel; when a precision has no kind-0 launches, all tiles
         ig = dom if dom['launches'] > 0 else allg
         tf = lambda d: d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+        # fp32 plans, round 6: the dominant kernel runs on the bf16 matrix cores (simq_plan_options.gemm_split = 1, the default) and issues SIX
+        # bf16 MFMA products per fp32 product: its executed flops are 6 x the contraction's and its roof is the dense bf16 peak; every other
+        # fp32 kernel (direct convolutions, weight gradients, stem) stays on v_mfma_f32_16x16x4_f32 and is priced against the fp32 matrix peak
+        split = precision == 'fp32' and groups_of_step[0]['policy'].plan.options.get('gemm_split', 0) == 1 and dom['launches'] > 0
+        key = precision if (precision != 'fp32' or split) else 'fp32_mfma'
         PEAK = PEAK_FP32_MFMA_TFLOPS if precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+        fp32_equiv = None
+        if split:
+            fp32_equiv = {'fp32_contraction_tflops': round(tf(dom), 2), 'of_fp32_mfma_peak': round(tf(dom) / PEAK_FP32_MFMA_TFLOPS, 4)}
+            dom = dict(dom, flops=6.0 * dom['flops'])
+            ig = dom
+            # the rest of the fp32 step's matrix work in bf16-pipe-equivalent flops (x peak ratio), so that ONE peak prices the sums below
+            scale = PEAK_BF16_MFMA_TFLOPS / PEAK_FP32_MFMA_TFLOPS
+            oth = dict(oth, flops=scale * oth['flops'])
+            wg = dict(wg, flops=scale * wg['flops'])
+            allg = {k: dom[k] + oth[k] for k in dom}
+            PEAK = PEAK_BF16_MFMA_TFLOPS
         executed = (dom['flops'] + oth['flops'] + wg['flops']) / steps          # matrix-core flops actually issued per step
-        traffic, traffic_source = pmc_traffic(precision)
+        traffic, traffic_source = pmc_traffic(key)
         return {
-            'bound': 'mfma', 'kernel': KERNEL_NAMES[precision],
+            'bound': 'mfma', 'kernel': KERNEL_NAMES[key], 'fp32_equivalent': fp32_equiv,
+            'matrix_pipe': 'bf16 (v_mfma_f32_32x32x16_bf16; the other fp32 kernels of the step run v_mfma_f32_16x16x4_f32 and enter all_gemm_tiles / wgrad / '
+                           'whole_step figures scaled by the peak ratio, i.e. as matrix-pipe TIME)' if split else ('fp32 (v_mfma_f32_16x16x4_f32)' if precision == 'fp32' else 'bf16'),
             'achieved': round(tf(ig), 2), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(tf(ig) / PEAK, 4),
             'traffic': traffic, 'traffic_source': traffic_source,
             'launches_per_step': ig['launches'] / steps, 'avg_launch_ms': round(ig['ms'] / max(ig['launches'], 1), 5),
@@ -601,7 +623,7 @@ def main():
             'ms_per_step_instrumented': round(dt_inst / steps * 1e3, 3),
             'timed': 'HIP-event pairs around every launch of the kernel over %d steps behind the timed region, each kernel ALONE on the device '
                      '(the step\'s stream overlaps off for these steps only; `value` is the overlapped step); the matching rocprofv3 trace is '
-                     'profiles/r05_bench_%s_kernel_trace_serial.txt, the overlapped step\'s profiles/r05_bench_%s_kernel_trace.txt' % (
+                     'profiles/r06_bench_%s_kernel_trace_serial.txt, the overlapped step\'s profiles/r06_bench_%s_kernel_trace.txt' % (
                          steps, 'b32' if precision == 'fp32' else 'bf16_b128', 'b32' if precision == 'fp32' else 'bf16_b128'),
         }
 
@@ -632,10 +654,6 @@ def main():
     m1, dt_m1, n_nets, sustained, exposed_comm = w['m1'], w['dt_m1'], w['n_nets'], w['sustained'], w['exposed_comm']
     release(w)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl['nets'][0][0], wl['nets'][0][1], min(wl['per_gpu'], 32))
-
     # second leg, reported beside the headline, never instead of it.  N=1 (configs[1] headline): BASELINE configs[2] on the bf16
     # matrix-core path.  N>1: the weak-scaling form (configs[1]'s net at 32 transitions per GPU) next to the config-faithful value.
     extra_name = None
@@ -663,6 +681,28 @@ def main():
                 raise                 # (a rank that left the collectives cannot rejoin them)
             extras = {'error': repr(ex)}
 
+    # third leg (N = 1, configs[1] only): the SAME fp32 workload with the transform-domain GEMMs on the fp32 matrix pipe
+    # (simq_plan_options.gemm_split = 0, the form of rounds 1-5) -- so that the line carries both forms of the fp32 arithmetic side by side
+    mfma_leg, roof_m = None, None
+    if extra_name == 'configs2' and 'gemm_split' not in plan_opts and wl['precision'] == 'fp32':
+        try:
+            e = run_workload(wl['nets'], wl['per_gpu'], wl['precision'], args.steps, args.warmup, args.replay, leg_opts={'gemm_split': 0})
+            mfma_leg = {'workload': '%s with simq_plan_options.gemm_split = 0: the transform-domain GEMMs on v_mfma_f32_16x16x4_f32 (rounds 1-5)' % wl['config'],
+                        'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / args.steps * 1e3, 3),
+                        'fwd_bwd_only_transitions_per_s': None if e['m1'] is None else round(e['m1'], 1), 'last_loss': e['info']['loss'],
+                        'sustained': e['sustained']}
+            if not args.no_roofline:
+                roof_m = roofline_pass(e['step'], e['groups'], args.steps, wl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
+            release(e)
+        except Exception as ex:       # noqa: BLE001
+            mfma_leg = {'error': repr(ex)}
+
+    # the CPU baseline LAST: its 32-128 OpenMP threads keep spinning for a while after the last oracle call and slowed the host thread that
+    # enqueues the GPU legs behind it (round 6: the fp32-MFMA leg read 3586 tr/s behind it, 3990 on its own)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl['nets'][0][0], wl['nets'][0][1], min(wl['per_gpu'], 32))
+
     if rank == 0:
         cin0 = wl['nets'][0][0]
         flop_m1, flop_m2 = FLOPS.get(cin0, FLOPS[5])
@@ -682,6 +722,11 @@ def main():
                        'concurrent_groups': (args.group_issue if (n_nets > 1 and args.group_streams and world == 1) else None),
                        'gradient_transport': transport, 'simq_comm_world_size': comm_world, 'backend': args.backend if world > 1 else None,
                        'flop_per_transition': flop_m2, 'flop_per_transition_fwd_bwd_only': flop_m1,
+                       'fp32_gemm_form': (None if wl['precision'] != 'fp32' else
+                                          ('gemm_split = %d: %s' % ((plan_opts.get('gemm_split', 1)), 'transform-domain GEMMs of the Winograd layers on the bf16 matrix cores through an '
+                                           'EXACT three-way split of both fp32 operands (6 partial products, fp32 accumulate; fp32 in, fp32 out, round-off <= the '
+                                           'fp32-MFMA form\'s against fp64: tests/test_gpu_ops.py); the same workload on v_mfma_f32_16x16x4_f32 is the leg `fp32_mfma_configs1`'
+                                           if plan_opts.get('gemm_split', 1) == 1 else 'transform-domain GEMMs on v_mfma_f32_16x16x4_f32'))),
                        'last_loss': info['loss'], 'last_td_error': info['td_error']},
             'roofline': roof, 'cpu_baseline': cpu, 'sustained': sustained, 'exposed_comm': exposed_comm,
         }
@@ -710,6 +755,15 @@ def main():
                 for k in ('achieved', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms', 'launches_per_step', 'kernel_ms_per_step',
                           'whole_step_executed_frac', 'wgrad_frac', 'all_gemm_tiles_frac'):
                     line['roofline'][key + '_' + k] = roof_x[k]
+        if mfma_leg is not None:
+            line['fp32_mfma_configs1'] = mfma_leg
+            line['roofline_fp32_mfma_configs1'] = roof_m
+            if 'full_step_transitions_per_s' in mfma_leg:
+                line['config']['fp32_mfma_configs1_full_step_transitions_per_s'] = mfma_leg['full_step_transitions_per_s']
+                line['config']['fp32_mfma_configs1_fwd_bwd_only_transitions_per_s'] = mfma_leg['fwd_bwd_only_transitions_per_s']
+            if roof_m is not None and roof is not None:
+                for k in ('achieved', 'frac', 'avg_launch_ms', 'kernel_ms_per_step', 'whole_step_executed_frac'):
+                    line['roofline']['fp32_mfma_configs1_' + k] = roof_m[k]
         line['vs_target'] = vs_target
         line['vs_baseline_note'] = 'null: BASELINE.md holds no published number for this metric; see vs_target for the ratio to the north_star target'
         print(json.dumps(line), flush=True)

@@ -141,6 +141,13 @@ typedef struct simq_plan_options {
                                    * the first of the walk ... 0 = layer1's first, the last), so that it runs beside the END of that backward pass, the
                                    * optimiser step and the weight-cache refresh -- the part of a step with the fewest matrix kernels -- instead of
                                    * racing through the start of the backward pass.  -1 = no such wait.  Ordering only: results are bit-identical. */
+    /* Round 6: fp32 plans -- which matrix pipe contracts the transform-domain GEMMs of the Winograd layers (forward, dgrad, weight gradient) */
+    int gemm_split;               /* 1.  0 = v_mfma_f32_16x16x4_f32 on the fp32 operands (the fp32 FMA chain of rounds 1-5).
+                                   * 1 = the bf16 matrix cores through an EXACT three-way split of both fp32 operands (v = v0 + v1 + v2 in bf16
+                                   * pieces, no bit dropped) and the six partial products down to 2^-24 of the product, fp32 accumulate
+                                   * (gemm_split3.hip): fp32 operands, fp32 accumulators, fp32 output, fp32-level round-off (measured against fp64
+                                   * beside form 0, tests/test_gpu_ops.py) at 6/16 of the matrix-pipe time.  Changes the round-off of those
+                                   * contractions (summation order and the dropped sub-ulp terms), nothing else. */
 } simq_plan_options;
 void simq_plan_options_default(simq_plan_options* options);
 int simq_plan_create_opts(int num_input_channels, int num_output_channels, int precision, const simq_plan_options* options,
@@ -398,6 +405,7 @@ typedef struct simq_launch_opts {
     int plane_xcd;                /* as simq_plan_options.plane_xcd (1) */
     int wgrad_xcd_group;          /* as simq_plan_options.wgrad_xcd_group (1) */
     int wgrad_ksplit;             /* as simq_plan_options.wgrad_ksplit (0) */
+    int gemm_split;               /* as simq_plan_options.gemm_split (0) */
 } simq_launch_opts;
 void simq_launch_opts_default(simq_launch_opts* opts);
 int simq_conv2d_fwd(const float* d_x, const float* d_w_ohwi, const float* d_bias, float* d_y,

@@ -52,6 +52,7 @@ struct LaunchTune {
     int plane_xcd = 1;                // conv_igemm.hip, batched GEMMs: whole transform elements per XCD
     int wgrad_xcd_group = 1;          // conv_wgrad*.hip: the tiles of a pixel range on one XCD -- 0 off, 1 the bf16 kernel only, 2 fp32 too
     int wgrad_ksplit = 0;             // conv_winograd.hip: K-split of the transform-domain weight-gradient GEMMs -- 0 by shape, 1 / 2 / 4 forced
+    int gemm_split = 0;               // batched transform-domain GEMMs: 1 = bf16 matrix cores through the exact three-way operand split (gemm_split3.hip)
                                       // (changes the summation order of those gradients: a plan option, never a run-time switch)
 };
 
@@ -136,6 +137,9 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 // ping-pong LDS-DMA form (gemm_f32_pp.hip): 1 = launch taken, 0 = shape not covered, < 0 error
 int try_gemm_batched_pp(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream);
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune = LaunchTune());
+// gemm_split3.hip: the same contraction on the bf16 matrix cores through the exact three-way split of the fp32 operands (LaunchTune::gemm_split)
+bool gemm_split3_eligible(int M, int N, int K, int batch);
+int launch_gemm_batched_split3(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune);
 // conv_winograd.hip: Winograd F(2x2,3x3) for the wide 3x3 layers; U = transformed weights [16][Cout][Cin]
 bool winograd_eligible(const ConvGeom& g);
 bool winograd_pays(int cin, int cout, long min_cc);

@@ -665,6 +665,7 @@ int launch_conv_igemm(const float* x, const float* w, float* y, const ConvGeom& 
 // launch (grid.y = batch): the transform-domain contractions of conv_winograd.hip.  K % 16 == 0, N % 64 == 0.
 int launch_gemm_batched(const float* x, const float* w, float* y, int M, int N, int K, int batch, hipStream_t stream, const LaunchTune& tune) {
     SIMQ_REQUIRE(M > 0 && K % BK == 0 && N % 64 == 0 && batch >= 1, "gemm_batched: M=%d N=%d K=%d batch=%d not supported", M, N, K, batch);
+    if (tune.gemm_split == 1 && gemm_split3_eligible(M, N, K, batch)) return launch_gemm_batched_split3(x, w, y, M, N, K, batch, stream, tune);
 #ifdef SIMQ_ABLATIONS      // the opt-in ping-pong form (gemm_f32_pp.hip, step-neutral: docs/history.md 4) exists in libsimq_ablate.so only
     if (int rc = try_gemm_batched_pp(x, w, y, M, N, K, batch, stream)) return rc < 0 ? rc : 0;     // (N % 128 == 0)
 #endif

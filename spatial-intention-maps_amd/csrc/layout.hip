@@ -203,6 +203,7 @@ void simq_plan_options_default(simq_plan_options* o) {
     o->fuse_bn1_apply = 1; o->bn1_mask_from_preact = 1; o->deterministic = 0;
     o->wgrad_ksplit = 0; o->fwd_overlap = 2; o->wgrad_overlap = 4; o->plane_xcd = 1; o->wgrad_xcd_group = 1; o->tail_split = 0;
     o->early_target_after_block = 4;
+    o->gemm_split = 1;
 }
 
 void simq_launch_opts_default(simq_launch_opts* o) {
@@ -210,7 +211,7 @@ void simq_launch_opts_default(simq_launch_opts* o) {
     const LaunchTune t;
     o->struct_bytes = (int)sizeof(simq_launch_opts);
     o->force_bm = t.force_bm; o->force_bn = t.force_bn; o->tail_split = t.tail_split; o->plane_xcd = t.plane_xcd;
-    o->wgrad_xcd_group = t.wgrad_xcd_group; o->wgrad_ksplit = t.wgrad_ksplit;
+    o->wgrad_xcd_group = t.wgrad_xcd_group; o->wgrad_ksplit = t.wgrad_ksplit; o->gemm_split = t.gemm_split;
 }
 
 int simq_plan_get_options(const simq_plan* plan, simq_plan_options* out) {
@@ -238,6 +239,7 @@ int simq_plan_create_opts(int cin, int cout, int precision, const simq_plan_opti
         SIMQ_REQUIRE(opt.wgrad_xcd_group >= 0 && opt.wgrad_xcd_group <= 2, "plan_create: wgrad_xcd_group = %d (0, 1 or 2)", opt.wgrad_xcd_group);
         SIMQ_REQUIRE(opt.early_target_after_block >= -1 && opt.early_target_after_block <= 7, "plan_create: early_target_after_block = %d (-1 .. 7)",
                      opt.early_target_after_block);
+        SIMQ_REQUIRE(opt.gemm_split == 0 || opt.gemm_split == 1, "plan_create: gemm_split = %d (0 or 1)", opt.gemm_split);
     }
     SIMQ_REQUIRE(cin >= 1 && cin <= 64, "plan_create: num_input_channels=%d out of range", cin);
     SIMQ_REQUIRE(cout >= 1 && cout <= 4, "plan_create: num_output_channels=%d out of range [1,4]", cout);

@@ -13,6 +13,7 @@ int tune_of(const simq_launch_opts* o, LaunchTune* t) {
                  "simq_launch_opts_default first)", o->struct_bytes, (int)sizeof(simq_launch_opts));
     t->force_bm = o->force_bm > 0 ? o->force_bm : 0; t->force_bn = o->force_bm > 0 ? o->force_bn : 0;
     t->tail_split = o->tail_split; t->plane_xcd = o->plane_xcd; t->wgrad_xcd_group = o->wgrad_xcd_group; t->wgrad_ksplit = o->wgrad_ksplit;
+    t->gemm_split = o->gemm_split;
     return 0;
 }
 }  // namespace

@@ -93,6 +93,7 @@ struct simq_plan {
     simq::LaunchTune tune() const {
         simq::LaunchTune t;
         t.tail_split = opt.tail_split; t.plane_xcd = opt.plane_xcd; t.wgrad_xcd_group = opt.wgrad_xcd_group; t.wgrad_ksplit = opt.wgrad_ksplit;
+        t.gemm_split = opt.gemm_split;
         return t;
     }
 };

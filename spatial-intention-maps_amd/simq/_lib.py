@@ -48,12 +48,12 @@ class PlanOptions(ctypes.Structure):
         'struct_bytes', 'winograd', 'winograd_min_cc', 'winograd_f4_forward', 'winograd_f4_min_tiles', 'winograd_f4_grad',
         'winograd_f4_fwd_grad_min_cc', 'winograd_wgrad', 'winograd_wgrad_f4', 'stem_bf16', 'bf16_act_grads', 'keep_fp32_activations', 'fold_eval_bn_bf16',
         'fuse_bn_backward_sums', 'fuse_stem_backward_sums', 'fuse_bn1_apply', 'deterministic', 'bn1_mask_from_preact',
-        'wgrad_ksplit', 'fwd_overlap', 'wgrad_overlap', 'plane_xcd', 'wgrad_xcd_group', 'tail_split', 'early_target_after_block')]
+        'wgrad_ksplit', 'fwd_overlap', 'wgrad_overlap', 'plane_xcd', 'wgrad_xcd_group', 'tail_split', 'early_target_after_block', 'gemm_split')]
 
 
 class LaunchOpts(ctypes.Structure):
     """simq_launch_opts of include/simq.h: kernel selection / block scheduling of ONE standalone operator call (per-kernel tests, tools/)."""
-    _fields_ = [(n, c_int) for n in ('struct_bytes', 'force_bm', 'force_bn', 'tail_split', 'plane_xcd', 'wgrad_xcd_group', 'wgrad_ksplit')]
+    _fields_ = [(n, c_int) for n in ('struct_bytes', 'force_bm', 'force_bn', 'tail_split', 'plane_xcd', 'wgrad_xcd_group', 'wgrad_ksplit', 'gemm_split')]
 
 
 class TrainArgs(ctypes.Structure):

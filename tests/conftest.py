@@ -18,6 +18,18 @@ def pytest_configure(config):
 
 def pytest_addoption(parser):
     parser.addoption('--runslow', action='store_true', default=False, help='also run the tests marked slow')
+    parser.addoption('--plan-option', action='append', default=[], metavar='NAME=INT',
+                     help='run the suite with this simq_plan_options default for every plan a test creates without naming the field '
+                          '(e.g. gemm_split=1: the whole fp32 parity suite on the other form of the transform-domain GEMMs)')
+
+
+@pytest.fixture(autouse=True, scope='session')
+def _plan_option_defaults(request):
+    opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in request.config.getoption('--plan-option')}
+    if opts:
+        from simq import _lib
+        _lib.DEFAULT_PLAN_OPTIONS.update(opts)
+    yield
 
 
 def pytest_sessionstart(session):

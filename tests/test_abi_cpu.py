@@ -282,7 +282,7 @@ def test_plan_options_are_a_property_of_the_plan_and_not_of_the_environment(L, m
                  'winograd_f4_fwd_grad_min_cc': 512 * 512, 'winograd_wgrad': 1, 'winograd_wgrad_f4': 1, 'stem_bf16': 1, 'bf16_act_grads': 1, 'keep_fp32_activations': 0,
                  'fold_eval_bn_bf16': 1, 'fuse_bn_backward_sums': 1, 'fuse_stem_backward_sums': 1, 'fuse_bn1_apply': 1, 'deterministic': 0, 'bn1_mask_from_preact': 1,
                  'wgrad_ksplit': 0, 'fwd_overlap': 2, 'wgrad_overlap': 4, 'plane_xcd': 1, 'wgrad_xcd_group': 1, 'tail_split': 0,
-                 'early_target_after_block': 4}
+                 'early_target_after_block': 4, 'gemm_split': 1}
     p = L.Plan(5, 1, 'bf16', options={'stem_bf16': 0, 'keep_fp32_activations': 1})
     assert p.options['stem_bf16'] == 0 and p.options['keep_fp32_activations'] == 1 and p.options['winograd'] == 1
     # the Winograd weight cache exists only when the option is on: the option changes the plan, not a global

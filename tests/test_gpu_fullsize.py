@@ -185,7 +185,7 @@ def test_ragged_and_degenerate_batches(simq_mod):
         policy.forward_nhwc(torch.zeros(1, 96, 96, cin + 1, device='cuda'))      # wrong channel count
 
 
-_FP32_FAMILIES_B32 = ('gemm_f32_batched', 'winograd_f4', 'winograd_f2', 'winograd_f4_wgrad', 'stem_conv_f32')
+_FP32_FAMILIES_B32 = ('winograd_f4', 'winograd_f2', 'winograd_f4_wgrad', 'stem_conv_f32')
 
 
 @pytest.mark.parametrize('through_ring', [False, True], ids=['host_batch', 'hbm_ring_early_stream'])
@@ -242,6 +242,9 @@ def test_b32_train_step_against_reference_pinned_golden(simq_mod, golden_dir, th
     # the image-tile 1x1 / strided convolutions, the fp32 stem; nothing of the bf16 families
     missing = [f for f in _FP32_FAMILIES_B32 if ran.get(f, 0) == 0]
     assert not missing and not [f for f in ran if 'bf16' in f or f.endswith('16')], (missing, ran)
+    # the transform-domain contractions in the form the plan names (simq_plan_options.gemm_split) -- and in that form only
+    gemm = {1: 'gemm_split3_batched', 0: 'gemm_f32_batched'}
+    assert ran.get(gemm[policy.plan.options['gemm_split']], 0) > 0 and ran.get(gemm[1 - policy.plan.options['gemm_split']], 0) == 0, ran
     rel1 = lambda a, b: abs(a - b) / abs(b)
     assert rel1(info1['loss'], float(g['loss'][0])) < 1e-4 and rel1(info1['td_error'], float(g['td_error'][0])) < 1e-4
     q_sa, y = last1['q_sa'].cpu().double().numpy(), last1['y'].cpu().double().numpy()

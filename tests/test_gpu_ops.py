@@ -642,6 +642,60 @@ def test_gemm_f32_batched_is_an_exact_fp32_contraction(L, M, N, K, P):
         L.lib.call('simq_gemm_f32_batched', L.ptr(x), L.ptr(w), L.ptr(ys[0]), M, N - 1, K, P, L.stream_ptr())
 
 
+@pytest.mark.parametrize('M,N,K,P,tile', [(1152, 512, 512, 36, None), (1152, 512, 512, 36, (128, 128)), (1044, 256, 128, 36, None), (4608, 128, 128, 16, None),
+                                          (512, 512, 1152, 36, None), (256, 256, 576, 72, None), (200, 128, 48, 5, None), (70, 256, 512, 9, (128, 256))],
+                         ids=['f4_l4_b32_wide_tile', 'f4_l4_b32_128x128', 'f4_b29_ragged_rows', 'f2_l2_b32', 'wgrad_l4', 'wgrad_l3_ksplit', 'small_odd_planes', 'one_ragged_tile_wide'])
+def test_gemm_split3_reproduces_the_fp32_contraction_at_fp32_roundoff(L, M, N, K, P, tile):
+    """Round 6: simq_gemm_f32_batched with gemm_split = 1 (gemm_split3.hip) -- the same contraction on the bf16 matrix cores: both fp32 operands
+    split EXACTLY into three bf16 pieces while they are staged, the six partial products down to 2^-24 of each product, fp32 accumulators,
+    fp32 output.  Held to the bars of the fp32-MFMA form (2e-6 of the range against fp64) AND to that form itself: its rms error against
+    fp64 may not exceed 1.1 x the fp32-MFMA kernel's on the same operands (measured 0.85 x: the matrix core rounds once per 16 products
+    instead of once per product); NaN-filled destination, rows past M never written, both block walks bit-identical; operands with a 2^40
+    dynamic range (every piece of the split in play) and exactly representable integers (result EXACT: no piece is lost)."""
+    g = torch.Generator().manual_seed(7 + M + N + K)
+    x = torch.randn(P, M, K, generator=g).cuda(); w = torch.randn(P, N, K, generator=g).cuda()
+    ref = torch.bmm(x.double(), w.double().transpose(1, 2))
+    y0 = torch.empty(P, M, N, device='cuda')
+    L.lib.call('simq_gemm_f32_batched', L.ptr(x), L.ptr(w), L.ptr(y0), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(gemm_split=0))
+    ys = []
+    for on in (1, 0):
+        y = torch.full((P * M * N + 3 * N,), float('nan'), device='cuda')          # (three guard rows behind the last plane: rows past M)
+        L.lib.call('simq_launch_counts_reset')
+        L.lib.call('simq_gemm_f32_batched', L.ptr(x), L.ptr(w), L.ptr(y), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(tile=tile, plane_xcd=on, gemm_split=1))
+        torch.cuda.synchronize()
+        assert L.launch_counts().get('gemm_split3_batched', 0) == 1
+        assert torch.isnan(y[P * M * N:]).all(), 'rows past M of the last plane were written'
+        y = y[:P * M * N].view(P, M, N)
+        assert torch.isfinite(y).all()
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    err = lambda t: float((t.double() - ref).pow(2).mean().sqrt())
+    assert float((ys[0].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert err(ys[0]) <= 1.1 * err(y0), (err(ys[0]), err(y0))
+    # wide dynamic range: magnitudes over 2^40 in both operands
+    xs = x * torch.exp2(torch.randint(-20, 20, x.shape, generator=g).float().cuda()); ws = w * torch.exp2(torch.randint(-20, 20, w.shape, generator=g).float().cuda())
+    refs = torch.bmm(xs.double(), ws.double().transpose(1, 2))
+    ya, yb = torch.empty(P, M, N, device='cuda'), torch.empty(P, M, N, device='cuda')
+    L.lib.call('simq_gemm_f32_batched', L.ptr(xs), L.ptr(ws), L.ptr(ya), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(gemm_split=0))
+    L.lib.call('simq_gemm_f32_batched', L.ptr(xs), L.ptr(ws), L.ptr(yb), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(tile=tile, gemm_split=1))
+    ea, eb = float((ya.double() - refs).pow(2).mean().sqrt()), float((yb.double() - refs).pow(2).mean().sqrt())
+    assert eb <= 2.0 * ea, (eb, ea)
+    # integers below 2^11 (11 significant bits: two pieces of the split), products and sums exact in fp32: the result must be EXACT
+    xi = torch.randint(-2047, 2048, (P, M, K), generator=g).float().cuda(); wi = torch.randint(-3, 4, (P, N, K), generator=g).float().cuda()
+    yi = torch.empty(P, M, N, device='cuda')
+    L.lib.call('simq_gemm_f32_batched', L.ptr(xi), L.ptr(wi), L.ptr(yi), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(tile=tile, gemm_split=1))
+    assert torch.equal(yi.double(), torch.bmm(xi.double(), wi.double().transpose(1, 2)))
+    # ... and 24-bit integers (all three pieces of the split carry bits) against small ones: the sums need more than 24 bits, so the result is
+    # rounded -- no worse than the fp32-MFMA form rounds it
+    xi = torch.randint(-(1 << 24) + 1, 1 << 24, (P, M, K), generator=g).float().cuda()
+    refi = torch.bmm(xi.double(), wi.double().transpose(1, 2))
+    L.lib.call('simq_gemm_f32_batched', L.ptr(xi), L.ptr(wi), L.ptr(yi), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(tile=tile, gemm_split=1))
+    e1 = float((yi.double() - refi).pow(2).mean().sqrt())
+    L.lib.call('simq_gemm_f32_batched', L.ptr(xi), L.ptr(wi), L.ptr(yi), M, N, K, P, L.stream_ptr(), opts=L.launch_opts(gemm_split=0))
+    e0 = float((yi.double() - refi).pow(2).mean().sqrt())
+    assert e1 <= 1.1 * e0 + 1e-30, (e1, e0)
+
+
 def test_conv_winograd_rejects_unsupported_geometry(L):
     """Odd map sizes / channel counts the transform kernels cannot tile are refused with a message, not mis-computed."""
     x = torch.zeros(1, 23, 23, 64, device='cuda'); w = torch.zeros(64, 3, 3, 64, device='cuda'); y = torch.zeros(1, 23, 23, 64, device='cuda')
