@@ -199,7 +199,12 @@ int simq_workspace_tensor(const simq_plan* plan, int batch, const char* name, in
  * conv1 / conv2 / the downsample convolution, the activation between the two convolutions, the block output; NHWC [batch][24][24][C]),
  * "layer<l>.<b>.<bn1|bn2|bnd>" (4*C floats: scale | shift | mean | invstd as the consuming kernel formed them), "stem.pool.plane"
  * (matrix-core precisions), "layer<l>.<b>.<red1|red2|redd>" (2*C doubles: the BatchNorm's reduction slot -- after a backward pass
- * [sum dz | sum dz*xhat]).  storage: 0 fp32, 1 bf16, 2 fp64.  Fails for tensors the plan does not store (e.g. a1 under fuse_bn1_apply). */
+ * [sum dz | sum dz*xhat]).  Round 6, the stem (resnet.py:94-97) and the head (networks.py:18-26 in the order the plan runs it): "stem.y0"
+ * ([batch][48][48][64], the 7x7 convolution's pre-BN output), "stem.bn" / "stem.red", "stem.idx" (uint8 [batch][24][24][64]: the max-pool's
+ * first maximal window slot dy*3+dx), "head.y1" ([batch][24][24][128] conv1 pre-BN), "head.bn1" / "head.red1", "head.a1.plane" (matrix-core
+ * precisions), "head.z2" ([batch][24][24][32]: conv2 + bias, before the first bilinear x2), "head.y2" ([batch][48][48][32]: BatchNorm 2's input),
+ * "head.bn2" / "head.red2", "head.z3" ([batch][48][48][Cout]: conv3 before the second bilinear x2 and the bias).
+ * storage: 0 fp32, 1 bf16, 2 fp64, 3 uint8.  Fails for tensors the plan does not store (e.g. a1 under fuse_bn1_apply). */
 int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels,
                              int* storage);
 
@@ -226,7 +231,11 @@ int simq_backward(const simq_plan* plan, int batch, const float* d_params, const
  * the walk itself reuses four temporaries.  name: "layer<1-4>.<0-1>.<g_out|dy2|dz|dyd|da1|dy1|g_ds|g_in>" = gradient w.r.t. the block output
  * (as received), conv2's pre-BN output, the masked gradient dz = g_out * [out > 0] (identity blocks: the shortcut's addend), the
  * downsample convolution's pre-BN output (downsample blocks), the activation between the convolutions, conv1's pre-BN output, the
- * downsample convolution's data gradient (downsample blocks: the addend of conv1's data gradient), the block input; NHWC [batch][24][24][C].  storage as simq_workspace_tensor_ex.  d_trace: simq_backward_trace_bytes() bytes. */
+ * downsample convolution's data gradient (downsample blocks: the addend of conv1's data gradient), the block input; NHWC [batch][24][24][C].
+ * Round 6: "head.<da2|dy2>" ([batch][48][48][32]: w.r.t. the activation behind / the input of the head's BatchNorm 2), "head.dz2"
+ * ([batch][24][24][32]: w.r.t. conv2's output), "head.<da1|dy1>" ([batch][24][24][128]: behind / in front of BatchNorm 1), "stem.dz"
+ * ([batch][48][48][64]: max-pool + ReLU backward) and "stem.dy0" (w.r.t. the 7x7 convolution's output).
+ * storage as simq_workspace_tensor_ex.  d_trace: simq_backward_trace_bytes() bytes. */
 int64_t simq_backward_trace_bytes(const simq_plan* plan, int batch);
 int simq_backward_trace_tensor(const simq_plan* plan, int batch, const char* name, int64_t* byte_offset, int64_t* elems, int* channels,
                                int* storage);

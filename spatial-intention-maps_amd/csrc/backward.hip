@@ -141,6 +141,7 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
         RC(launch_head_conv3_bwd(c.f(L.up2), c.params + p->h3.w_off, d_dq, S[0], c.grads + p->h3.w_off, c.grads + p->h3.b_off, B, 9216, 32, p->cout, c.stream,
                                  c.dslab()));
         RC(launch_upsample2x_bwd(S[0], S[1], B, 48, 48, 32, c.stream));
+        RC(trace(TL.head.da2, S[1], (int64_t)B * 2304 * 32 * 4));
     }
     // (piped: the head's two weight gradients run on the side stream too.  Their dy operands live in the SECOND set of temporaries, which
     // the walk below does not touch before its second block -- that block then waits for them like for any earlier user of the set.
@@ -158,7 +159,9 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     {   // BatchNorm 2 at 48x48; conv2 and everything behind it at 24x24 (the forward pass's order, transposed)
         Act dy2; dy2.f = S[0];                                       // (fp32 only: its consumer is the bilinear transpose)
         RC(bn_bwd(c, p->hb2, S[1], c.f(L.ah2), c.f(L.yh2), dy2, nullptr, (int64_t)B * 2304, oh != nullptr && !no_fuse_head, nullptr, 0));
+        RC(trace(TL.head.dy2, S[0], (int64_t)B * 2304 * 32 * 4));
         RC(launch_upsample2x_bwd(S[0], t2.f, B, 24, 24, 32, c.stream, t2.pl));
+        RC(trace(TL.head.dz2, t2.f, rows * 32 * 4));
         Act a1; a1.f = c.f(L.ah1); a1.pl = c.planes(L.p_up1, rows * 128);
         if (head_side) RC(fork());
         // the bias gradient (three small launches) goes where the weight gradient goes: off the head's serial chain when that is the side stream
@@ -180,9 +183,11 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
             fh.bnr_mean1 = c.aux(p->hb1, 2); fh.bnr_invstd1 = c.aux(p->hb1, 3); fh.bnr_red1 = c.red(p->hb1);
         }
         RC(conv_dgrad(c, p->h2, t2, S[2], nullptr, 24, fh));         // gradient w.r.t. a1
+        RC(trace(TL.head.da1, S[2], rows * 128 * 4));
         hb1_fused = fuse_hb1;
     }
     RC(bn_bwd(c, p->hb1, S[2], c.lazy1() ? nullptr : c.f(L.ah1), c.f(L.yh1), dyh, nullptr, rows, hb1_fused, nullptr, -1, 0, c.lazy1()));
+    RC(trace(TL.head.dy1, dyh.f, rows * 128 * 4));
     if (head_side) RC(fork());
     RC(launch_colsum_rep(dyh.f, bias_side ? cs_side : cs, c.grads + p->h1.b_off, rows, 128, kStatReplicas, bias_side ? ch.stream : c.stream));
     RC(conv_wgrad(ch, p->h1, c.act(L.blk[7].out, L.blk[7].p_out, rows * 512), dyh, 24));
@@ -307,7 +312,9 @@ int backward_impl(const Ctx& c, const float* d_dq, int phase, const OneHotGrad* 
     RC(launch_stem_pool_bwd(G, c.f(L.pooled), reinterpret_cast<const uint8_t*>(c.ws + L.idx), T0, B, 48, 48, 64, c.stream, c.gbf(),
                             c.f(L.y0), c.aux(p->stem_bn, 2), c.aux(p->stem_bn, 3), no_stem_fuse ? nullptr : srep, y0_bf16, kStatReplicas));
     if (!no_stem_fuse) RC(launch_stats_fold(srep, c.red(p->stem_bn), 2 * p->stem_bn.C, kStatReplicas, c.stream));
+    RC(trace(TL.stem.dz, T0, (int64_t)B * 2304 * 64 * 4));
     RC(bn_bwd(c, p->stem_bn, T0, nullptr, c.f(L.y0), T1, nullptr, (int64_t)B * 2304, !no_stem_fuse, nullptr, y0_bf16));   // (pre-BN output: fp32, or bf16 from stem_conv_bf16)
+    RC(trace(TL.stem.dy0, stem16 ? (const void*)T1.pl.hi : (const void*)T1.f, (int64_t)B * 2304 * 64 * (stem16 ? 2 : 4)));
     if (stem16)                                      // (T0 = dz is dead behind bn_bwd: it holds the partial-sum slabs)
         RC(launch_stem_wgrad_bf16(x0.f, T1.pl.hi, c.grads + p->stem.w_off, T0, B, 96, 96, p->cin, c.stream));
     else
@@ -358,6 +365,9 @@ TraceLayout make_trace_layout(const simq_plan* p, int B) {
         T.blk[i].g_ds = p->blocks[i].has_ds ? take((int64_t)B * 576 * p->blocks[i].cin * gsz) : -1;
         T.blk[i].g_in = take((int64_t)B * 576 * p->blocks[i].cin * gsz);
     }
+    T.head.da2 = take((int64_t)B * 2304 * 32 * 4); T.head.dy2 = take((int64_t)B * 2304 * 32 * 4); T.head.dz2 = take((int64_t)B * 576 * 32 * 4);
+    T.head.da1 = take((int64_t)B * 576 * 128 * 4); T.head.dy1 = take((int64_t)B * 576 * 128 * 4);
+    T.stem.dz = take((int64_t)B * 2304 * 64 * 4); T.stem.dy0 = take((int64_t)B * 2304 * 64 * 4);
     T.total = off;
     return T;
 }
@@ -446,9 +456,22 @@ int simq_backward_trace_tensor(const simq_plan* plan, int batch, const char* nam
         else if (w == "g_in") { off = T.blk[i].g_in; st = gst; ch = b.cin; }
         else if (w == "g_ds" && b.has_ds) { off = T.blk[i].g_ds; st = gst; ch = b.cin; }
     }
-    SIMQ_REQUIRE(off >= 0, "backward_trace_tensor: '%s' is not a tensor of the traced walk (layer<1-4>.<0-1>.<g_out|dy2|dz|dyd|da1|dy1|g_ds|g_in>)", name);
+    int64_t pixels = 576;
+    if (off < 0) {
+        const std::string n(name);
+        const bool stem16 = make_wlayout(plan).stem16 >= 0;
+        if (n == "head.da2") { off = T.head.da2; ch = 32; pixels = 2304; }
+        else if (n == "head.dy2") { off = T.head.dy2; ch = 32; pixels = 2304; }
+        else if (n == "head.dz2") { off = T.head.dz2; ch = 32; }
+        else if (n == "head.da1") { off = T.head.da1; ch = 128; }
+        else if (n == "head.dy1") { off = T.head.dy1; ch = 128; }
+        else if (n == "stem.dz") { off = T.stem.dz; ch = 64; pixels = 2304; }
+        else if (n == "stem.dy0") { off = T.stem.dy0; ch = 64; pixels = 2304; st = stem16 ? 1 : 0; }
+    }
+    SIMQ_REQUIRE(off >= 0, "backward_trace_tensor: '%s' is not a tensor of the traced walk (layer<1-4>.<0-1>.<g_out|dy2|dz|dyd|da1|dy1|g_ds|g_in>, "
+                 "head.<da2|dy2|dz2|da1|dy1>, stem.<dz|dy0>)", name);
     if (byte_offset) *byte_offset = off;
-    if (elems) *elems = (int64_t)batch * 576 * ch;
+    if (elems) *elems = (int64_t)batch * pixels * ch;
     if (channels) *channels = ch;
     if (storage) *storage = st;
     return 0;

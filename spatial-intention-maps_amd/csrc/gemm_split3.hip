@@ -63,7 +63,7 @@ __device__ __forceinline__ void split3(const float4 v, unsigned (&out)[3][2]) {
 // WM x WN waves of 64 x 64 each: block tile (64 WM) x (64 WN), 64 WM WN threads; OCC = blocks per CU the register budget is held to.
 //   <2, 2, 2>  128 x 128, 256 threads, two blocks per CU     <2, 4, 1>  128 x 256, 512 threads, one block per CU: the same eight waves per CU and
 //   the same tile rounds per launch, a quarter fewer operand elements staged (and split) per MFMA
-template <int WM, int WN, int OCC>
+template <int WM, int WN, int OCC, bool ABL_NOSPLIT = false>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) gemm_split3_kernel(const Split3Args p) {
     constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
     constexpr int TM = 2, TN = 2;                                  // 32x32 MFMA tiles per wave and dimension
@@ -135,6 +135,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) gemm_split3_kernel(const Sp
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             unsigned pk[3][2];
+            if constexpr (ABL_NOSPLIT) {      // timing ablation (wrong results): what the kernel would cost with operands that arrive split
+                const float4 v = va[SET][ps];
+                pk[0][0] = __float_as_uint(v.x); pk[0][1] = __float_as_uint(v.y); pk[1][0] = __float_as_uint(v.z); pk[1][1] = __float_as_uint(v.w);
+                pk[2][0] = pk[0][0]; pk[2][1] = pk[1][1];
+            } else
             split3(va[SET][ps], pk);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(st + pl * A_PLANE + awr[ps]) = make_uint2(pk[pl][0], pk[pl][1]);
@@ -142,6 +147,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) gemm_split3_kernel(const Sp
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             unsigned pk[3][2];
+            if constexpr (ABL_NOSPLIT) {
+                const float4 v = vb[SET][ps];
+                pk[0][0] = __float_as_uint(v.x); pk[0][1] = __float_as_uint(v.y); pk[1][0] = __float_as_uint(v.z); pk[1][1] = __float_as_uint(v.w);
+                pk[2][0] = pk[0][0]; pk[2][1] = pk[1][1];
+            } else
             split3(vb[SET][ps], pk);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(st + pl * B_PLANE + bwr[ps]) = make_uint2(pk[pl][0], pk[pl][1]);
@@ -262,6 +272,9 @@ int launch_gemm_batched_split3(const float* x, const float* w, float* y, int M, 
     a.plane_xcd = (tune.plane_xcd && batch >= 8 && rem_ok && ((long)tiles * batch) % 8 == 0) ? 1 : 0;
     note_launch("gemm_split3_batched");
     prof_launch_begin(0, 2.0 * M * N * K * batch, 4.0 * batch * ((double)M * K + (double)N * K + (double)M * N), stream);
+#ifdef SIMQ_ABLATIONS
+    if (tune.force_bm == 128 && tune.force_bn == 130) { a.tilesN = N / 128; hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 2, true>), dim3((unsigned)(tilesM * a.tilesN), (unsigned)batch), dim3(256), 0, stream, a); SIMQ_CHECK_LAUNCH(); return 0; }
+#endif
     if (bn == 256) hipLaunchKernelGGL((gemm_split3_kernel<2, 4, 1>), dim3((unsigned)tiles, (unsigned)batch), dim3(512), 0, stream, a);
     else if (occ3) hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 3>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 2>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, stream, a);

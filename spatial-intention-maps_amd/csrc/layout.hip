@@ -406,6 +406,26 @@ int simq_workspace_tensor_ex(const simq_plan* plan, int batch, const char* name,
         if ((w == "a1") && plan->precision == SIMQ_PREC_FP32 && plan->opt.fuse_bn1_apply && plan->opt.fuse_bn_backward_sums) off = -1;   // never stored
     } else if (std::string(name) == "stem.pool.plane" && mc) {
         off = L.p_pooled; ch = 64; cnt = (int64_t)batch * 576 * 64; st = 1;
+    } else {
+        // round 6: the stem (resnet.py:94-97) and the head (networks.py:18-26, in the order the plan runs it: conv1 -> bn1 -> relu -> conv2 at
+        // 24x24 -> x2 -> bn2 -> relu -> conv3 at 48x48 -> x2 + bias) for the teacher-forced tests
+        const std::string n(name);
+        const bool stem16 = make_wlayout(plan).stem16 >= 0;
+        auto bnaux = [&](const BnL& bn) { off = L.aux + bn.aux_off * (int64_t)sizeof(float); cnt = 4 * (int64_t)bn.C; ch = bn.C; st = 0; };
+        if (n == "stem.y0") { off = L.y0; ch = 64; cnt = (int64_t)batch * 2304 * 64; st = stem16 ? 1 : 0; }         // pre-BN output of the 7x7 convolution
+        else if (n == "stem.bn") bnaux(plan->stem_bn);
+        else if (n == "stem.idx") { off = L.idx; ch = 64; cnt = (int64_t)batch * 576 * 64; st = 3; }                // uint8: first maximal window slot dy*3+dx
+        else if (n == "head.y1") { off = L.yh1; ch = 128; cnt = (int64_t)batch * 576 * 128; st = (ybf && plan->h1.wp_off >= 0) ? 1 : 0; }
+        else if (n == "head.bn1") bnaux(plan->hb1);
+        else if (n == "head.a1.plane" && mc) { off = L.p_up1; ch = 128; cnt = (int64_t)batch * 576 * 128; st = 1; }
+        else if (n == "head.z2") { off = L.up1; ch = 32; cnt = (int64_t)batch * 576 * 32; }                         // conv2 (+ bias) at 24x24, fp32
+        else if (n == "head.y2") { off = L.yh2; ch = 32; cnt = (int64_t)batch * 2304 * 32; }                        // its bilinear x2: BatchNorm 2's input
+        else if (n == "head.bn2") bnaux(plan->hb2);
+        else if (n == "head.z3") { off = L.up2; ch = plan->cout; cnt = (int64_t)batch * 2304 * plan->cout; }         // conv3 at 48x48 (no bias yet)
+        auto bnred = [&](const BnL& bn) { off = L.red + bn.red_off * (int64_t)sizeof(double); cnt = 2 * (int64_t)bn.C; ch = bn.C; st = 2; };
+        if (n == "stem.red") bnred(plan->stem_bn);
+        else if (n == "head.red1") bnred(plan->hb1);
+        else if (n == "head.red2") bnred(plan->hb2);
     }
     SIMQ_REQUIRE(off >= 0, "workspace_tensor_ex: '%s' is not a tensor this plan stores", name);
     if (byte_offset) *byte_offset = off;

@@ -250,6 +250,12 @@ struct OneHotGrad { const int64_t* action; const float* q_sa; const float* y; fl
 // (Ctx::gbf), every other plan fp32.
 struct TraceLayout {
     struct Blk { int64_t g_out, dy2, t1, da1, dy1, g_ds, g_in; } blk[8];      // g_ds: downsample blocks only (-1 otherwise)
+    // round 6: the head's walk (fp32 in every plan) -- da2: w.r.t. the activation behind BatchNorm 2 (48x48x32), dy2: w.r.t. BatchNorm 2's input,
+    // dz2: its bilinear transpose = w.r.t. conv2's 24x24 output, da1 / dy1: w.r.t. the activation behind / the input of BatchNorm 1 (24x24x128)
+    struct Head { int64_t da2, dy2, dz2, da1, dy1; } head;
+    // ... and the stem's: dz w.r.t. the 48x48x64 activation behind the stem's BatchNorm (max-pool + ReLU backward, fp32), dy0 w.r.t. the 7x7
+    // convolution's output (a bf16 plane in plain-bf16 plans with the bf16 stem, fp32 otherwise)
+    struct Stem { int64_t dz, dy0; } stem;
     int64_t total;
 };
 TraceLayout make_trace_layout(const simq_plan* p, int B);   // backward.hip

@@ -372,28 +372,36 @@ class FCN(torch.nn.Module):
         hw = int(round((n.value // (batch * ch.value)) ** 0.5))
         return ws[off.value:off.value + 4 * n.value].view(torch.float32).view(batch, hw, hw, ch.value)
 
+    @staticmethod
+    def _typed_view(buf, off, n, ch, st, batch):
+        """(storage code of simq_workspace_tensor_ex: 0 fp32, 1 bf16, 2 fp64, 3 uint8) -> the tensor in its natural shape."""
+        if st == 2:
+            return buf[off:off + 8 * n].view(torch.float64).view(2, ch)
+        if st == 3:
+            t = buf[off:off + n]
+        elif st:
+            t = buf[off:off + 2 * n].view(torch.bfloat16)
+        else:
+            t = buf[off:off + 4 * n].view(torch.float32)
+        if n == 4 * ch:
+            return t.view(4, ch)
+        hw = int(round((n // (batch * ch)) ** 0.5))
+        return t.view(batch, hw, hw, ch)
+
     def stored_tensor(self, name, batch, slot='train'):
-        """A block-internal tensor of the last forward in workspace `slot` (simq_workspace_tensor_ex: 'layer<l>.<b>.<y1|a1|y2|yd|out>' as
-        [B,24,24,C] fp32 or bf16, 'layer<l>.<b>.<bn1|bn2|bnd>' as [4,C] = scale | shift | mean | invstd, 'layer<l>.<b>.<red1|red2|redd>' as [2,C] fp64,
-        'stem.pool.plane') -- teacher-forced tests."""
+        """A tensor of the last forward in workspace `slot` (simq_workspace_tensor_ex: 'layer<l>.<b>.<y1|a1|y2|yd|out>' as [B,24,24,C] fp32 or
+        bf16, 'layer<l>.<b>.<bn1|bn2|bnd>' as [4,C] = scale | shift | mean | invstd, 'layer<l>.<b>.<red1|red2|redd>' as [2,C] fp64,
+        'stem.pool.plane', and -- round 6 -- the stem's and the head's: 'stem.y0', 'stem.bn', 'stem.idx', 'head.y1', 'head.bn1', 'head.a1.plane',
+        'head.z2', 'head.y2', 'head.bn2', 'head.z3', '<stem|head>.red*') -- teacher-forced tests."""
         import ctypes
         off, n, ch, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
         lib.call('simq_workspace_tensor_ex', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch), ctypes.byref(st))
-        ws = self._ws[slot]
-        if st.value == 2:
-            return ws[off.value:off.value + 8 * n.value].view(torch.float64).view(2, ch.value)
-        if st.value:
-            t = ws[off.value:off.value + 2 * n.value].view(torch.bfloat16)
-        else:
-            t = ws[off.value:off.value + 4 * n.value].view(torch.float32)
-        if n.value == 4 * ch.value:
-            return t.view(4, ch.value)
-        return t.view(batch, 24, 24, ch.value)
+        return self._typed_view(self._ws[slot], off.value, n.value, ch.value, st.value, batch)
 
     def backward_traced(self, dq, batch):
-        """simq_backward_traced: the backward pass of the last grad-mode forward with every gradient tensor of the residual blocks' walk
-        kept (teacher-forced tests).  Returns (flat gradient buffer, lookup) with lookup('layer<l>.<b>.<g_out|dy2|dz|dyd|da1|dy1|g_in>') ->
-        [B,24,24,C] tensor in the plan's storage type."""
+        """simq_backward_traced: the backward pass of the last grad-mode forward with every gradient tensor of the walk kept (teacher-forced
+        tests).  Returns (flat gradient buffer, lookup) with lookup('layer<l>.<b>.<g_out|dy2|dz|dyd|da1|dy1|g_in>' | 'head.<da2|dy2|dz2|da1|dy1>'
+        | 'stem.<dz|dy0>') -> NHWC tensor in the plan's storage type."""
         import ctypes
         ws = self._train_workspace_for_backward()
         trace = torch.empty(int(lib.c.simq_backward_trace_bytes(self.plan.handle, batch)), dtype=torch.uint8, device=self.device_)
@@ -403,11 +411,7 @@ class FCN(torch.nn.Module):
         def lookup(name):
             off, n, ch, st = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
             lib.call('simq_backward_trace_tensor', self.plan.handle, batch, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(ch), ctypes.byref(st))
-            if st.value:
-                t = trace[off.value:off.value + 2 * n.value].view(torch.bfloat16)
-            else:
-                t = trace[off.value:off.value + 4 * n.value].view(torch.float32)
-            return t.view(batch, 24, 24, ch.value)
+            return self._typed_view(trace, off.value, n.value, ch.value, st.value, batch)
         return self.flat_grads, lookup
 
     def infer_argmax_batch(self, states, need_q=False):

@@ -398,3 +398,220 @@ def test_bf16_backward_teacher_forced_block_by_block(simq_mod, B):
         print('\n'.join(log))
     finally:
         torch.set_num_threads(keep_threads)
+
+
+def _ulp_close32(name, got, want64, frac_bar=1e-3, log=None):
+    """fp32 elementwise results against the fp64 emulation of the same fma / max: equal except on half-way cases of the double rounding."""
+    want = want64.float()
+    frac = float((got != want).double().mean())
+    worst = float(((got.double() - want64).abs() / want64.abs().clamp_min(1e-3 * float(want64.abs().max()))).max())
+    if log is not None:
+        log.append('  %-22s %.5f %% of the fp32 elements differ from the emulation, worst %.2e of the value' % (name, 100 * frac, worst))
+    assert frac < frac_bar and worst < 4e-7, (name, frac, worst)
+
+
+@pytest.mark.parametrize('B', [6, 128], ids=['b6', 'b128'])
+def test_bf16_stem_and_head_teacher_forced_forward(simq_mod, B):
+    """Round 6 (verdict: the two teacher-forced walks started behind the stem and stopped in front of the head): the SAME bar for the first and
+    the last kernels of the bf16 plan's train-mode forward.  Every stored tensor of the stem (resnet.py:94-97: 7x7 / stride-2 convolution on the
+    bf16 matrix cores -> BatchNorm -> ReLU -> 3x3 / stride-2 max-pool) and of the head (networks.py:18-26, in the order the plan runs it --
+    conv1 -> bn1 -> relu -> conv2 at 24x24 -> bilinear x2 -> bn2 -> relu -> conv3 at 48x48 -> bilinear x2 + bias: conv2 / conv3 commute with
+    the bilinear maps, whose weights sum to 1) is recomputed in fp64 from the stored tensors it was made from:
+      stem.y0        == bf16(fp64 conv7x7(bf16(x), bf16(w))) except < 1 % one-ulp flips; its BatchNorm statistics at 2e-5 (they come from the
+                     UNROUNDED fp32 outputs); stem.pool == maxpool(relu(fma(y0, scale, shift))) BIT-exact in fp32, its bf16 plane its rounding,
+                     stem.idx == the first maximal window slot (what the backward pass routes through);
+      head.y1        == bf16(fp64 conv1x1(stored layer4.1.out plane, bf16(w1)) + b1) (< 1 % flips), bn1 at 2e-5, a1 plane bit-exact;
+      head.z2        fp32: conv1x1(a1 plane, bf16(w2)) + b2 at 2e-5 (fp32 accumulation of exact bf16 products over K = 128);
+      head.y2        its bilinear x2 (align_corners) at 1e-6; bn2 statistics of THAT tensor at 2e-5; a2 = relu(fma(y2, scale, shift)) at fp32 ulp;
+      head.z3, q     conv3 (exact fp32 arithmetic: 32 -> Cout) at 1e-5 and the final bilinear x2 + bias at 1e-6 -- q is what FCN.forward returns."""
+    import torch.nn.functional as F
+    from simq import _lib
+    from simq._lib import MODE_TRAIN
+    cin, cout = 5, 2
+    net = simq_mod.FCN(cin, cout, precision='bf16')
+    assert net.plan.options['stem_bf16'] == 1
+    net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 91)))
+    net.train()
+    x = torch.cat([olearner.apply_transform(s) for s in synth.make_states(B, cin, 92)]).permute(0, 2, 3, 1).contiguous().cuda()
+    net._ensure_weights()
+    _lib.lib.call('simq_launch_counts_reset')
+    q = net._forward_raw(x, MODE_TRAIN)
+    torch.cuda.synchronize()
+    ran = _lib.launch_counts()
+    assert ran.get('stem_conv_bf16', 0) == 1, ran
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    try:
+        sd = {k[len('module.'):]: v.detach().cpu() for k, v in net.state_dict().items()}
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        nhwc = lambda t: t.permute(0, 2, 3, 1)
+        stored = lambda name: net.stored_tensor(name, B, 'train').cpu()
+        rnd = lambda t: t.to(torch.bfloat16)
+        log = []
+
+        def check_bn(name, aux, ref64, gamma, beta):
+            mean, var = ref64.mean(dim=(0, 2, 3)), ref64.var(dim=(0, 2, 3), unbiased=False)
+            invstd = 1.0 / torch.sqrt(var + 1e-5)
+            rng = float(ref64.abs().max())
+            assert float((aux[2].double() - mean).abs().max()) < 2e-5 * rng and relmax(aux[3], invstd) < 2e-5, name
+            sc = gamma.double() * aux[3].double()
+            assert relmax(aux[0], sc) < 1e-6 and float((aux[1].double() - (beta.double() - aux[2].double() * sc)).abs().max()) < 1e-5 * max(1.0, float(sc.abs().max()) * rng), name
+        # ---- stem
+        y0 = stored('stem.y0')
+        assert y0.dtype == torch.bfloat16 and tuple(y0.shape) == (B, 48, 48, 64)
+        y0ref = F.conv2d(nchw(rnd(x.cpu()).double()), rnd(sd['resnet18.conv1.weight']).double(), stride=2, padding=3)
+        _check_conv('stem.conv', nchw(y0), y0ref, log)
+        aux0 = stored('stem.bn')
+        check_bn('stem.bn', aux0, y0ref, sd['resnet18.bn1.weight'], sd['resnet18.bn1.bias'])
+        a0 = torch.relu(_fma32(y0.float(), aux0[0], aux0[1]))
+        pooled_ref, idx_ref = F.max_pool2d(nchw(a0), 3, 2, 1, return_indices=True)
+        pooled = net.saved_activation('stem.pool', B, 'train').cpu()
+        assert torch.equal(nchw(pooled), pooled_ref), 'stem.pool is not maxpool(relu(fma(y0, scale, shift))) bit for bit'
+        assert torch.equal(stored('stem.pool.plane'), rnd(pooled))
+        slot = nchw(stored('stem.idx')).long()
+        py, px = torch.meshgrid(torch.arange(24), torch.arange(24), indexing='ij')
+        flat = (2 * py - 1 + slot // 3) * 48 + (2 * px - 1 + slot % 3)
+        assert torch.equal(flat, idx_ref), 'stem.idx is not the first maximal window slot'
+        # ---- head
+        out7 = stored('layer4.1.out')
+        y1 = stored('head.y1')
+        assert y1.dtype == torch.bfloat16
+        y1ref = F.conv2d(nchw(out7.double()), rnd(sd['conv1.weight']).double(), sd['conv1.bias'].double())
+        _check_conv('head.conv1', nchw(y1), y1ref, log)
+        aux1 = stored('head.bn1')
+        check_bn('head.bn1', aux1, y1ref, sd['bn1.weight'], sd['bn1.bias'])
+        a1p = stored('head.a1.plane')
+        want = rnd(torch.relu(_fma32(y1.float(), aux1[0], aux1[1])))
+        frac = float((a1p != want).double().mean())
+        log.append('  %-22s %.5f %% of the elements differ from the bit-exact emulation' % ('head.a1', 100 * frac))
+        assert frac < 1e-4
+        z2 = stored('head.z2')
+        z2ref = F.conv2d(nchw(a1p.double()), rnd(sd['conv2.weight']).double(), sd['conv2.bias'].double())
+        e = relmax(nchw(z2), z2ref)
+        log.append('  %-22s conv2 + bias at 24x24 vs fp64 on the stored plane %.2e' % ('head.z2', e))
+        assert e < 2e-5
+        y2 = stored('head.y2')
+        assert tuple(y2.shape) == (B, 48, 48, 32)
+        y2ref = F.interpolate(nchw(z2.double()), scale_factor=2, mode='bilinear', align_corners=True)
+        assert relmax(nchw(y2), y2ref) < 2e-6
+        aux2 = stored('head.bn2')
+        check_bn('head.bn2', aux2, nchw(y2.double()), sd['bn2.weight'], sd['bn2.bias'])
+        a2 = net.saved_activation('head.a2', B, 'train').cpu()
+        _ulp_close32('head.a2', a2, torch.relu(y2.double() * aux2[0].double() + aux2[1].double()), log=log)
+        z3 = stored('head.z3').reshape(B, cout, 48, 48)              # (stored channel-major, like the Q-map it becomes)
+        z3ref = F.conv2d(nchw(a2.double()), sd['conv3.weight'].double())
+        e = relmax(z3, z3ref)
+        log.append('  %-22s conv3 (fp32) at 48x48 vs fp64 on the stored activation %.2e' % ('head.z3', e))
+        assert e < 1e-5
+        qref = F.interpolate(z3.double(), scale_factor=2, mode='bilinear', align_corners=True) + sd['conv3.bias'].double().view(1, -1, 1, 1)
+        assert relmax(q.cpu(), qref) < 2e-6
+        # ... and the order the REFERENCE runs the last two stages in (networks.py:23-26: upsample, then conv3) gives the same Q-map
+        qorder = F.conv2d(F.interpolate(nchw(a2.double()), scale_factor=2, mode='bilinear', align_corners=True), sd['conv3.weight'].double(), sd['conv3.bias'].double())
+        assert relmax(q.cpu(), qorder) < 1e-5
+        print('\n'.join(log))
+    finally:
+        torch.set_num_threads(keep_threads)
+
+
+@pytest.mark.parametrize('B', [6, 128], ids=['b6', 'b128'])
+def test_bf16_stem_and_head_teacher_forced_backward(simq_mod, B):
+    """... and of the backward walk (loss.backward(), train.py:132): the head's chain in front of layer4 and the stem's behind layer1, every
+    traced gradient tensor and every parameter gradient recomputed in fp64 from the STORED operands (simq_backward_traced, round 6 names):
+      conv3 + second bilinear (reference order, autograd in fp64 on the stored a2): d conv3.weight / bias, head.da2 at 1e-5;
+      BatchNorm 2 backward (mask a2 > 0, xhat from the stored y2): head.dy2, d gamma / d beta at 2e-5; first bilinear transposed: head.dz2 at 1e-5,
+      d conv2.bias = its pixel sum; conv2: weight gradient (bf16(dz2) x the stored a1 plane) and data gradient head.da1 (bf16(dz2) x bf16(w2)) at 2e-5;
+      BatchNorm 1 backward (mask from the stored plane): head.dy1 at 2e-5, d gamma / d beta; conv1: bias / weight gradient (bf16(dy1) x the stored
+      layer4.1.out plane) at 2e-5 and layer4.1.g_out == bf16(bf16(dy1) x bf16(w1)) with < 1 % one-ulp flips;
+      stem: stem.dz == max-pool + ReLU backward of the stored layer1.0.g_in through the stored pre-BN output (autograd in fp64: same first-maximum
+      routing) at 1e-6; stem.dy0 (a bf16 plane) == bf16(BatchNorm backward) with < 1 % flips, d gamma / d beta at 2e-5; the 7x7 weight gradient
+      == conv2d_weight(bf16(x), stored dy0 plane) at 2e-5."""
+    import torch.nn.functional as F
+    from simq import _lib
+    from simq._lib import MODE_TRAIN
+    cin, cout = 5, 2
+    net = simq_mod.FCN(cin, cout, precision='bf16')
+    net.load_state_dict(ofcn.state_from_numpy(synth.make_state_dict(cin, cout, 93)))
+    net.train()
+    x = torch.cat([olearner.apply_transform(s) for s in synth.make_states(B, cin, 94)]).permute(0, 2, 3, 1).contiguous().cuda()
+    q = net._forward_raw(x, MODE_TRAIN)
+    dq = torch.from_numpy(cases.dense_upstream(cout, B, 95)).cuda().contiguous()
+    _lib.lib.call('simq_launch_counts_reset')
+    grads_flat, traced = net.backward_traced(dq, B)
+    torch.cuda.synchronize()
+    ran = _lib.launch_counts()
+    assert ran.get('stem_wgrad_bf16', 0) == 1, ran
+    gview = {k: v.detach().cpu().double() for (k, _, _), v in zip(net._param_names, net.reference_views(grads_flat))}
+    keep_threads = torch.get_num_threads()
+    torch.set_num_threads(_host_threads())
+    try:
+        sd = {k[len('module.'):]: v.detach().cpu() for k, v in net.state_dict().items()}
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        nhwc = lambda t: t.permute(0, 2, 3, 1)
+        stored = lambda name: net.stored_tensor(name, B, 'train').cpu()
+        tr = lambda name: traced(name).cpu()
+        rnd = lambda t: t.to(torch.bfloat16)
+        log = []
+
+        def close(name, got, want, bar, scale=None):
+            """scale: what the error is measured against when `want` itself cancels (the biases in front of a BatchNorm have a gradient that is
+            zero in exact arithmetic: the sum over rows of a BatchNorm backward output) -- the sum of the magnitudes that were added"""
+            e = float((got.double() - want).abs().max() / (want.abs().max() if scale is None else scale))
+            log.append('  %-26s %.2e (bar %.0e)' % (name, e, bar))
+            assert e < bar, (name, e)
+
+        def bn_backward(name, g64, mask, y, aux, gamma, gkey, bkey, rows):
+            dz = g64 * mask.double()
+            xhat = (y.double() - aux[2].double()) * aux[3].double()
+            s0, s1 = dz.sum(dim=(0, 1, 2)), (dz * xhat).sum(dim=(0, 1, 2))
+            close(name + ' d beta', gview[bkey], s0, 2e-5)
+            close(name + ' d gamma', gview[gkey], s1, 2e-5)
+            return gamma.double() * aux[3].double() * (dz - s0 / rows - xhat * s1 / rows)
+        # ---- conv3 + the second bilinear map, in the reference's order, differentiated by autograd in fp64 on the stored activation
+        a2 = net.saved_activation('head.a2', B, 'train').cpu()
+        A2 = nchw(a2.double()).contiguous().requires_grad_()
+        w3, b3 = sd['conv3.weight'].double().requires_grad_(), sd['conv3.bias'].double().requires_grad_()
+        F.conv2d(F.interpolate(A2, scale_factor=2, mode='bilinear', align_corners=True), w3, b3).backward(dq.cpu().double())
+        close('conv3.weight', gview['conv3.weight'], w3.grad, 2e-5)
+        close('conv3.bias', gview['conv3.bias'], b3.grad, 2e-5)
+        da2 = tr('head.da2')
+        close('head.da2', nchw(da2), A2.grad, 1e-5)
+        # ---- BatchNorm 2 backward at 48x48, the first bilinear map transposed
+        y2, aux2 = stored('head.y2'), stored('head.bn2')
+        dy2 = tr('head.dy2')
+        close('head.dy2', dy2, bn_backward('bn2', da2.double(), a2 > 0, y2, aux2, sd['bn2.weight'], 'bn2.weight', 'bn2.bias', B * 2304), 2e-5)
+        Z = torch.zeros(B, 32, 24, 24, dtype=torch.float64, requires_grad=True)
+        F.interpolate(Z, scale_factor=2, mode='bilinear', align_corners=True).backward(nchw(dy2.double()).contiguous())
+        dz2 = tr('head.dz2')
+        close('head.dz2', nchw(dz2), Z.grad, 1e-5)
+        close('conv2.bias', gview['conv2.bias'], dz2.double().sum(dim=(0, 1, 2)), 1e-6, scale=float(dz2.double().abs().sum(dim=(0, 1, 2)).max()))
+        # ---- conv2 (1x1, 128 -> 32) on the bf16 matrix cores: operands = the stored a1 plane and bf16(dz2)
+        a1p, dz2b = stored('head.a1.plane'), rnd(dz2)
+        close('conv2.weight', gview['conv2.weight'].reshape(32, 128), dz2b.double().reshape(-1, 32).t() @ a1p.double().reshape(-1, 128), 2e-5)
+        da1 = tr('head.da1')
+        close('head.da1', da1.reshape(-1, 128), dz2b.double().reshape(-1, 32) @ rnd(sd['conv2.weight']).double().reshape(32, 128), 2e-5)
+        # ---- BatchNorm 1 backward at 24x24
+        y1, aux1 = stored('head.y1'), stored('head.bn1')
+        dy1 = tr('head.dy1')
+        close('head.dy1', dy1, bn_backward('bn1', da1.double(), a1p.float() > 0, y1, aux1, sd['bn1.weight'], 'bn1.weight', 'bn1.bias', B * 576), 2e-5)
+        close('conv1.bias', gview['conv1.bias'], dy1.double().sum(dim=(0, 1, 2)), 1e-6, scale=float(dy1.double().abs().sum(dim=(0, 1, 2)).max()))
+        out7, dy1b = stored('layer4.1.out'), rnd(dy1)
+        close('conv1.weight', gview['conv1.weight'].reshape(128, 512), dy1b.double().reshape(-1, 128).t() @ out7.double().reshape(-1, 512), 2e-5)
+        g7 = tr('layer4.1.g_out')
+        _check_conv('layer4.1.g_out', g7.reshape(-1, 512), dy1b.double().reshape(-1, 128) @ rnd(sd['conv1.weight']).double().reshape(128, 512), log)
+        # ---- stem: max-pool + ReLU backward through the stored pre-BN output, BatchNorm backward, the 7x7 weight gradient
+        y0, aux0 = stored('stem.y0'), stored('stem.bn')
+        g0 = tr('layer1.0.g_in')
+        V = nchw(_fma32(y0.float(), aux0[0], aux0[1]).double()).contiguous().requires_grad_()
+        F.max_pool2d(torch.relu(V), 3, 2, 1).backward(nchw(g0.double()).contiguous())
+        dz0 = tr('stem.dz')
+        close('stem.dz', nchw(dz0), V.grad, 1e-6)
+        dy0 = tr('stem.dy0')
+        assert dy0.dtype == torch.bfloat16
+        ones = torch.ones_like(dz0, dtype=torch.bool)
+        _check_conv('stem.dy0', dy0, bn_backward('resnet18.bn1', dz0.double(), ones, y0, aux0, sd['resnet18.bn1.weight'], 'resnet18.bn1.weight',
+                                                 'resnet18.bn1.bias', B * 2304), log)
+        want = torch.nn.grad.conv2d_weight(nchw(rnd(x.cpu()).double()), tuple(sd['resnet18.conv1.weight'].shape), nchw(dy0.double()), stride=2, padding=3)
+        close('resnet18.conv1.weight', gview['resnet18.conv1.weight'], want, 2e-5)
+        print('\n'.join(log))
+    finally:
+        torch.set_num_threads(keep_threads)
