@@ -212,7 +212,7 @@ def cpu_baseline(cin, cout, batch):
 PMC_TRAFFIC = {   # precision -> (committed rocprofv3 PMC summaries newest first, kernel whose bytes per launch `roofline.traffic` quotes)
     'fp32': (('r06_pmc_traffic.json',), 'gemm_split3_kernel'),   # (name prefix; round 6: the transform-domain GEMMs on the bf16 matrix cores)
     'fp32_mfma': (('r06_pmc_traffic_fp32_mfma.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'igemm_conv_kernel<64, 64, true, true'),
-    'bf16': (('r05_pmc_traffic_bf16_b128.json', 'r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
+    'bf16': (('r06_pmc_traffic_bf16_b128.json', 'r05_pmc_traffic_bf16_b128.json', 'r04_pmc_traffic_bf16_b128.json', 'r03_pmc_traffic_bf16_b128.json', 'r02_pmc_traffic_bf16_b128.json'), None),     # None: the kernel named by DOMINANT_BF16 below
 }
 DOMINANT_BF16 = 'igemm_bf16_img_kernel'      # name prefix of the bf16 leg's dominant kernel in the rocprofv3 summaries
 

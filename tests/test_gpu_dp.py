@@ -178,9 +178,12 @@ def _sampled_relerr(got, g):
 
 DP_GOLDEN = [('dp_c5o2_b8_w1', 'nccl', True), ('dp_c5o2_b8_w2', 'gloo', False), ('dp_c5o2_b8_w8', 'gloo', False),
              ('dp_c5o1_b8_w2', 'gloo', False)]
+# (round 6, suite budget: eight processes importing torch and sharing the one GPU take a minute of wall time for a B = 8 step -- the 8-rank
+# fixture runs with --runslow / SIMQ_RUN_SLOW=1; the 1-, 2- and 4-rank fixtures stay in the default run)
+_DP_PARAMS = [pytest.param(*c, id=c[0] + '-' + c[1], marks=[pytest.mark.slow] if c[0].endswith('_w8') else []) for c in DP_GOLDEN]
 
 
-@pytest.mark.parametrize('name,backend,use_comm', DP_GOLDEN, ids=[c[0] + '-' + c[1] for c in DP_GOLDEN])
+@pytest.mark.parametrize('name,backend,use_comm', _DP_PARAMS)
 def test_dp_step_against_reference_replica_fixture(tmp_path, golden_dir, name, backend, use_comm):
     import simq
     case = [c for c in cases.DP_CASES if c[0] == name][0]
@@ -272,7 +275,7 @@ def test_dp_step_full_size_properties(tmp_path, name, spec, world, backend, use_
     assert float((torch.as_tensor(r0['params1']).double() - p1).norm() / p1.norm()) < 1e-6
 
 
-SYNCBN_CASES = [('train_c4o2_b8', 2, 'gloo', False), ('train_c4o2_b8', 4, 'gloo', False), ('train_c5o1_b4', 4, 'gloo', False),
+SYNCBN_CASES = [('train_c4o2_b8', 2, 'gloo', False), ('train_c4o2_b8', 4, 'gloo', False), ('train_c5o1_b4', 2, 'gloo', False),
                 ('train_c4o2_b8', 1, 'nccl', True)]
 
 

@@ -619,7 +619,7 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list, 
         coef = min(1.0, cases.CLIP / (tn + 1e-6))
         grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
         p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
-        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < (3 if B >= 128 else 6) or B <= 8 else (None, None)
+        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < (2 if B >= 64 else 3) or B <= 8 else (None, None)       # (the fp64 second-step oracle costs 3-8 s of host time per case at B >= 32)
         info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
         if sd1 is not None:     # the second call per transition against the fp64 oracle run from the post-step-1 state (tests/step2_oracle.py)
             step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)

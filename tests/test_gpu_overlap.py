@@ -115,7 +115,7 @@ def test_plan_owned_streams_are_created_lazily_and_die_with_the_plan(env):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(B, 96, 96, cin, generator=g).cuda()
     ref = None
-    for rep in range(12):                           # (12 plans, each creating its side stream and 4 events; a leak shows in rocm-smi, a crash here)
+    for rep in range(6):                            # (6 plans, each creating its side stream and 4 events; a leak shows in rocm-smi, a crash here)
         policy, _ = _nets(e, 'fp32', {'deterministic': 1}, cin, cout)
         q = policy._forward_raw(x, MODE_TRAIN)
         dq = torch.full_like(q, 1e-3)

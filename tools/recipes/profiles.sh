@@ -37,6 +37,10 @@ serial() {   # name, extra bench args...
 }
 prof b32; serial b32
 prof bf16_b128 --workload configs2; serial bf16_b128 --workload configs2
+# round 6: the fp32 step with the transform-domain GEMMs on the fp32 matrix pipe (the form of rounds 1-5), serial trace only -- the comparison leg of bench.py
+serial b32_mfma --plan-option gemm_split=0
+# ... and BASELINE configs[3] on one GPU (two nets x 256, a launch stream per robot group): how many kernels run at once
+bash $R/tools/recipes/overlap.sh configs3 --workload configs3 --steps 4 --warmup 2 > /dev/null; cp $R/gpurun_out/configs3_overlap.txt $O/phases_configs3.txt
 find $O -name "*.db" -delete
 find $O -type d -empty -delete
 tail -c 1500 $O/bench.json
