@@ -3,7 +3,7 @@
 pybullet environment (random 96x96xC observations, random rewards, robots that finish their actions at random times).
 
 It exists to exercise the drop-in surface end to end on an MI355X: DQNPolicy / DQNIntentionPolicy.step, TransitionTracker,
-(Aliased)DeviceReplayBuffer.push / sample, train, train_intention, target sync through state_dict, the Q-map debug path
+(Aliased)DeviceReplayBuffer.push / sample, train_groups (train + train_intention per robot group, concurrently), target sync through state_dict, the Q-map debug path
 of train.py:294-296, policy + optimizer checkpoints and resume.  Not a benchmark (bench.py is)."""
 import argparse
 import os
@@ -62,14 +62,15 @@ def run(cfg, checkpoint_dir, verbose=True):
             state = env.reset()
             tracker = simq.TransitionTracker(state)
         if timestep >= learning_starts and (timestep + 1) % cfg.train_freq == 0:                      # train.py:252-264
-            for i in range(num_robot_groups):
-                if len(replay_buffers[i]) < cfg.batch_size:
+            # the loop pass over the robot groups (train.py:255-261) handed over whole: every group's train() -- and train_intention() -- on a
+            # launch stream of its own, side by side on the device (simq.train_groups; per net the results of the sequential loop)
+            batches = [replay_buffers[i].sample(cfg.batch_size) if len(replay_buffers[i]) >= cfg.batch_size else None for i in range(num_robot_groups)]
+            infos = simq.train_groups(cfg, policy.policy_nets, target_nets, optimizers, batches, policy.apply_transform, cfg.discount_factors,
+                                      intention_nets=policy.intention_nets if cfg.use_predicted_intention else None,
+                                      optimizers_intention=optimizers_intention)
+            for i, info_i in enumerate(infos):
+                if info_i is None:
                     continue
-                batch = replay_buffers[i].sample(cfg.batch_size)
-                info_i = simq.train(cfg, policy.policy_nets[i], target_nets[i], optimizers[i], batch, policy.apply_transform,
-                                    cfg.discount_factors[i])
-                if cfg.use_predicted_intention:
-                    info_i.update(simq.train_intention(policy.intention_nets[i], optimizers_intention[i], batch, policy.apply_transform))
                 log.append((timestep + 1, i, info_i))
                 if verbose:
                     print('t=%d group %d %s' % (timestep + 1, i, {k: round(v, 4) for k, v in info_i.items()}))
