@@ -277,7 +277,12 @@ int launch_gemm_batched_split3(const float* x, const float* w, float* y, int M, 
 #endif
     if (bn == 256) hipLaunchKernelGGL((gemm_split3_kernel<2, 4, 1>), dim3((unsigned)tiles, (unsigned)batch), dim3(512), 0, stream, a);
     else if (occ3) hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 3>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 2>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), 0, stream, a);
+    else {
+        // (ablation build: SIMQ_SPLIT3_PAD_LDS = bytes of unused dynamic LDS per block -- 40000 leaves room for ONE block per CU, so that a
+        // co-running HBM-bound kernel gets two thirds of the register file: A/B of "GEMM alone faster" against "the pair faster")
+        static const int pad = SIMQ_TUNE_INT("SIMQ_SPLIT3_PAD_LDS", 0);
+        hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 2>), dim3((unsigned)tiles, (unsigned)batch), dim3(256), (size_t)pad, stream, a);
+    }
     prof_launch_end(stream);
     SIMQ_CHECK_LAUNCH();
     return 0;
