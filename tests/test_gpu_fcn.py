@@ -613,21 +613,24 @@ def test_gradient_parity_distribution(simq_mod, golden_dir, fixture, case_list, 
         cfg, batch = cases.make_cfg(B), cases.make_batch(cin, cout, B, dseed)
         policy, target = make_net(simq_mod, cin, cout, wseed, True), make_net(simq_mod, cin, cout, wseed + 1000, False)
         opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
-        p0 = [v.detach().clone().cpu().double() for v in policy.reference_views(policy.flat_params)]
+        # (round 6, suite budget: the 16 sampled elements per tensor are picked ON the device -- three host copies of 11 M doubles per case were most
+        # of this test's time)
+        samp = [torch.tensor(cases.sample_indices(v.numel()), device='cuda') for v in policy.reference_views(policy.flat_params)]
+        pick = lambda flat: [v.detach().reshape(-1)[i].double().cpu() for v, i in zip(policy.reference_views(flat), samp)]
+        p0 = pick(policy.flat_params)
         info1 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
         tn = float(policy._simq_opt_state.total_norm.item())
         coef = min(1.0, cases.CLIP / (tn + 1e-6))
-        grads = [v.detach().cpu().double() / coef for v in policy.reference_views(policy.flat_grads)]
-        p1 = [v.detach().cpu().double() for v in policy.reference_views(policy.flat_params)]
-        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < (2 if B >= 64 else 3) or B <= 8 else (None, None)       # (the fp64 second-step oracle costs 3-8 s of host time per case at B >= 32)
+        grads = [v / coef for v in pick(policy.flat_grads)]
+        p1 = pick(policy.flat_params)
+        sd1, sd_target = (step2_oracle.snapshot(policy), step2_oracle.snapshot(target)) if len(rows) < (2 if B >= 64 else 3) or (B <= 8 and len(rows) < 6) else (None, None)       # (the fp64 second-step oracle costs 3-8 s of host time per case at B >= 32)
         info2 = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
         if sd1 is not None:     # the second call per transition against the fp64 oracle run from the post-step-1 state (tests/step2_oracle.py)
             step2_oracle.second_step_against_the_oracle(sd1, sd_target, batch, policy._last['q_sa'].cpu().numpy(), policy._last['y'].cpu().numpy(), info2)
         gs, ds = [], []
         for t, a, b in zip(grads, p0, p1):
-            idx = torch.tensor(cases.sample_indices(t.numel()))
-            gs.append(t.reshape(-1)[idx].numpy())
-            ds.append((b - a).reshape(-1)[idx].numpy())
+            gs.append(t.numpy())
+            ds.append((b - a).numpy())
         rl2 = lambda a, b: float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
         rows.append(dict(name=name, grad=rl2(np.stack(gs), g[name + '.grad64']), ref_grad=float(g[name + '.ref_grad_err']),
                          dparam=rl2(np.stack(ds), g[name + '.dparam64']), ref_dparam=float(g[name + '.ref_dparam_err']),
