@@ -254,20 +254,17 @@ int launch_gemm_batched_split3(const float* x, const float* w, float* y, int M, 
     const double xb = 4.0 * M * K, wb = 4.0 * N * K;
     SIMQ_REQUIRE(xb < 4294967000.0 && wb < 4294967000.0 && 4.0 * (M + 128) * K < 4294967000.0, "gemm_split3: operand exceeds the 4 GiB buffer-addressing limit");
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-    // tile: 128 x 256 (eight waves) where the columns allow; tune.force_bm / force_bn = 128 / 128 | 128 / 256 | 64 / 128 select a form for
-    // tools/gemm_batched_probe.py and the per-kernel tests (128 x 128 held to three blocks per CU spilled 21 registers and measured 8-13 % slower)
+    // tile: 128 x 256 (eight waves) where the columns allow; tune.force_bm / force_bn = 128 / 128 | 128 / 256 select a form for
+    // tools/gemm_batched_probe.py and the per-kernel tests.  Measured and not kept: 128 x 128 held to three waves per SIMD (spills 21 registers,
+    // 8-13 % slower); a 64 x 128 tile of two waves for the launches with few blocks (3-40 % slower on every shape of the step,
+    // gpurun_out/split3_probe_small.log -> profiles/r06_gemm_split3_probe.txt)
     // (measured per shape, profiles/r06_gemm_split3_probe.txt: the wide tile wins where a block has >= 32 K-steps to amortise its prologue
     // and epilogue -- one block per CU, nothing beside it -- and the launch still has two rounds of blocks: M = 1152, N = K = 512 116.7 us
     // against 127.0; K = 256 or a single column of tiles: the two co-resident 128 x 128 blocks are 5-15 % faster)
     const long wide_blocks = (long)((M + 127) / 128) * (N / 256) * batch;
-    int bm = 128, bn = (N % 256 == 0 && K >= 512 && wide_blocks >= 512) ? 256 : 128;
-    // few blocks of few K-steps (the 128-channel layers at 32 transitions: 324 blocks of 8 K-steps on 256 CUs): half-height tiles, four blocks per
-    // CU -- more blocks whose prologues and epilogues overlap
-    const long blocks128 = (long)((M + 127) / 128) * (N / 128) * batch;
-    static const int small_rule = SIMQ_TUNE_INT("SIMQ_SPLIT3_SMALL_TILE", 0);
-    if (small_rule && bn == 128 && blocks128 < 512 && K <= 256) bm = 64;
-    if (tune.force_bm == 128 && (tune.force_bn == 128 || (tune.force_bn == 256 && N % 256 == 0))) { bm = 128; bn = tune.force_bn; }
-    if (tune.force_bm == 64 && tune.force_bn == 128) { bm = 64; bn = 128; }
+    const int bm = 128;
+    int bn = (N % 256 == 0 && K >= 512 && wide_blocks >= 512) ? 256 : 128;
+    if (tune.force_bm == 128 && (tune.force_bn == 128 || (tune.force_bn == 256 && N % 256 == 0))) bn = tune.force_bn;
     a.tilesN = N / bn;
     const int tilesM = (M + bm - 1) / bm;
     const int tiles = tilesM * a.tilesN;
@@ -281,7 +278,6 @@ int launch_gemm_batched_split3(const float* x, const float* w, float* y, int M, 
     if (tune.force_bm == 128 && tune.force_bn == 130) { a.tilesN = N / 128; hipLaunchKernelGGL((gemm_split3_kernel<2, 2, 2, true>), dim3((unsigned)(tilesM * a.tilesN), (unsigned)batch), dim3(256), 0, stream, a); SIMQ_CHECK_LAUNCH(); return 0; }
 #endif
     if (bn == 256) hipLaunchKernelGGL((gemm_split3_kernel<2, 4, 1>), dim3((unsigned)tiles, (unsigned)batch), dim3(512), 0, stream, a);
-    else if (bm == 64) hipLaunchKernelGGL((gemm_split3_kernel<1, 2, 2>), dim3((unsigned)tiles, (unsigned)batch), dim3(128), 0, stream, a);
     else {
         // (ablation build: SIMQ_SPLIT3_PAD_LDS = bytes of unused dynamic LDS per block -- 40000 leaves room for ONE block per CU, so that a
         // co-running HBM-bound kernel gets two thirds of the register file: A/B of "GEMM alone faster" against "the pair faster")
