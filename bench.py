@@ -87,7 +87,7 @@ def parse():
     ap.add_argument('--fwd-overlap', type=int, default=None, choices=[0, 1, 2], help='tools only: simq_plan_options.fwd_overlap of every plan, A/B (2 = default: three forwards side by side)')
     ap.add_argument('--plane-xcd', type=int, default=None, choices=[0, 1], help='tools only: simq_plan_options.plane_xcd of every plan (batched GEMM planes per XCD), A/B')
     ap.add_argument('--early-target', type=int, default=None, choices=[0, 1], help='tools only: StepOptions.early_target_forward of every learner (the target-net forward of a step beside the previous step), A/B')
-    ap.add_argument('--group-streams', type=int, default=1, choices=[0, 1], help='tools only: multi-net workloads (configs3): 1 = every robot group issues its step on a launch stream of its own (the groups run side by side), 0 = one after the other on one stream (rounds 1-5), A/B')
+    ap.add_argument('--group-streams', type=int, default=0, choices=[0, 1], help='tools only: multi-net workloads (configs3): 1 = every robot group issues its step on a launch stream of its own (the groups run side by side), 0 = one after the other on one stream (the reference\'s order; measured level with 1 once a step\'s streams are chosen by test: profiles/r06_ab_concurrent_groups.txt), A/B')
     ap.add_argument('--group-issue', default='defer', choices=['defer', 'stagger'], help="tools only: with --group-streams 1: 'defer' = enqueue every group's step, then wait for the losses (simq.train_groups); 'stagger' = wait for each group's loss before enqueueing the next group's step")
     ap.add_argument('--third-leg-split', type=int, default=0, choices=[0, 1], help='tools only: simq_plan_options.gemm_split of the third leg (1: the headline form again -- is a THIRD leg slower as such?)')
     ap.add_argument('--stream-skew', type=int, default=0, help='tools only: take this many streams from torch\'s stream pool before the learners do (which hardware queue a stream shares follows the order of creation: A/B)')
@@ -686,25 +686,20 @@ def main():
 
     # third leg (N = 1, configs[1] only): the SAME fp32 workload with the transform-domain GEMMs on the fp32 matrix pipe
     # (simq_plan_options.gemm_split = 0, the form of rounds 1-5) -- so that the line carries both forms of the fp32 arithmetic side by side.
-    # It runs as a process of its own (this script with --plan-option gemm_split=0 and no further legs): a workload that is the THIRD to run
-    # in one process reads 10-13 % low whatever its plan (round 6: the headline configuration itself 4293 tr/s as a third leg, 4936 as the first
-    # -- profiles/r06_third_leg_order_effect.txt), and the two forms are to be compared like for like, each as the first workload of a process.
+    # (Mid round 6 this leg read 10-13 % low as the third workload of the process -- its side stream had landed on the launch stream's hardware
+    # queue; simq.learner now picks a step's streams from streams TESTED to run concurrently, and a workload reads the same whether it is the
+    # first or the fourth of a process: profiles/r06_third_leg_order_effect.txt.)
     mfma_leg, roof_m = None, None
-    if extra_name == 'configs2' and 'gemm_split' not in plan_opts and wl['precision'] == 'fp32' and rank == 0:
+    if extra_name == 'configs2' and 'gemm_split' not in plan_opts and wl['precision'] == 'fp32':
         try:
-            torch.cuda.synchronize(dev)
-            torch.cuda.empty_cache()
-            cmd = [sys.executable, os.path.abspath(__file__), '--plan-option', 'gemm_split=%d' % args.third_leg_split, '--no-extras', '--no-cpu-baseline',
-                   '--steps', str(args.steps), '--warmup', str(args.warmup), '--sustained-seconds', str(args.sustained_seconds), '--replay', str(args.replay)]
-            if args.no_roofline:
-                cmd.append('--no-roofline')
-            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            sub = json.loads(out.stdout.strip().splitlines()[-1])
-            mfma_leg = {'workload': '%s with simq_plan_options.gemm_split = %d: the transform-domain GEMMs on v_mfma_f32_16x16x4_f32 (rounds 1-5); a process of '
-                                    'its own, same steps / warm-up' % (wl['config'], args.third_leg_split),
-                        'full_step_transitions_per_s': sub['value'], 'ms_per_step': sub['ms_per_step'],
-                        'fwd_bwd_only_transitions_per_s': sub['value_fwd_bwd_only'], 'last_loss': sub['config']['last_loss'], 'sustained': sub['sustained']}
-            roof_m = sub['roofline']
+            e = run_workload(wl['nets'], wl['per_gpu'], wl['precision'], args.steps, args.warmup, args.replay, leg_opts={'gemm_split': args.third_leg_split})
+            mfma_leg = {'workload': '%s with simq_plan_options.gemm_split = %d: the transform-domain GEMMs on v_mfma_f32_16x16x4_f32 (rounds 1-5)' % (wl['config'], args.third_leg_split),
+                        'full_step_transitions_per_s': round(e['value'], 1), 'ms_per_step': round(e['dt'] / args.steps * 1e3, 3),
+                        'fwd_bwd_only_transitions_per_s': None if e['m1'] is None else round(e['m1'], 1), 'last_loss': e['info']['loss'],
+                        'sustained': e['sustained']}
+            if not args.no_roofline:
+                roof_m = roofline_pass(e['step'], e['groups'], args.steps, wl['precision'], e['dt'] / args.steps * 1e3, e['value'] / world)
+            release(e)
         except Exception as ex:       # noqa: BLE001
             mfma_leg = {'error': repr(ex)}
 

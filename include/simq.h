@@ -350,6 +350,13 @@ typedef struct simq_train_args {
                                   * step t+1 while step t still runs, see loss_host) -- and `stream` waits for it where the values are
                                   * gathered.  Needs the three-forward form (side_stream, fwd_overlap = 2, double DQN, non-final next states, no SyncBN):
                                   * an ERROR otherwise (round 6; it used to be ignored silently).  Results are bit-identical. */
+    void* third_stream;          /* NULL: the policy's no-grad forward of the three-forward form runs on a stream the plan owns.  Otherwise the
+                                  * caller's stream for it (round 6).  Why a caller would care: the HIP runtime multiplexes streams onto 4 hardware
+                                  * queues by default, kernels of ONE hardware queue run in order, and which queue a stream lands on follows the
+                                  * order in which the process's streams were first used -- with the launch stream and the side (or this) stream on
+                                  * one queue the step loses its forward overlap (-13 % measured: profiles/r06_third_leg_order_effect.txt).  The
+                                  * Python host picks `stream` / `side_stream` / `third_stream` / `target_stream` from streams it has TESTED to run
+                                  * concurrently (simq.learner.LearnerStreams); a C caller can do the same with two spin kernels. */
 } simq_train_args;
 int simq_train_step(const simq_train_args* a);
 /* blocks until the loss_host copy of the last simq_train_step of `plan` on the current device has landed.  The step's streams must belong

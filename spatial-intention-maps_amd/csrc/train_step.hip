@@ -98,12 +98,16 @@ int simq_train_step(const simq_train_args* a) {
     SIMQ_REQUIRE(!a->target_stream || three, "train_step: target_stream needs the three-forward form (fwd_overlap = 2, a side stream, double DQN, "
                  "non-final next states, no SyncBN)");
     if (three) {
-        if (!ps->third) {
+        if (!ps->third_ev) {
             std::lock_guard<std::mutex> lk(p->mu);
-            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->third, hipStreamNonBlocking));
             SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->third_ev, hipEventDisableTiming));
         }
-        hipStream_t third = ps->third;
+        if (!a->third_stream && !ps->third) {
+            std::lock_guard<std::mutex> lk(p->mu);
+            SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->third, hipStreamNonBlocking));
+        }
+        // (the caller's stream when it names one: it has chosen streams that do not share a hardware queue, see simq_train_args.third_stream)
+        hipStream_t third = a->third_stream ? static_cast<hipStream_t>(a->third_stream) : ps->third;
         // (target_stream: the caller ordered it behind the target forward's inputs -- no wait for this step's or the previous step's work)
         hipStream_t tstream = a->target_stream ? static_cast<hipStream_t>(a->target_stream) : side;
         // ... except for a point of the PREVIOUS step's backward walk (simq_plan_options.early_target_after_block): started at once, this forward

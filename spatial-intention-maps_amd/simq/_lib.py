@@ -67,7 +67,7 @@ class TrainArgs(ctypes.Structure):
                     't_params', 't_wcache', 't_bnbuf', 't_ws',
                     'state', 'next_state', 'action', 'reward', 'nonfinal_pos',
                     'q', 'q_next', 'q_tgt', 'dq', 'nsv', 'vals', 'best', 'q_sa', 'y', 'td', 'out4',
-                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('struct_bytes', c_int), ('comm', c_void_p), ('loss_host', c_void_p), ('target_stream', c_void_p)]
+                    'opt_scratch', 'total_norm', 'stream', 'side_stream')] + [('global_nonfinal', c_int), ('struct_bytes', c_int), ('comm', c_void_p), ('loss_host', c_void_p), ('target_stream', c_void_p), ('third_stream', c_void_p)]
 
 
 _SIGS = {

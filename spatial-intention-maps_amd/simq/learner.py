@@ -461,6 +461,93 @@ class AliasedDeviceReplayBuffer(DeviceReplayBuffer):
         return len(self._ref) - len(self._free)
 
 
+class _HardwareQueues:
+    """Which streams of one device share a HARDWARE queue.  The HIP runtime multiplexes a process's streams onto a few hardware queues
+    (4 by default), kernels of one hardware queue run in order, and which queue a stream lands on follows the order in which the
+    process's streams were first used.  Measured (round 6, tools/leg_order_probe.py): whenever a learner's side stream shared the launch
+    stream's queue, its step lost the forward overlap -- 4 090 instead of 4 720 tr/s on configs[1], the whole "third leg of bench.py reads
+    13 % low" effect.  So the streams of a step are not taken blindly: two spin kernels (torch.cuda._sleep) on two streams take twice as long
+    when the streams share a queue, which sorts candidate streams into classes; a learner gets its side / third / early streams from
+    classes other than its launch stream's and, as far as the queues go, from three different ones.  Streams go back to the pool when their
+    learner is collected (the suite creates hundreds of nets: a handful of calibrations per process, ~3 ms each)."""
+    CYCLES = 1_500_000          # ~0.7 ms per spin kernel
+
+    def __init__(self, device):
+        self.device = device
+        self.reps = []            # one representative stream per class
+        self.free = []            # [(class, stream)] handed back by collected learners
+        self.known = {}           # cuda_stream handle -> class
+        self.ok = hasattr(torch.cuda, '_sleep')
+
+    def _shared(self, a, b):
+        import time
+        def both(x, y):
+            torch.cuda.synchronize(self.device)
+            t = time.perf_counter()
+            with torch.cuda.stream(x):
+                torch.cuda._sleep(self.CYCLES)
+            with torch.cuda.stream(y):
+                torch.cuda._sleep(self.CYCLES)
+            torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t
+        serial = min(both(a, a), both(a, a))
+        return min(both(a, b), both(a, b)) > 0.75 * serial
+
+    def classify(self, stream):
+        key = stream.cuda_stream
+        c = self.known.get(key)
+        if c is None:
+            for c, rep in enumerate(self.reps):
+                if self._shared(rep, stream):
+                    break
+            else:
+                self.reps.append(stream)
+                c = len(self.reps) - 1
+            self.known[key] = c
+        return c
+
+    def acquire(self, avoid, n):
+        """n streams whose classes differ from `avoid` and, as far as possible, from each other."""
+        out, used = [], set(avoid)
+        if not self.ok:
+            return [torch.cuda.Stream(self.device) for _ in range(n)]
+        for distinct in (True, False):            # second pass: classes may repeat among the n (fewer queues than roles), still never `avoid`
+            tries = 0
+            while len(out) < n and tries < 10:
+                pick = next((i for i, (c, _) in enumerate(self.free) if c not in (used if distinct else set(avoid))), None)
+                if pick is not None:
+                    c, st = self.free.pop(pick)
+                else:
+                    tries += 1
+                    st = torch.cuda.Stream(self.device)
+                    c = self.classify(st)
+                    if c in (used if distinct else set(avoid)):
+                        self.free.append((c, st))
+                        continue
+                out.append(st)
+                used.add(c)
+        while len(out) < n:                       # (one hardware queue in all: nothing to choose)
+            out.append(torch.cuda.Stream(self.device))
+        return out
+
+    def release(self, streams):
+        for st in streams:
+            self.free.append((self.classify(st), st))
+
+
+_HWQ = {}
+
+
+def _hardware_queues(device):
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    q = _HWQ.get(device)
+    if q is None:
+        q = _HWQ[device] = _HardwareQueues(device)
+    return q
+
+
 class LearnerStreams:
     """The streams ONE learner (a policy net with its target net, optimiser state and ring: one robot group of train.py:180-195, or an
     intention net) issues its steps on.  Round 6: they belong to the learner, not to the device -- the robot groups of train.py:255-257 and
@@ -470,38 +557,76 @@ class LearnerStreams:
                ordered behind the caller's stream at the moment of the call, and whoever touches the nets next on another stream is
                ordered behind the step (FCN._order_behind_last_step) -- no join at the end of the loop pass is needed.
       side     target-net forward / weight gradients beside the launch stream (StepOptions.overlap_target_forward)
-      early    the target-net forward that does not wait for the previous step (StepOptions.early_target_forward)"""
-    __slots__ = ('device', 'launch', '_side', '_early')
+      third    the policy's no-grad forward of the three-forward form (simq_train_args.third_stream)
+      early    the target-net forward that does not wait for the previous step (StepOptions.early_target_forward)
+    side / third / early are chosen against the stream the step is issued on (bind): streams TESTED not to share its hardware queue
+    (_HardwareQueues)."""
+    __slots__ = ('device', 'launch', '_bound', '_side', '_third', '_early', '__weakref__')
 
     def __init__(self, device, own_launch_stream=False):
         self.device = torch.device(device)
         self.launch = torch.cuda.Stream(self.device) if own_launch_stream else None
-        self._side = self._early = None
+        self._bound = self._side = self._third = self._early = None
+
+    def bind(self, main):
+        """Choose side / third / early for steps issued on `main` (once per launch stream)."""
+        if self._bound == main.cuda_stream:
+            return self
+        q = _hardware_queues(self.device)
+        if self._side is not None:
+            q.release([self._side, self._third, self._early])
+        avoid = {q.classify(main)} if q.ok else set()
+        self._side, self._third, self._early = q.acquire(avoid, 3)
+        self._bound = main.cuda_stream
+        return self
+
+    def _need(self):
+        if self._side is None:
+            self.bind(self.launch if self.launch is not None else torch.cuda.current_stream(self.device))
 
     @property
     def side(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
+        self._need()
         return self._side
 
     @property
+    def third(self):
+        self._need()
+        return self._third
+
+    @property
     def early(self):
-        if self._early is None:
-            self._early = torch.cuda.Stream(self.device)
+        self._need()
         return self._early
+
+    def give_back(self):
+        if self._side is not None:
+            _hardware_queues(self.device).release([self._side, self._third, self._early])
+            self._bound = self._side = self._third = self._early = None
 
 
 def learner_streams(policy_net, own_launch_stream=None):
     """The LearnerStreams of `policy_net` (created on first use).  own_launch_stream=True gives the learner a launch stream of its own
     (train_groups / bench.py's multi-net workloads do that for every robot group); None leaves it as it is."""
+    import weakref
     ls = getattr(policy_net, '_learner_streams', None)
     if ls is None:
         ls = policy_net._learner_streams = LearnerStreams(policy_net.device_, bool(own_launch_stream))
+        weakref.finalize(policy_net, _give_back_streams, weakref.ref(ls))
     elif own_launch_stream and ls.launch is None:
         ls.launch = torch.cuda.Stream(ls.device)
     elif own_launch_stream is False:
         ls.launch = None
     return ls
+
+
+def _give_back_streams(ref):
+    ls = ref()
+    if ls is not None:
+        try:
+            ls.give_back()
+        except Exception:            # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class _OptState:
@@ -649,6 +774,7 @@ def train_step(policy_net, target_net, batch, discount_factor, batch_size, lr, m
     # on a side stream, forked behind the train-mode forward so that it overlaps the policy's next-state forward (both work
     # on the ~29 non-final samples and fill each other's partially filled rounds of CUs).
     main = torch.cuda.current_stream(dev)
+    ls.bind(main)
     side = ls.side if opts.overlap_target_forward else main
     Nn = b.next_state.shape[0]
     nsv = torch.empty(B, dtype=torch.float32, device=dev)
@@ -738,6 +864,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     main = torch.cuda.current_stream(dev)
     if ls is None:
         ls = learner_streams(policy_net)
+    ls.bind(main)
     side = ls.side if opts.overlap_target_forward else None
     a = TrainArgs()
     a.struct_bytes = ctypes.sizeof(TrainArgs)
@@ -796,6 +923,7 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     a.stream = main.cuda_stream
     a.side_stream = side.cuda_stream if side is not None else None
     a.target_stream = early.cuda_stream if early is not None else None
+    a.third_stream = ls.third.cuda_stream if side is not None else None
     loss_host = None
     if sync:
         # train.py:137-139 (loss.item()) without synchronising the stream: the library copies the four sums to pinned memory as soon as
@@ -1021,7 +1149,7 @@ def _expose_momentum(net, optimizer, st, momentum):
 
 
 def train_groups(cfg, policy_nets, target_nets, optimizers, batches, transform_fn, discount_factors,
-                 intention_nets=None, optimizers_intention=None, concurrent=True):
+                 intention_nets=None, optimizers_intention=None, concurrent=False):
     """One pass of the reference's training loop body over ALL robot groups (train.py:253-261) as one call:
 
         for i in range(num_robot_groups):
@@ -1030,7 +1158,11 @@ def train_groups(cfg, policy_nets, target_nets, optimizers, batches, transform_f
                 train_info.update(train_intention(intention_nets[i], optimizers_intention[i], batches[i], transform_fn))
 
     The groups' Q-networks and the intention networks are independent networks with their own parameters, optimiser state, workspaces
-    and plans.  With concurrent=True every learner issues its step on a launch stream of its own (LearnerStreams) and the host enqueues ALL
+    and plans.  Every step is enqueued before the first loss is waited for.  With concurrent=True every learner also issues its step on a launch
+    stream of its own (LearnerStreams): measured on one MI355X this is level with the sequential order (configs[3]: 5 362 against 5 349 tr/s at 256
+    per net, 5 009 against 5 047 at 64 -- a single learner's four streams already occupy the four hardware queues and never more than two
+    kernels fit the device at once), hence off by default; the mechanism is tested bit-identical and is there for parts / runtimes where it pays.
+    With concurrent=True every learner issues its step on a launch stream of its own (LearnerStreams) and the host enqueues ALL
     steps before it waits for the first loss, so the steps run side by side on the device: one net's HBM-bound phases (Winograd transforms,
     BatchNorm passes, optimiser step) under the other's matrix-core phases.  Per net the same kernels run on the same operands in the same
     order: every net's results are what the sequential loop gives (bit-identical on deterministic plans, tests/test_gpu_overlap.py).

@@ -232,7 +232,7 @@ def test_concurrent_robot_groups_equal_the_sequential_loop_bit_for_bit(env, prec
             batches = [g['ring'].sample(B) for g in groups]                                        # train.py:256
             if concurrent:
                 infos = sl.train_groups(cfg, [g['policy'] for g in groups], [g['target'] for g in groups], [g['opt'] for g in groups],
-                                        batches, None, [0.85, 0.85])
+                                        batches, None, [0.85, 0.85], concurrent=True)
                 assert all(sl.learner_streams(g['policy']).launch is not None for g in groups)
             else:
                 infos = [sl.train(cfg, g['policy'], g['target'], g['opt'], b, None, 0.85) for g, b in zip(groups, batches)]
@@ -285,7 +285,7 @@ def test_concurrent_groups_with_intention_nets_equal_the_sequential_loop(env):
             batches = [g['ring'].sample(B) for g in groups]
             if concurrent:
                 infos = sl.train_groups(cfg, [g['policy'] for g in groups], [g['target'] for g in groups], [g['opt'] for g in groups],
-                                        batches, None, [0.85, 0.85], intention_nets=inets, optimizers_intention=iopts)
+                                        batches, None, [0.85, 0.85], intention_nets=inets, optimizers_intention=iopts, concurrent=True)
             else:
                 infos = []
                 for g, b, net, opt in zip(groups, batches, inets, iopts):
