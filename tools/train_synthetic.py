@@ -67,7 +67,7 @@ def run(cfg, checkpoint_dir, verbose=True):
             batches = [replay_buffers[i].sample(cfg.batch_size) if len(replay_buffers[i]) >= cfg.batch_size else None for i in range(num_robot_groups)]
             infos = simq.train_groups(cfg, policy.policy_nets, target_nets, optimizers, batches, policy.apply_transform, cfg.discount_factors,
                                       intention_nets=policy.intention_nets if cfg.use_predicted_intention else None,
-                                      optimizers_intention=optimizers_intention)
+                                      optimizers_intention=optimizers_intention, concurrent=True)
             for i, info_i in enumerate(infos):
                 if info_i is None:
                     continue
