@@ -104,7 +104,10 @@ def _upload_stream(device):
         device = torch.device('cuda', torch.cuda.current_device())
     up = _UPLOAD_STREAMS.get(device)
     if up is None:
-        up = _UPLOAD_STREAMS[device] = torch.cuda.Stream(device)
+        # (a stream TESTED not to share the hardware queue of the stream the rings are used from -- behind a learner's launch stream the
+        # next minibatch's gathers would wait for the whole running step: _HardwareQueues further down)
+        q = _hardware_queues(device)
+        up = _UPLOAD_STREAMS[device] = q.acquire({q.classify(torch.cuda.current_stream(device))} if q.ok else set(), 1)[0]
     return up
 
 
@@ -530,6 +533,19 @@ class _HardwareQueues:
             out.append(torch.cuda.Stream(self.device))
         return out
 
+    def acquire_in(self, want, avoid):
+        """One stream of class `want` (created and classified until one lands there; any class outside `avoid` after 12 tries)."""
+        pick = next((i for i, (c, _) in enumerate(self.free) if c == want), None)
+        if pick is not None:
+            return self.free.pop(pick)[1]
+        for _ in range(12):
+            st = torch.cuda.Stream(self.device)
+            c = self.classify(st)
+            if c == want:
+                return st
+            self.free.append((c, st))
+        return self.acquire(avoid, 1)[0]
+
     def release(self, streams):
         for st in streams:
             self.free.append((self.classify(st), st))
@@ -576,7 +592,16 @@ class LearnerStreams:
         if self._side is not None:
             q.release([self._side, self._third, self._early])
         avoid = {q.classify(main)} if q.ok else set()
-        self._side, self._third, self._early = q.acquire(avoid, 3)
+        up = _UPLOAD_STREAMS.get(self.device if self.device.index is not None else torch.device('cuda', torch.cuda.current_device()))
+        up_class = q.classify(up) if (q.ok and up is not None) else None
+        if up_class is not None and up_class not in avoid:
+            # four roles, four hardware queues: launch | side | third | early.  The upload stream (index copies, ring gathers: microseconds)
+            # has to share one of them -- the early stream's, whose work waits for those gathers anyway; never side's or third's, where a
+            # gather would queue behind a whole forward pass
+            self._side, self._third = q.acquire(avoid | {up_class}, 2)
+            self._early = q.acquire_in(up_class, avoid)
+        else:
+            self._side, self._third, self._early = q.acquire(avoid, 3)
         self._bound = main.cuda_stream
         return self
 
