@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SIMQ_VERSION 401            /* 0.4.1: simq_plan_options.early_target_after_block */
+#define SIMQ_VERSION 500            /* 0.5.0: simq_plan_options.gemm_split, simq_train_args.third_stream, simq_plan_adopt_side_stream, stem / head inspection names */
 #define SIMQ_STATE_WIDTH 96         /* envs.py:2010 */
 
 /* forward modes of simq_forward */
@@ -364,6 +364,12 @@ int simq_train_step(const simq_train_args* a);
  * set per device, created on first use, destroyed by simq_plan_destroy) -- as do the third stream of fwd_overlap = 2 and the side stream
  * of a backward pass called on its own (wgrad_overlap).  A plan is used by one host thread at a time. */
 int simq_train_loss_wait(const simq_plan* plan);
+/* Round 6.  The backward entry points called on their own (simq_backward*, FCN.backward) run the weight gradients beside the dgrads on a
+ * side stream the plan owns (simq_plan_options.wgrad_overlap).  A stream the library creates lands on whatever hardware queue the runtime
+ * gives it -- the launch stream's, on a bad day, and then nothing overlaps (see simq_train_args.third_stream: forward + backward alone 6 500 ->
+ * 5 460 tr/s on configs[1] when that happened).  A caller that has tested its streams hands one over here: it is used instead (for the
+ * calling thread's current device) and stays the caller's -- simq_plan_destroy does not destroy it.  NULL: back to the plan's own stream. */
+int simq_plan_adopt_side_stream(const simq_plan* plan, void* side_stream);
 
 /* ---- gradient exchange between data-parallel ranks (replaces the reduce-add of nn.DataParallel, policies.py:39) --------------
  * One process per GPU; RCCL (librccl.so.1, bound at run time) over xGMI.  Rank 0 obtains a SIMQ_COMM_ID_BYTES identifier and

@@ -340,12 +340,15 @@ static int attach_backward_side(Ctx& c) {
         SIMQ_CHECK_HIP(hipStreamGetDevice(c.stream, &sdev));
         if ((int)sdev != dev) return 0;      // (a stream of another device: no overlap rather than events on the wrong device)
     }
-    if (!ps->bwd_side) {
+    if (!ps->bwd_ev[0]) {
         std::lock_guard<std::mutex> lk(c.p->mu);
-        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->bwd_side, hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) SIMQ_CHECK_HIP(hipEventCreateWithFlags(&ps->bwd_ev[i], hipEventDisableTiming));
     }
-    c.wstream = ps->bwd_side; c.ev_wfork = ps->bwd_ev[0]; c.ev_wjoin = ps->bwd_ev[1]; c.ev_wdone[0] = ps->bwd_ev[2]; c.ev_wdone[1] = ps->bwd_ev[3];
+    if (!ps->bwd_side_ext && !ps->bwd_side) {
+        std::lock_guard<std::mutex> lk(c.p->mu);
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&ps->bwd_side, hipStreamNonBlocking));
+    }
+    c.wstream = ps->bwd_side_ext ? ps->bwd_side_ext : ps->bwd_side; c.ev_wfork = ps->bwd_ev[0]; c.ev_wjoin = ps->bwd_ev[1]; c.ev_wdone[0] = ps->bwd_ev[2]; c.ev_wdone[1] = ps->bwd_ev[3];
     return 0;
 }
 
@@ -425,6 +428,21 @@ int simq_backward_onehot(const simq_plan* plan, int batch, const float* d_params
     const OneHotGrad oh{d_action, d_q_sa, d_y, grad_scale};
     RC(attach_backward_side(c));
     return backward_impl(c, nullptr, phase, &oh);
+}
+
+int simq_plan_adopt_side_stream(const simq_plan* plan, void* side_stream) {
+    SIMQ_REQUIRE(plan, "plan_adopt_side_stream: NULL plan");
+    PlanStreams* ps = nullptr;
+    int dev = 0;
+    RC(plan_streams(plan, &ps, &dev));
+    SIMQ_REQUIRE(ps, "plan_adopt_side_stream: device index %d out of range", dev);
+    if (side_stream) {
+        hipDevice_t sdev = 0;
+        SIMQ_CHECK_HIP(hipStreamGetDevice(static_cast<hipStream_t>(side_stream), &sdev));
+        SIMQ_REQUIRE((int)sdev == dev, "plan_adopt_side_stream: the stream belongs to device %d, the calling thread's current device is %d", (int)sdev, dev);
+    }
+    ps->bwd_side_ext = static_cast<hipStream_t>(side_stream);
+    return 0;
 }
 
 int64_t simq_backward_trace_bytes(const simq_plan* plan, int batch) {

@@ -55,6 +55,7 @@ struct TensorInfo { std::string name; int64_t off; int64_t shape[4]; int kind; }
 // simq_plan_destroy.  A plan is used by one host thread at a time (include/simq.h), so the sets need no further locking.
 struct PlanStreams {
     hipStream_t bwd_side = nullptr;                 // weight gradients beside the dgrads of a backward pass called on its own (wgrad_overlap)
+    hipStream_t bwd_side_ext = nullptr;             // ... the CALLER's stream for that (simq_plan_adopt_side_stream): used instead, never destroyed here
     hipEvent_t bwd_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t third = nullptr;                    // simq_train_step: the policy's no-grad forward beside the other two (fwd_overlap = 2)
     hipEvent_t third_ev = nullptr;

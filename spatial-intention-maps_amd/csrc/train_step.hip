@@ -6,7 +6,10 @@ using namespace simq;
 
 namespace {
 // out4 -> pinned host memory without a stream synchronisation: the plan's copy stream + two events of the current device (PlanStreams)
-int loss_copy(const simq_plan* plan, const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream) {
+// copy_on: a stream of the CALLER's to run the copy on instead of the plan's copy stream -- simq_train_step hands over the third stream when
+// the caller named one: it is idle from the end of the forward phase to the next step, and the caller has TESTED that it does not share the
+// launch stream's hardware queue (simq_train_args.third_stream), which nobody can say of a stream the library creates
+int loss_copy(const simq_plan* plan, const float* d_out4, float* h_out4, hipStream_t producer, bool own_stream, hipStream_t copy_on = nullptr) {
     PlanStreams* c = nullptr;
     int dev = 0;
     RC(plan_streams(plan, &c, &dev));
@@ -16,17 +19,20 @@ int loss_copy(const simq_plan* plan, const float* d_out4, float* h_out4, hipStre
         SIMQ_CHECK_HIP(hipStreamGetDevice(producer, &sdev));
         SIMQ_REQUIRE((int)sdev == dev, "train_step: the stream belongs to device %d, the calling thread's current device is %d", (int)sdev, dev);
     }
-    if (!c->copy) {
+    if (!c->copy_ready) {
         std::lock_guard<std::mutex> lk(plan->mu);
-        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
         SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c->copy_ready, hipEventDisableTiming));
         SIMQ_CHECK_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     }
+    if (own_stream && !copy_on && !c->copy) {
+        std::lock_guard<std::mutex> lk(plan->mu);
+        SIMQ_CHECK_HIP(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    }
     hipStream_t s = producer;
     if (own_stream) {                       // the copy must not queue behind the backward pass that follows on `producer`
+        s = copy_on ? copy_on : c->copy;
         SIMQ_CHECK_HIP(hipEventRecord(c->copy_ready, producer));
-        SIMQ_CHECK_HIP(hipStreamWaitEvent(c->copy, c->copy_ready, 0));
-        s = c->copy;
+        SIMQ_CHECK_HIP(hipStreamWaitEvent(s, c->copy_ready, 0));
     }
     SIMQ_CHECK_HIP(hipMemcpyAsync(h_out4, d_out4, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
     SIMQ_CHECK_HIP(hipEventRecord(c->copy_done, s));
@@ -172,7 +178,8 @@ int simq_train_step(const simq_train_args* a) {
     RC(launch_scatter_next_values(a->vals, a->nonfinal_pos, Nn, a->nsv, B, main));                                    // train.py:116-122
     RC(launch_td_huber(a->q, B, n, a->action, a->reward, a->nsv, a->gamma, 1.0f / (float)a->global_batch, a->q_sa, a->y, a->td,
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
-    if (a->loss_host && !a->comm) RC(loss_copy(p, a->out4, a->loss_host, main, true));     // train.py:137-139: the loss is final here
+    if (a->loss_host && !a->comm)                                                          // train.py:137-139: the loss is final here
+        RC(loss_copy(p, a->out4, a->loss_host, main, true, (three && a->third_stream) ? static_cast<hipStream_t>(a->third_stream) : nullptr));
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;

@@ -103,6 +103,7 @@ _SIGS = {
     'simq_backward_traced': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_train_step': (c_int, [c_void_p]),
     'simq_train_loss_wait': (c_int, [c_void_p]),
+    'simq_plan_adopt_side_stream': (c_int, [c_void_p, c_void_p]),
     'simq_backward_onehot': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     'simq_q_argmax': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'simq_q_gather': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -299,7 +299,21 @@ class FCN(torch.nn.Module):
                             'copy in the workspace): a backward pass called on its own would differentiate the first convolution against a stale '
                             'input -- run a grad-mode forward first')
         self._order_behind_last_step()
+        self._adopt_side_stream()
         return ws
+
+    def _adopt_side_stream(self):
+        """The side stream of a backward pass called on its own: one the host has TESTED not to share the launch stream's hardware queue
+        (simq.learner.LearnerStreams), handed to the plan (simq_plan_adopt_side_stream) -- once per (plan, launch stream)."""
+        from . import learner
+        cur = torch.cuda.current_stream(self.device_)
+        key = (self.plan.handle.value if hasattr(self.plan.handle, 'value') else int(self.plan.handle), cur.cuda_stream)
+        if getattr(self, '_adopted_side', None) != key:
+            ls = learner.learner_streams(self)
+            if ls.launch is None or ls.launch.cuda_stream == cur.cuda_stream:
+                ls.bind(cur)
+                lib.call('simq_plan_adopt_side_stream', self.plan.handle, ls.side.cuda_stream)
+            self._adopted_side = key
 
     def _backward_raw(self, dq, batch, phase=0):
         """dq [B,Cout,96,96] -> flat gradient buffer (overwritten).  phase 1 / 2: the two halves of the walk

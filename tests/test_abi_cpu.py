@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(L):
     for s in syms:
         assert hasattr(raw, s), 'libsimq.so does not export %s' % s
     assert sorted(L.EXPORTS) == syms, 'ctypes binding and header disagree'
-    assert L.lib.version == 401
+    assert L.lib.version == 500
 
 
 def test_no_process_global_behaviour_switch_is_exported(L):
