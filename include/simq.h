@@ -384,6 +384,12 @@ int simq_plan_adopt_side_stream(const simq_plan* plan, void* side_stream);
 typedef struct simq_comm simq_comm;
 int simq_comm_unique_id(void* id_out /* SIMQ_COMM_ID_BYTES, host memory */);
 int simq_comm_init(const void* id, int world_size, int rank, simq_comm** out);
+/* Round 6: run the communicator's collectives on a stream of the CALLER's instead of the communicator's own (NULL: back to its own).  The
+ * point is the hardware queue (see simq_train_args.third_stream): a gradient bucket must travel beside the backward pass, so its stream may
+ * share a queue neither with the launch stream nor with the side stream of the weight gradients -- the Python host hands over the learner's
+ * third stream, idle from the end of the forward phase to the next step.  Synchronises the stream in use so far (the collectives of one
+ * communicator stay ordered); every rank must adopt at the same point of its sequence of collectives. */
+int simq_comm_adopt_stream(simq_comm* comm, void* stream);
 int simq_comm_world_size(const simq_comm* comm);
 int simq_comm_rank(const simq_comm* comm);
 int simq_comm_allreduce(simq_comm* comm, void* d_buf, int64_t count, int dtype, void* producer_stream);

@@ -80,6 +80,8 @@ struct simq_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
     hipStream_t stream = nullptr;          // library-owned: every collective runs here
+    hipStream_t stream_ext = nullptr;      // ... or here: the caller's stream (simq_comm_adopt_stream), never destroyed by the library
+    hipStream_t cs() const { return stream_ext ? stream_ext : stream; }
     hipEvent_t ready[kEvents] = {};        // producer stream -> comm stream (ring: one per collective in flight)
     hipEvent_t done = nullptr;             // comm stream -> consumer stream
     // exposed-wait timing (simq_comm_time_waits): a timing-enabled pair around the consumer stream's wait -- what the consumer stream
@@ -107,13 +109,13 @@ int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_
     hipEvent_t ev = c->ready[c->next];
     c->next = (c->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, producer));
-    SIMQ_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+    SIMQ_CHECK_HIP(hipStreamWaitEvent(c->cs(), ev, 0));
     const int slot = (int)(c->enqueued.load(std::memory_order_relaxed) % kEvents);
     c->last_kind.store(dtype == SIMQ_COMM_F32 ? 0 : 1, std::memory_order_relaxed); c->last_count.store(count, std::memory_order_relaxed);
     c->enqueued.fetch_add(1, std::memory_order_release);
     SIMQ_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dtype == SIMQ_COMM_F32 ? kNcclFloat32 : kNcclFloat64, kNcclSum, c->comm,
-                                     c->stream));
-    SIMQ_CHECK_HIP(hipEventRecord(c->fin[slot], c->stream));
+                                     c->cs()));
+    SIMQ_CHECK_HIP(hipEventRecord(c->fin[slot], c->cs()));
     c->recorded.fetch_add(1, std::memory_order_release);
     return 0;
 }
@@ -127,7 +129,7 @@ int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream) {
 
 int comm_wait(simq_comm* c, hipStream_t consumer) {
     SIMQ_REQUIRE(c, "comm_wait: NULL communicator");
-    SIMQ_CHECK_HIP(hipEventRecord(c->done, c->stream));
+    SIMQ_CHECK_HIP(hipEventRecord(c->done, c->cs()));
     if (c->time_waits) SIMQ_CHECK_HIP(hipEventRecord(c->wait_t0, consumer));
     SIMQ_CHECK_HIP(hipStreamWaitEvent(consumer, c->done, 0));
     if (c->time_waits) { SIMQ_CHECK_HIP(hipEventRecord(c->wait_t1, consumer)); c->wait_timed = 1; }
@@ -182,12 +184,12 @@ int simq_comm_broadcast(simq_comm* comm, void* d_buf, int64_t bytes, int root, v
     hipEvent_t ev = comm->ready[comm->next];
     comm->next = (comm->next + 1) % kEvents;
     SIMQ_CHECK_HIP(hipEventRecord(ev, static_cast<hipStream_t>(producer_stream)));
-    SIMQ_CHECK_HIP(hipStreamWaitEvent(comm->stream, ev, 0));
+    SIMQ_CHECK_HIP(hipStreamWaitEvent(comm->cs(), ev, 0));
     const int slot = (int)(comm->enqueued.load(std::memory_order_relaxed) % kEvents);
     comm->last_kind.store(2, std::memory_order_relaxed); comm->last_count.store(bytes, std::memory_order_relaxed);
     comm->enqueued.fetch_add(1, std::memory_order_release);
-    SIMQ_CHECK_RCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclInt8, root, comm->comm, comm->stream));
-    SIMQ_CHECK_HIP(hipEventRecord(comm->fin[slot], comm->stream));
+    SIMQ_CHECK_RCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclInt8, root, comm->comm, comm->cs()));
+    SIMQ_CHECK_HIP(hipEventRecord(comm->fin[slot], comm->cs()));
     comm->recorded.fetch_add(1, std::memory_order_release);
     return 0;
 }
@@ -232,8 +234,19 @@ int simq_comm_last_wait_ms(simq_comm* comm, float* ms) {
     return 0;
 }
 
+int simq_comm_adopt_stream(simq_comm* comm, void* stream) {
+    SIMQ_REQUIRE(comm, "comm_adopt_stream: NULL communicator");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (st == comm->stream_ext) return 0;
+    // collectives of ONE communicator must stay ordered: everything enqueued on the stream in use so far finishes first
+    SIMQ_CHECK_HIP(hipStreamSynchronize(comm->cs()));
+    comm->stream_ext = st;
+    return 0;
+}
+
 int simq_comm_destroy(simq_comm* comm) {
     if (!comm) return 0;
+    if (comm->cs()) (void)hipStreamSynchronize(comm->cs());
     if (comm->stream) (void)hipStreamSynchronize(comm->stream);
     if (comm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
     for (int i = 0; i < kEvents; ++i)

@@ -150,6 +150,7 @@ _SIGS = {
     'simq_forward_sync_null': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'simq_comm_unique_id': (c_int, [c_void_p]),
     'simq_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    'simq_comm_adopt_stream': (c_int, [c_void_p, c_void_p]),
     'simq_comm_world_size': (c_int, [c_void_p]),
     'simq_comm_rank': (c_int, [c_void_p]),
     'simq_comm_allreduce': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),

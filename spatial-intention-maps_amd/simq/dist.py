@@ -197,6 +197,14 @@ class Comm:
     def wait(self):
         self._lib.call('simq_comm_wait', self.handle, self._stream())
 
+    def adopt_stream(self, stream):
+        """Run the collectives on `stream` (a torch stream the caller has tested not to share the launch stream's hardware queue:
+        simq.learner.LearnerStreams.third) instead of the communicator's own; simq_comm_adopt_stream."""
+        key = None if stream is None else stream.cuda_stream
+        if getattr(self, '_adopted', 'unset') != key:
+            self._lib.call('simq_comm_adopt_stream', self.handle, None if stream is None else ctypes.c_void_p(stream.cuda_stream))
+            self._adopted, self._adopted_ref = key, stream
+
     def time_waits(self, on=True):
         """Bracket every simq_comm_wait with timing events (simq_comm_time_waits): exposed communication time of the data-parallel step."""
         self._lib.call('simq_comm_time_waits', self.handle, 1 if on else 0)

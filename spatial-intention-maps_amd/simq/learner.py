@@ -949,6 +949,10 @@ def _train_step_fused(policy_net, target_net, b, discount_factor, gB, lr, moment
     a.side_stream = side.cuda_stream if side is not None else None
     a.target_stream = early.cuda_stream if early is not None else None
     a.third_stream = ls.third.cuda_stream if side is not None else None
+    if comm is not None and side is not None:
+        # the gradient buckets travel on the learner's third stream: idle during the backward pass, and TESTED not to share the hardware queue of
+        # the launch stream (dgrads) or of the side stream (weight gradients) -- the communicator's own stream lands wherever the runtime puts it
+        comm.adopt_stream(ls.third)
     loss_host = None
     if sync:
         # train.py:137-139 (loss.item()) without synchronising the stream: the library copies the four sums to pinned memory as soon as
