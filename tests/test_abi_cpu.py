@@ -322,3 +322,47 @@ def test_the_python_host_keeps_no_process_wide_behaviour_switch_either():
     ring = sl.DeviceReplayBuffer(4, 4, device='cpu', upload_stream='index')
     assert ring.upload_stream == 'index' and ring.ring_on_upload_stream is False
     ring.sync_ring()                                        # (no device: nothing to wait for)
+
+
+def test_streams_of_a_step_are_sorted_by_hardware_queue(monkeypatch):
+    """Round 6, the logic of simq.learner._HardwareQueues on a stand-in for the device: streams land on 4 hardware queues round-robin (as the
+    HIP runtime deals them), "share a queue" is what the two-spin-kernel test would measure.  A learner's side / third / early streams must
+    avoid the launch stream's queue and each other's, the early stream must sit on the upload stream's queue when that is not the launch
+    stream's, and streams handed back are reused without a new test."""
+    import simq.learner as sl
+
+    class FakeStream:
+        made = 0
+
+        def __init__(self, device=None, priority=0):
+            FakeStream.made += 1
+            self.cuda_stream = 1000 + FakeStream.made
+            self.queue = FakeStream.made % 4
+
+    main = FakeStream()
+    main.queue = 0
+    tests = []
+    q = sl._HardwareQueues('fake')
+    q.ok = True
+    monkeypatch.setattr(q, '_shared', lambda a, b: tests.append(1) or a.queue == b.queue)
+    monkeypatch.setattr(sl.torch.cuda, 'Stream', FakeStream)
+    c_main = q.classify(main)
+    got = q.acquire({c_main}, 3)
+    assert len({s.queue for s in got}) == 3 and main.queue not in {s.queue for s in got}
+    assert q.classify(got[0]) != c_main and len(q.reps) <= 4
+    up = q.acquire({c_main}, 1)[0]
+    same = q.acquire_in(q.classify(up), {c_main})
+    assert same.queue == up.queue and same is not up
+    n_tests, n_made = len(tests), FakeStream.made
+    q.release(got)
+    again = q.acquire({c_main}, 3)
+    assert len(tests) == n_tests and FakeStream.made == n_made          # (from the pool: no new stream, no new test)
+    assert len({s.queue for s in again}) == 3 and main.queue not in {s.queue for s in again}
+    # fewer queues than roles: still never the launch stream's queue
+    FakeStream.made = 0
+    q2 = sl._HardwareQueues('fake2')
+    q2.ok = True
+    monkeypatch.setattr(q2, '_shared', lambda a, b: (a.queue % 2) == (b.queue % 2))
+    m2 = FakeStream()
+    got2 = q2.acquire({q2.classify(m2)}, 3)
+    assert len(got2) == 3 and all((s.queue % 2) != (m2.queue % 2) for s in got2)
