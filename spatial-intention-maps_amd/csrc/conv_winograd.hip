@@ -338,13 +338,14 @@ __global__ void __launch_bounds__(256) wino4f_input_kernel(const float* __restri
 // ReLU; for the dgrads -- backward.hip runs them in this form too -- the fused BatchNorm-backward sums of the layer(s) that consume the
 // gradient next).  One thread = one tile x 4 channels: 2 / 1 channels per thread (2-4 x the waves of a B = 32 launch) measured SLOWER
 // here and 4-6 % faster in the input transform, nothing on the step (profiles/r05_wino4f_channels_per_thread.txt).
-__global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restrict__ Mt, const EpiArgs p, int B, int H, int W, int C, int T) {
+__global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restrict__ Mt, const EpiArgs p, int B, int H, int W, int C, int T, int lanes) {
     __shared__ float red[4][256][4];
-    const int lanes = C >> 2, tpb = 256 / lanes;
+    // lanes = channel quads of this block's channel slice (blockIdx.y): see the launcher
+    const int tpb = 256 / lanes;
     const int cl = threadIdx.x % lanes, tl = threadIdx.x / lanes;
     const int th = H >> 2, tw = W >> 2;
     const size_t gstride = (size_t)T * C;
-    const int n = cl * 4;
+    const int n = (blockIdx.y * lanes + cl) * 4;
     const bool bnr = p.bnr_red1 != nullptr, bnr2 = bnr && p.bnr_red2 != nullptr;
     floatx4 bias = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bias, mu1 = bias, is1 = bias, mu2 = bias, is2 = bias, msc = bias, msh = bias;
 #pragma unroll
@@ -416,13 +417,14 @@ __global__ void __launch_bounds__(256) wino4f_output_kernel(const float* __restr
         red[2][threadIdx.x][c] = s2[c]; red[3][threadIdx.x][c] = s3[c];
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
+    for (int lc = threadIdx.x; lc < 4 * lanes; lc += 256) {      // channel lc of the slice lives in lane lc / 4, component lc % 4 of every tile lane group
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         for (int k = 0; k < tpb; ++k) {
-            const int src = k * lanes + (ch >> 2);
-            a0 += (double)red[0][src][ch & 3]; a1 += (double)red[1][src][ch & 3];
-            a2 += (double)red[2][src][ch & 3]; a3 += (double)red[3][src][ch & 3];
+            const int src = k * lanes + (lc >> 2);
+            a0 += (double)red[0][src][lc & 3]; a1 += (double)red[1][src][lc & 3];
+            a2 += (double)red[2][src][lc & 3]; a3 += (double)red[3][src][lc & 3];
         }
+        const int ch = blockIdx.y * lanes * 4 + lc;
         double* dst = p.stats ? p.stats : p.bnr_red1;
         unsafeAtomicAdd(dst + ch, a0);
         unsafeAtomicAdd(dst + C + ch, a1);
@@ -790,20 +792,29 @@ int launch_conv_winograd4(const float* x, const float* U4, float* y, const ConvG
     const int T4 = g.B * (g.Hin / 4) * (g.Win / 4);
     float* V = scratch;
     float* Mt = scratch + (size_t)36 * T4 * g.Cin;
-    const int tpb_in = 256 / (g.Cin / 4), tpb_out = 256 / (g.Cout / 4);
+    const int tpb_in = 256 / (g.Cin / 4);
     int bin = (T4 + tpb_in - 1) / tpb_in;
     if (bin > 4096) bin = 4096;
     if (in.on()) hipLaunchKernelGGL(wino4f_input_kernel<true>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
     else hipLaunchKernelGGL(wino4f_input_kernel<false>, dim3(bin), dim3(256), 0, stream, x, V, g.B, g.Hin, g.Win, g.Cin, T4, in);
     SIMQ_CHECK_LAUNCH();
     if (int rc = launch_gemm_batched(V, U4, Mt, T4, g.Cout, g.Cin, 36, stream, g.tune)) return rc;
-    int bout = (T4 + tpb_out - 1) / tpb_out;
+    // Round 6.  A launch that leaves BatchNorm sums (train-mode statistics; the dgrads' fused backward sums) ends with 2-4 fp64 atomics per
+    // channel and block, and its blocks all finish together: 576 blocks x 1024 sums onto 64 cache lines serialise (~6 ns each) into tens of
+    // microseconds -- the 512-channel launches took 32-95 us where the bare transform takes 19.  So such a launch cuts the channels into slices
+    // of `lanes` quads (blockIdx.y) and gives a block MORE TILES of fewer channels: the same blocks and bytes, 1 / (C / 4 / lanes) of the
+    // atomics per block (256-byte instead of 2-KB runs per tile and plane: still whole DRAM bursts).
+    static const int slice_quads = SIMQ_TUNE_INT("SIMQ_W4F_OUT_SLICE_QUADS", 16);      // (ablation build: 0 = whole channel range per block, rounds 2-5)
+    int lanes_out = g.Cout / 4;
+    if ((e.stats || e.bnr_red1) && slice_quads > 0 && lanes_out > slice_quads && lanes_out % slice_quads == 0) lanes_out = slice_quads;
+    const int tpb_o = 256 / lanes_out, slices = (g.Cout / 4) / lanes_out;
+    int bout = (T4 + tpb_o - 1) / tpb_o;
     // F(4x4,3x3) has a quarter of the tiles: at 512 channels a block is two tiles and B = 32 gives 576 blocks -- capped at 512, sixty-four
     // blocks did two grid-stride trips while the rest did one (the launch took the time of two).  Up to 1024 blocks, equal trips each.
-    bout = balanced_grid(bout, (e.stats || e.bnr_red1) ? 1024 : 4096);
+    bout = balanced_grid(bout, ((e.stats || e.bnr_red1) ? 1024 : 4096) / slices);
     const EpiArgs ea = make_epi(y, e);
     note_launch("winograd_f4");
-    hipLaunchKernelGGL(wino4f_output_kernel, dim3(bout), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T4);
+    hipLaunchKernelGGL(wino4f_output_kernel, dim3(bout, slices), dim3(256), 0, stream, Mt, ea, g.B, g.Hin, g.Win, g.Cout, T4, lanes_out);
     SIMQ_CHECK_LAUNCH();
     return 0;
 }
