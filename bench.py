@@ -91,6 +91,7 @@ def parse():
     ap.add_argument('--group-issue', default='defer', choices=['defer', 'stagger'], help="tools only: with --group-streams 1: 'defer' = enqueue every group's step, then wait for the losses (simq.train_groups); 'stagger' = wait for each group's loss before enqueueing the next group's step")
     ap.add_argument('--third-leg-split', type=int, default=0, choices=[0, 1], help='tools only: simq_plan_options.gemm_split of the third leg (1: the headline form again -- is a THIRD leg slower as such?)')
     ap.add_argument('--stream-skew', type=int, default=0, help='tools only: take this many streams from torch\'s stream pool before the learners do (which hardware queue a stream shares follows the order of creation: A/B)')
+    ap.add_argument('--single-rank-comm', action='store_true', help='tools only, N = 1: run the DATA-PARALLEL form of the step (backward phases, two gradient buckets all-reduced on a 1-rank RCCL communicator) on the one GPU a lease has')
     ap.add_argument('--replay', type=int, default=REPLAY_ITEMS, help='transitions resident in the HBM replay ring per net')
     ap.add_argument('--sustained-seconds', type=float, default=3.0, help='length of the sustained leg behind the timed window (0 = skip)')
     ap.add_argument('--watchdog-seconds', type=int, default=120, help='multi-rank runs: abort with a diagnosis when a phase makes no progress for this long')
@@ -294,9 +295,10 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     pg = None
-    if world > 1:
+    if world > 1 or args.single_rank_comm:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -493,7 +495,7 @@ def main():
                          'vs_timed_window': round(gB * len(groups) * n_done / total / value, 4), 'last_loss': info_s['loss']}
 
         # Exposed communication (extra key, outside every timed window): per rank, how long the main stream stood waiting in the step's last
-        # simq_comm_wait -- the un-overlapped part of gradient bucket 2 + the loss scalars (bucket 1 travels beside backward phase 2; DESIGN 6
+        # simq_comm_wait -- the un-overlapped part of gradient bucket 2 (bucket 1 travels beside backward phase 2, the loss scalars beside the whole backward pass; DESIGN 6
         # prices the exposed part at ~0.12 ms).  Timing events around the wait inside libsimq (simq_comm_time_waits); each query synchronises,
         # hence its own pass.
         exposed = None
@@ -507,7 +509,7 @@ def main():
             mine = torch.tensor([float(np.mean(exposed_log)), float(np.max(exposed_log))], dtype=torch.float64, device=dev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             torch.distributed.all_gather(allr, mine, group=pg)
-            exposed = {'what': 'ms per train() call the main stream waited in simq_comm_wait (bucket 2 + loss scalars not hidden behind backward phase 2)',
+            exposed = {'what': 'ms per train() call the main stream waited in simq_comm_wait (gradient bucket 2 not hidden behind backward phase 2)',
                        'calls_timed': len(exposed_log), 'per_rank_mean_ms': [round(float(t[0]), 4) for t in allr],
                        'per_rank_max_ms': [round(float(t[1]), 4) for t in allr]}
 

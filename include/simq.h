@@ -337,10 +337,12 @@ typedef struct simq_train_args {
     struct simq_comm* comm;      /* NULL: single process.  Otherwise the data-parallel form: `batch` is this rank's shard of a
                                   * minibatch of `global_batch` transitions; head + layer4 gradients (simq_grad_bucket_split) are
                                   * summed over the ranks while layers 3..1 + stem are still being differentiated, then the rest
-                                  * and out4; every rank applies the identical clip + SGD.  num_nonfinal may then be 0 (a shard
+                                  * (out4 is summed over the ranks right behind the TD / Huber launch: three collectives per step,
+                                  * in this order on every rank); every rank applies the identical clip + SGD.  num_nonfinal may then be 0 (a shard
                                   * whose transitions are all terminal still has to join the collectives). */
     float* loss_host;            /* NULL, or 4 floats of PINNED host memory: out4 is copied there as soon as it is final (behind the
-                                  * TD / Huber launch -- behind the all-reduce with `comm`), on the library's own copy stream.  The
+                                  * TD / Huber launch; with `comm`: behind the all-reduce of out4 that follows it, on the
+                                  * communicator's stream), on the library's own copy stream or the caller's third stream.  The
                                   * host then calls simq_train_loss_wait() instead of synchronising the stream: train.py:137-139's
                                   * loss.item() without waiting for backward + SGD, so that the next step is enqueued while this one runs */
     void* target_stream;         /* NULL, or a stream the CALLER has already ordered behind everything the target-net forward reads (next_state,
@@ -402,7 +404,7 @@ int simq_comm_progress(simq_comm* comm, int64_t out[4]);
 /* Exposed communication time (no reference counterpart: measurement aid of the data-parallel step).  With timing on, every simq_comm_wait
  * brackets the consumer stream's wait with a pair of timing events; simq_comm_last_wait_ms blocks until the LAST wait has been passed and
  * returns how long the consumer stream stood waiting for collectives still in flight -- inside simq_train_step that is the un-overlapped
- * part of the second gradient bucket + the loss scalars (bucket 1 travels beside backward phase 2).  ~0 when everything was hidden. */
+ * part of the second gradient bucket (bucket 1 travels beside backward phase 2, the loss scalars beside the whole backward pass).  ~0 when everything was hidden. */
 int simq_comm_time_waits(simq_comm* comm, int on);
 int simq_comm_last_wait_ms(simq_comm* comm, float* ms);
 int simq_comm_destroy(simq_comm* comm);

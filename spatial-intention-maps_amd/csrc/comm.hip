@@ -127,6 +127,8 @@ int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream) {
     return comm_wait(c, st);
 }
 
+hipStream_t comm_stream(simq_comm* c) { return c ? c->cs() : nullptr; }
+
 int comm_wait(simq_comm* c, hipStream_t consumer) {
     SIMQ_REQUIRE(c, "comm_wait: NULL communicator");
     SIMQ_CHECK_HIP(hipEventRecord(c->done, c->cs()));

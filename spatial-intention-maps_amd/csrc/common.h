@@ -288,5 +288,6 @@ int launch_replay_gather(const float* ring, int64_t item_floats, const int64_t* 
 int comm_allreduce(simq_comm* c, void* buf, int64_t count, int dtype, hipStream_t producer);
 int comm_reduce_f64(void* comm, double* buf, int64_t count, void* stream);   // simq_reduce_fn over a communicator
 int comm_wait(simq_comm* c, hipStream_t consumer);
+hipStream_t comm_stream(simq_comm* c);       // the stream the communicator's collectives run on (its own, or the adopted one)
 
 }  // namespace simq

@@ -180,6 +180,15 @@ int simq_train_step(const simq_train_args* a) {
                        a->out4, a->dq, main));                                                                       // train.py:115,126-129
     if (a->loss_host && !a->comm)                                                          // train.py:137-139: the loss is final here
         RC(loss_copy(p, a->out4, a->loss_host, main, true, (three && a->third_stream) ? static_cast<hipStream_t>(a->third_stream) : nullptr));
+    if (a->comm) {
+        // data parallel: the four loss sums are summed over the ranks HERE, not behind the last gradient bucket, and copied to the host on the
+        // communicator's stream right behind that all-reduce -- a caller that waits for the loss (simq_train_loss_wait) gets it when the forwards
+        // of all ranks are done, as in the single-GPU form, and enqueues its next step while this one's backward pass runs.  Measured with a
+        // 1-rank communicator on one GPU (profiles/r06_ab_early_target_delay_dp.txt): with the loss behind bucket 2 the host stood still for the
+        // whole backward pass and the data-parallel form was 6.5 % slower than the plain step.
+        RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
+        if (a->loss_host) RC(loss_copy(p, a->out4, a->loss_host, comm_stream(a->comm), false));
+    }
     const float gscale = 1.0f / (float)a->global_batch;
     auto backward = [&](int phase) {                                                                                 // train.py:131-132
         if (int rc = check_sync(sync, B)) return rc;
@@ -197,9 +206,7 @@ int simq_train_step(const simq_train_args* a) {
         RC(comm_allreduce(a->comm, a->grads + split, p->nparams - split, SIMQ_COMM_F32, main));
         RC(backward(2));
         RC(comm_allreduce(a->comm, a->grads, split, SIMQ_COMM_F32, main));
-        RC(comm_allreduce(a->comm, a->out4, 4, SIMQ_COMM_F32, main));
         RC(comm_wait(a->comm, main));
-        if (a->loss_host) RC(loss_copy(p, a->out4, a->loss_host, main, false));            // (summed over the ranks)
     }
     // (both phases of the data-parallel form together visit every block once.)  A step that recorded no such event -- early_target_after_block < 0 --
     // clears the mark: a later step must not wait on an event of some unrelated earlier walk
