@@ -386,6 +386,66 @@ def test_dp_syncbn_over_rccl_between_two_gpus(tmp_path, golden_dir):
     test_dp_step_with_syncbn_equals_the_single_device_reference_step(tmp_path, golden_dir, 'train_c4o2_b8', 2, 'nccl', True)
 
 
+def _loss_timing_worker(port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'spatial-intention-maps_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        import simq
+        from simq import dist as sdist
+        from simq.learner import train_step
+        cin, cout, B = 4, 2, 64
+        policy, target = _make_nets(simq, cin, cout, 77, 'fp32', dev)
+        comm = sdist.Comm(dist.group.WORLD)
+        ring = simq.DeviceReplayBuffer(256, cin, device=dev)
+        for t in _transitions(cin, cout, 256, 5, 0.1):
+            ring.push(*t)
+        import time
+        busy, losses, sums = [], [], []
+        for s in range(7):
+            shard = ring.gather(ring.sample_indices(B), allow_all_final=True)
+            info = train_step(policy, target, shard, cases.GAMMA, B, cases.LR, cases.MOMENTUM, cases.WEIGHT_DECAY, cases.CLIP,
+                              use_double_dqn=True, global_batch=B, comm=comm)
+            t0 = time.perf_counter()                     # the loss is on the host; how much of the step is the device still to run?
+            torch.cuda.synchronize(dev)
+            busy.append((time.perf_counter() - t0) * 1e3)
+            losses.append(info['loss'])
+            sums.append(float(torch.nn.functional.smooth_l1_loss(policy._last['q_sa'], policy._last['y'], reduction='sum')) / B)
+        comm.close()
+        np.savez(os.path.join(out_dir, 'loss_timing.npz'), busy=np.array(busy), loss=np.array(losses), loss_from_rows=np.array(sums))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_step_hands_the_loss_to_the_host_before_its_backward_pass_ends(tmp_path):
+    """Round 6: in the data-parallel form of simq_train_step the four loss sums are all-reduced right behind the TD / Huber launch and copied
+    to the host from the communicator's stream -- not behind the second gradient bucket.  A host that reads the loss every step
+    (train.py:137-139) therefore gets it while the backward pass of the same step still runs and enqueues the next step beside it (with the
+    loss behind bucket 2 the 1-rank form measured 6.5 % slower than the plain step: profiles/r06_ab_early_target_delay_dp.txt).  1-rank RCCL
+    communicator, 64 transitions: when train_step returns, the device still has more than 1.5 ms of the step to run (the backward pass of 64
+    transitions takes ~5 ms; behind bucket 2 only clip + SGD + the weight-cache refresh, ~0.2 ms, were left) in at least 5 of the 6
+    steady-state steps (a descheduled host thread may miss one), and the loss it returned is the mean Huber term of the rows the step left."""
+    ctx = mp.get_context('spawn')
+    p = ctx.Process(target=_loss_timing_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(600)
+    if p.is_alive():
+        p.kill()
+        pytest.fail('the 1-rank data-parallel worker did not finish (hang)')
+    assert p.exitcode == 0
+    r = np.load(os.path.join(str(tmp_path), 'loss_timing.npz'))
+    print('device time left when the loss reached the host, ms per step:', np.round(r['busy'], 2))
+    assert int((r['busy'][1:] > 1.5).sum()) >= 5, r['busy']
+    assert np.allclose(r['loss'], r['loss_from_rows'], rtol=1e-5, atol=1e-7), (r['loss'], r['loss_from_rows'])
+
+
 def _bench_line(argv, timeout=900):
     """bench.py started BARE (no launcher, no WORLD_SIZE in the environment) -- the way the driver starts `--gpus 1` -- and its one
     JSON line."""
