@@ -1191,10 +1191,8 @@ def train_groups(cfg, policy_nets, target_nets, optimizers, batches, transform_f
     stream of its own (LearnerStreams): measured on one MI355X this is level with the sequential order (configs[3]: 5 362 against 5 349 tr/s at 256
     per net, 5 009 against 5 047 at 64 -- a single learner's four streams already occupy the four hardware queues and never more than two
     kernels fit the device at once), hence off by default; the mechanism is tested bit-identical and is there for parts / runtimes where it pays.
-    With concurrent=True every learner issues its step on a launch stream of its own (LearnerStreams) and the host enqueues ALL
-    steps before it waits for the first loss, so the steps run side by side on the device: one net's HBM-bound phases (Winograd transforms,
-    BatchNorm passes, optimiser step) under the other's matrix-core phases.  Per net the same kernels run on the same operands in the same
-    order: every net's results are what the sequential loop gives (bit-identical on deterministic plans, tests/test_gpu_overlap.py).
+    Per net the same kernels run on the same operands in the same order either way: every net's results are what the sequential loop gives
+    (bit-identical on deterministic plans, tests/test_gpu_overlap.py).
     No join at the end: anything that touches one of the nets later on another stream is ordered behind its step
     (FCN._order_behind_last_step).
     batches[i]: what replay_buffers[i].sample(cfg.batch_size) returned (a DeviceBatch or the reference's Transition-of-tuples), or None to
