@@ -284,7 +284,8 @@ int simq_forward_sync_null(const simq_plan* plan, int layout_batch, float* d_bnb
 int simq_q_argmax(const float* d_q, int rows, int n, int64_t* d_index, float* d_max, void* stream);
 /* d_out[i] = d_q[i][d_index[i]]  (train.py:115,122) */
 int simq_q_gather(const float* d_q, int rows, int n, const int64_t* d_index, float* d_out, void* stream);
-/* next_state_values[nonfinal_pos[i]] = d_values[i]; others 0 (train.py:116,122) */
+/* next_state_values[nonfinal_pos[i]] = d_values[i]; others 0 (train.py:116,122); 1 <= batch <= 4096 (the minibatch limit of every entry point),
+ * 0 <= n_nonfinal <= batch */
 int simq_scatter_next_values(const float* d_values, const int32_t* d_nonfinal_pos, int n_nonfinal,
                              float* d_next_state_values, int batch, void* stream);
 /* y = r + gamma*v ; td = |q_sa - y| ; loss = mean Huber(delta=1) ; dq = one-hot dLoss/dQ

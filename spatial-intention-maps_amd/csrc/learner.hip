@@ -51,10 +51,10 @@ __global__ void q_gather_kernel(const float* __restrict__ q, int rows, int n, co
 
 __global__ void scatter_next_values_kernel(const float* __restrict__ values, const int32_t* __restrict__ pos, int n,
                                            float* nsv, int batch) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < batch) nsv[i] = 0.f;
-    __syncthreads();   // single-block launch: zero fill completes before the scatter
-    if (i < n) nsv[pos[i]] = values[i];
+    // ONE block walks the rows: the zero fill completes (block barrier) before the scatter
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) nsv[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) nsv[pos[i]] = values[i];
 }
 
 __global__ void __launch_bounds__(256) td_huber_kernel(const float* __restrict__ q, int batch, int n,
@@ -244,7 +244,7 @@ int launch_q_gather(const float* q, int rows, int n, const int64_t* index, float
 
 int launch_scatter_next_values(const float* values, const int32_t* pos, int n, float* nsv, int batch,
                                hipStream_t stream) {
-    SIMQ_REQUIRE(batch <= 1024 && n <= batch, "scatter_next_values: batch=%d n=%d unsupported", batch, n);
+    SIMQ_REQUIRE(batch >= 1 && batch <= 4096 && n >= 0 && n <= batch, "scatter_next_values: batch=%d n=%d unsupported (1 <= batch <= 4096, 0 <= n <= batch)", batch, n);
     hipLaunchKernelGGL(scatter_next_values_kernel, dim3(1), dim3(1024), 0, stream, values, pos, n, nsv, batch);
     SIMQ_CHECK_LAUNCH();
     return 0;

@@ -196,6 +196,24 @@ def test_td_huber_and_scatter(L):
     assert int((dq != 0).sum()) <= B
 
 
+@pytest.mark.parametrize('B,nf', [(1, 0), (1, 1), (1024, 1024), (1025, 700), (4096, 3700)], ids=['one_terminal', 'one', 'b1024_all', 'b1025', 'b4096_max'])
+def test_scatter_next_values_edge_sizes(L, B, nf):
+    """next_state_values[non_final_mask] = ... (train.py:116,122) at the edges: no non-final row, every row, and the library's largest minibatch
+    (4096 rows: the limit of the forward / backward entry points; the kernel is one block walking the rows) -- and one row more is refused."""
+    g = torch.Generator().manual_seed(B + nf)
+    pos = torch.randperm(B, generator=g)[:nf].sort().values.to(torch.int32)
+    vals = torch.randn(max(nf, 1), generator=g)
+    ref = torch.zeros(B)
+    ref[pos.long()] = vals[:nf]
+    pos_d, vals_d = dev(pos) if nf else torch.zeros(1, dtype=torch.int32, device='cuda'), dev(vals)
+    nsv = torch.full((B + 3,), 9.0, device='cuda')
+    L.lib.call('simq_scatter_next_values', L.ptr(vals_d), L.ptr(pos_d), nf, L.ptr(nsv), B, L.stream_ptr())
+    assert torch.equal(nsv[:B].cpu(), ref) and bool((nsv[B:] == 9.0).all())
+    if B == 4096:
+        with pytest.raises(Exception, match='unsupported'):
+            L.lib.call('simq_scatter_next_values', L.ptr(vals_d), L.ptr(pos_d), nf, L.ptr(nsv), B + 1, L.stream_ptr())
+
+
 @pytest.mark.parametrize('count,max_norm', [(1003, 100.0), (4096, 0.5), (11249826, 100.0)])
 def test_clip_sgd(L, count, max_norm):
     """clip_grad_norm_ + SGD(momentum 0.9, wd 1e-4) (train.py:133-135,186) restated in fp64.
