@@ -200,6 +200,31 @@ def test_autograd_path_reference_style_train(simq_mod, case, golden_dir):
     assert abs(norms[0] - float(g['total_norm64'])) <= 5e-2 * float(g['total_norm64'])
 
 
+@pytest.mark.parametrize('cin,cout,B', [(4, 3, 3), (5, 4, 4)], ids=['c4o3_b3', 'c5o4_b4'])
+def test_fused_train_with_three_and_four_output_channels_against_the_live_oracle(simq_mod, cin, cout, B):
+    """networks.FCN takes any num_output_channels (networks.py:8-14); the reference's robot types use 1 or 2, libsimq's plans go to 4 (head
+    kernels, Q-map reductions and the one-hot backward are written for Cout <= 4).  No golden fixture exists for 3 / 4: one train() call against
+    the oracle run live in fp64 (loss and td error at 1e-4, the gradient at the bar of the golden cases)."""
+    cfg = cases.make_cfg(B)
+    batch = cases.make_batch(cin, cout, B, 1)
+    spec = ofcn.state_spec(cin, cout)
+    policy = make_net(simq_mod, cin, cout, 2, training=True)
+    target = make_net(simq_mod, cin, cout, 1002, training=False)
+    opt = torch.optim.SGD(policy.parameters(), lr=cases.LR, momentum=cases.MOMENTUM, weight_decay=cases.WEIGHT_DECAY)
+    st, tg = cases.oracle_state(cin, cout, 2, torch.float64), cases.oracle_state(cin, cout, 1002, torch.float64)
+    ex64 = {}
+    ref = olearner.train_step(cfg, st, tg, spec, [None] * len(olearner.grad_keys(spec)), batch, cases.GAMMA, cases.LR, cases.MOMENTUM,
+                              cases.WEIGHT_DECAY, dtype=torch.float64, extras=ex64)
+    info = simq_mod.train(cfg, policy, target, opt, batch, olearner.apply_transform, cases.GAMMA)
+    assert rel(info['loss'], ref['loss']) < TOL and rel(info['td_error'], ref['td_error']) < TOL
+    assert policy._last['q'].shape[1] == cout
+    tn = float(policy._simq_opt_state.total_norm.item())
+    coef = min(1.0, cases.CLIP / (tn + 1e-6))
+    got = {k: v / coef for k, v in grads_to_reference_layout(policy).items()}
+    err = global_rel_l2(got, ex64['grads'])
+    assert err <= 5e-2, 'gradient rel-L2 error %.3g vs fp64' % err
+
+
 @pytest.mark.parametrize('case', cases.TRAIN_CASES + cases.TRAIN_CASES_CIN, ids=[c[0] for c in cases.TRAIN_CASES + cases.TRAIN_CASES_CIN])
 def test_fused_train_vs_golden_and_oracle(simq_mod, case, golden_dir):
     """simq.train (drop-in signature of train.py:108) -- two consecutive calls.  train_c{3,6,7,10}*: the reference's other input-channel
